@@ -1,0 +1,75 @@
+/* oracle/fuif_oracle.h -- TEST INFRASTRUCTURE ONLY: CPU restatement of the FUIF decode path.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this library.
+ * The product (fuif_amd/, libfuifgpu.so) never links, imports or calls it.
+ */
+#ifndef FUIF_ORACLE_H
+#define FUIF_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* reference: image/image.h:54-91 (Channel), planes widened to int32 (image/image.h:39-45 variant) */
+typedef struct {
+    int32_t *data;
+    size_t size; /* number of samples held (0 = never decoded), mirrors data.size() */
+    int w, h;
+    int minval, maxval, zero;
+    int q;
+    int hshift, vshift, hcshift, vcshift;
+    int component;
+} fo_channel;
+
+/* reference: transform/transform.h:77-106 */
+typedef struct {
+    int id;
+    int nparams;
+    int *params;
+} fo_transform;
+
+/* reference: image/image.h:98-129 */
+typedef struct {
+    fo_channel *ch;
+    int nch;
+    fo_transform *tr;
+    int ntr;
+    int w, h, minval, maxval;
+    int nb_channels, real_nb_channels, nb_meta_channels, colormodel;
+    int nb_frames;
+    int max_properties;
+    int responsive_offsets[5];
+    int error;
+    /* statistics (not in the reference): */
+    uint64_t stat_symbols, stat_rac_decisions, stat_tree_steps;
+    size_t bytes_consumed;
+} fo_image;
+
+/* io_kind 0: FileIO semantics (feof only after a failed read; what the CLI uses, fileio.h:55-63)
+ * io_kind 1: BlobReader semantics (EOF as soon as the cursor reaches the end, fileio.h:100-102) */
+fo_image *fo_decode(const uint8_t *blob, size_t n, int preview, int io_kind, int *ok);
+int fo_undo_transforms(fo_image *img, int keep);
+void fo_free(fo_image *img);
+
+void fo_image_info(fo_image *img, int32_t *out10);
+void fo_channel_info(fo_image *img, int c, int32_t *out12);
+void fo_channel_data(fo_image *img, int c, int32_t *out);
+void fo_transform_info(fo_image *img, int t, int32_t *out, int cap);
+void fo_stats(fo_image *img, uint64_t *out4);
+
+/* known-answer helpers for unit tests */
+void fo_build_table(uint16_t *table8192, uint32_t alpha, int cut);
+void fo_symbol_chance_init(uint16_t *ch31, int zero_chance);
+int fo_smooth_tendency(int B, int a, int n);
+void fo_idct8x8(double *block64);
+int fo_kat_simple_symbols(const uint8_t *buf, size_t n, int count, int min, int max, int32_t *out, int *pos);
+int fo_kat_uniform_symbols(const uint8_t *buf, size_t n, int count, int min, int len, int32_t *out, int *pos);
+int fo_kat_final_symbols(const uint8_t *buf, size_t n, int count, int zero_chance, int min, int max, int32_t *out, int *pos);
+int fo_kat_read_bits(const uint8_t *buf, size_t n, int count, int32_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
