@@ -1,0 +1,255 @@
+"""fuif_amd -- MI355X (gfx950) native FUIF decode path.
+
+Python host mirror of the reference's decode interface on top of the C-ABI library
+``libfuifgpu.so`` (include/fuifgpu.h):
+
+    reference (C++)                               here
+    --------------------------------------------  ---------------------------------------------
+    fuif_decode<IO>(io, image, options)           Batch.upload(blobs, preview) + Batch.decode()
+      (encoding/encoding.cpp:599-720)
+    Image::undo_transforms()                      Batch.undo_transforms()
+      (image/image.cpp:94-115)
+    Image / Channel geometry after meta_apply     Plan.coded_channels / Plan.output_channels
+
+There is NO CPU fallback: everything that touches pixels runs in HIP kernels, and importing a
+Batch without the built extension or without a GPU raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libfuifgpu.so")
+_SOURCES = ["plan.cpp", "maniac_decode.hip", "transforms.hip", "capi.hip"]
+_lib = None
+
+
+class FuifGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("fuifgpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build(force=False, verbose=False):
+    """Compile libfuifgpu.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_HERE, "csrc", s) for s in _SOURCES]
+    deps = srcs + [os.path.join(_HERE, "csrc", h) for h in ("fuifgpu_internal.h", "maniac_decode.h", "transforms.h")]
+    deps.append(os.path.join(_HERE, "..", "include", "fuifgpu.h"))
+    if not force and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return _LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-o", _LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return _LIB_PATH
+
+
+class ImageInfo(C.Structure):
+    _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("bit_depth", C.c_int32), ("maxval", C.c_int32),
+                ("nb_channels", C.c_int32), ("colormodel", C.c_int32), ("max_properties", C.c_int32),
+                ("nb_frames", C.c_int32), ("nb_transforms", C.c_int32), ("nb_coded_channels", C.c_int32),
+                ("nb_output_channels", C.c_int32), ("nb_ops", C.c_int32), ("responsive_offsets", C.c_int32 * 5),
+                ("data_start", C.c_int32), ("coef_elems", C.c_int64), ("out_elems", C.c_int64),
+                ("tmp_elems", C.c_int64), ("signature", C.c_uint64)]
+
+
+class ChannelDesc(C.Structure):
+    _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("hshift", C.c_int32), ("vshift", C.c_int32),
+                ("hcshift", C.c_int32), ("vcshift", C.c_int32), ("component", C.c_int32), ("reserved", C.c_int32),
+                ("offset", C.c_int64)]
+
+
+# every symbol include/fuifgpu.h declares (tests check that the library exports all of them)
+ABI_SYMBOLS = [
+    "fuifgpu_strerror", "fuifgpu_last_error", "fuifgpu_abi_version", "fuifgpu_plan_create", "fuifgpu_plan_destroy",
+    "fuifgpu_plan_info", "fuifgpu_plan_coded_channel", "fuifgpu_plan_output_channel", "fuifgpu_plan_transform",
+    "fuifgpu_build_chance_table", "fuifgpu_batch_create", "fuifgpu_batch_destroy", "fuifgpu_batch_upload",
+    "fuifgpu_batch_decode", "fuifgpu_batch_undo_transforms", "fuifgpu_batch_sync", "fuifgpu_batch_status",
+    "fuifgpu_batch_channel_meta", "fuifgpu_batch_coef_ptr", "fuifgpu_batch_out_ptr", "fuifgpu_batch_download_coef",
+    "fuifgpu_batch_download_out", "fuifgpu_batch_last_timing", "fuifgpu_inv_hsqueeze", "fuifgpu_inv_vsqueeze",
+    "fuifgpu_inv_ycocg", "fuifgpu_inv_ycbcr", "fuifgpu_idct8x8", "fuifgpu_upsample",
+]
+
+
+def lib():
+    """Load libfuifgpu.so; raises if the HIP extension was not built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError("fuif_amd/libfuifgpu.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(_LIB_PATH)
+    vp, i32p, u8p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    L.fuifgpu_strerror.restype = C.c_char_p; L.fuifgpu_strerror.argtypes = [C.c_int]
+    L.fuifgpu_last_error.restype = C.c_char_p; L.fuifgpu_last_error.argtypes = []
+    L.fuifgpu_abi_version.restype = C.c_int
+    L.fuifgpu_plan_create.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(vp)]
+    L.fuifgpu_plan_destroy.argtypes = [vp]; L.fuifgpu_plan_destroy.restype = None
+    L.fuifgpu_plan_info.argtypes = [vp, C.POINTER(ImageInfo)]
+    L.fuifgpu_plan_coded_channel.argtypes = [vp, C.c_int, C.POINTER(ChannelDesc)]
+    L.fuifgpu_plan_output_channel.argtypes = [vp, C.c_int, C.POINTER(ChannelDesc)]
+    L.fuifgpu_plan_transform.argtypes = [vp, C.c_int, i32p, vp, C.c_int, i32p]
+    L.fuifgpu_build_chance_table.argtypes = [vp, C.c_uint32, C.c_int]; L.fuifgpu_build_chance_table.restype = None
+    L.fuifgpu_batch_create.argtypes = [vp, C.c_int, C.c_size_t, vp, vp, C.c_int, C.POINTER(vp)]
+    L.fuifgpu_batch_destroy.argtypes = [vp]; L.fuifgpu_batch_destroy.restype = None
+    L.fuifgpu_batch_upload.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, vp]
+    L.fuifgpu_batch_decode.argtypes = [vp, vp]
+    L.fuifgpu_batch_undo_transforms.argtypes = [vp, vp]
+    L.fuifgpu_batch_sync.argtypes = [vp, vp]
+    L.fuifgpu_batch_status.argtypes = [vp, vp, vp]
+    L.fuifgpu_batch_channel_meta.argtypes = [vp, C.c_int, vp]
+    L.fuifgpu_batch_coef_ptr.argtypes = [vp, C.c_int]; L.fuifgpu_batch_coef_ptr.restype = vp
+    L.fuifgpu_batch_out_ptr.argtypes = [vp, C.c_int]; L.fuifgpu_batch_out_ptr.restype = vp
+    L.fuifgpu_batch_download_coef.argtypes = [vp, C.c_int, vp, vp]
+    L.fuifgpu_batch_download_out.argtypes = [vp, C.c_int, vp, vp]
+    L.fuifgpu_batch_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.fuifgpu_inv_hsqueeze.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, vp]
+    L.fuifgpu_inv_vsqueeze.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, vp]
+    L.fuifgpu_inv_ycocg.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    L.fuifgpu_inv_ycbcr.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    L.fuifgpu_idct8x8.argtypes = [C.POINTER(vp), C.c_int, C.c_int, vp, C.c_int, vp]
+    L.fuifgpu_upsample.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    _lib = L
+    return L
+
+
+def _check(code):
+    if code != 0:
+        L = lib()
+        msg = L.fuifgpu_strerror(code).decode()
+        last = L.fuifgpu_last_error().decode()
+        raise FuifGpuError(code, msg + (" (" + last + ")" if last else ""))
+
+
+class Plan:
+    """Parsed header + channel table + inverse schedule of one stream (host only)."""
+
+    def __init__(self, blob):
+        L = lib()
+        self._h = C.c_void_p()
+        _check(L.fuifgpu_plan_create(bytes(blob[:65536]) if len(blob) > 65536 else bytes(blob), min(len(blob), 65536), C.byref(self._h)))
+        self.info = ImageInfo()
+        _check(L.fuifgpu_plan_info(self._h, C.byref(self.info)))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.fuifgpu_plan_destroy(self._h)
+            self._h = None
+
+    def _channels(self, fn, n):
+        out = []
+        for i in range(n):
+            d = ChannelDesc()
+            _check(fn(self._h, i, C.byref(d)))
+            out.append({k: int(getattr(d, k)) for k, _ in ChannelDesc._fields_ if k != "reserved"})
+        return out
+
+    @property
+    def coded_channels(self):
+        return self._channels(lib().fuifgpu_plan_coded_channel, self.info.nb_coded_channels)
+
+    @property
+    def output_channels(self):
+        return self._channels(lib().fuifgpu_plan_output_channel, self.info.nb_output_channels)
+
+    @property
+    def transforms(self):
+        out = []
+        for i in range(self.info.nb_transforms):
+            tid, n = C.c_int32(), C.c_int32()
+            buf = np.zeros(1024, np.int32)
+            _check(lib().fuifgpu_plan_transform(self._h, i, C.byref(tid), buf.ctypes.data, 1024, C.byref(n)))
+            out.append((int(tid.value), [int(v) for v in buf[: n.value]]))
+        return out
+
+
+class Batch:
+    """Device state for ``n_images`` streams sharing one plan (geometry + transform chain)."""
+
+    def __init__(self, plan, n_images, blob_capacity, coef_ptr=None, out_ptr=None, tmp_images=0):
+        L = lib()
+        self.plan = plan
+        self.n = n_images
+        self._h = C.c_void_p()
+        _check(L.fuifgpu_batch_create(plan._h, n_images, blob_capacity, coef_ptr, out_ptr, tmp_images, C.byref(self._h)))
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.fuifgpu_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def upload(self, blobs, preview=-1, stream=None):
+        n = len(blobs)
+        arr = (C.c_char_p * n)(*[C.c_char_p(b) for b in blobs])
+        sizes = (C.c_size_t * n)(*[len(b) for b in blobs])
+        self._keep = (blobs, arr, sizes)
+        _check(lib().fuifgpu_batch_upload(self._h, arr, sizes, n, preview, stream))
+        self.n_loaded = n
+
+    def decode(self, stream=None):
+        _check(lib().fuifgpu_batch_decode(self._h, stream))
+
+    def undo_transforms(self, stream=None):
+        _check(lib().fuifgpu_batch_undo_transforms(self._h, stream))
+
+    def sync(self, stream=None):
+        _check(lib().fuifgpu_batch_sync(self._h, stream))
+
+    def status(self):
+        st = np.zeros(self.n_loaded, np.int32)
+        used = np.zeros(self.n_loaded, np.uint32)
+        _check(lib().fuifgpu_batch_status(self._h, st.ctypes.data, used.ctypes.data))
+        return st, used
+
+    def channel_meta(self, image):
+        m = np.zeros((self.plan.info.nb_coded_channels, 4), np.int32)
+        _check(lib().fuifgpu_batch_channel_meta(self._h, image, m.ctypes.data))
+        return m
+
+    def coef_ptr(self, image=0):
+        return lib().fuifgpu_batch_coef_ptr(self._h, image)
+
+    def out_ptr(self, image=0):
+        return lib().fuifgpu_batch_out_ptr(self._h, image)
+
+    def timing(self):
+        a, b = C.c_float(), C.c_float()
+        _check(lib().fuifgpu_batch_last_timing(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def coef_planes(self, image):
+        """coded channel planes of one image as a list of (h,w) int32 arrays (device -> host)"""
+        slab = np.zeros(max(self.plan.info.coef_elems, 1), np.int32)
+        _check(lib().fuifgpu_batch_download_coef(self._h, image, slab.ctypes.data, None))
+        return [slab[c["offset"]: c["offset"] + c["w"] * c["h"]].reshape(c["h"], c["w"]).copy() for c in self.plan.coded_channels]
+
+    def out_planes(self, image):
+        slab = np.zeros(max(self.plan.info.out_elems, 1), np.int32)
+        _check(lib().fuifgpu_batch_download_out(self._h, image, slab.ctypes.data, None))
+        return [slab[c["offset"]: c["offset"] + c["w"] * c["h"]].reshape(c["h"], c["w"]).copy() for c in self.plan.output_channels]
+
+
+def decode_batch(blobs, preview=-1, undo=True):
+    """Decode same-geometry streams on the GPU; returns (list of per-image output planes, status)."""
+    plan = Plan(blobs[0])
+    cap = sum(len(b) for b in blobs)
+    batch = Batch(plan, len(blobs), cap)
+    try:
+        batch.upload(blobs, preview)
+        batch.decode()
+        if undo:
+            batch.undo_transforms()
+        batch.sync()
+        st, used = batch.status()
+        outs = [batch.out_planes(i) if undo else batch.coef_planes(i) for i in range(len(blobs))]
+        return outs, st
+    finally:
+        batch.close()

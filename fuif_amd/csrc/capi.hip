@@ -1,0 +1,431 @@
+// fuif_amd/csrc/capi.hip -- the extern "C" layer of libfuifgpu.so (see include/fuifgpu.h).
+//
+// Host-side batch management for the MI355X FUIF decode path: staging of compressed streams in
+// HBM, one entropy-kernel launch per batch, and the inverse-transform schedule replayed over
+// chunks of images so that the TMP slab stays small next to the 288 GB of HBM the coefficient and
+// output slabs are sized for.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fuifgpu.h"
+#include "fuifgpu_internal.h"
+#include "maniac_decode.h"
+#include "transforms.h"
+
+using namespace fuifgpu;
+
+struct fuifgpu_plan {
+    Plan plan;
+};
+
+struct fuifgpu_batch {
+    Plan plan;
+    int n = 0;
+    int n_loaded = 0;
+    // device state
+    uint8_t *d_blobs = nullptr;
+    size_t blob_cap = 0;
+    StreamJob *d_jobs = nullptr;
+    ChannelGeom *d_geom = nullptr;
+    ChannelMeta *d_meta = nullptr;
+    int32_t *d_status = nullptr;
+    uint32_t *d_consumed = nullptr;
+    uint16_t *d_tables = nullptr;
+    uint8_t *d_scratch = nullptr;
+    size_t scratch_stride = 0, leaves_off = 0, stack_off = 0;
+    int max_nodes = kMaxNodes;
+    int32_t *d_coef = nullptr, *d_out = nullptr, *d_tmp = nullptr;
+    bool own_coef = false, own_out = false;
+    int tmp_images = 0;
+    PlaneRef *d_list = nullptr;
+    // host staging (pinned)
+    uint8_t *h_blobs = nullptr;
+    std::vector<StreamJob> jobs;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool decode_timed = false, transform_timed = false;
+};
+
+static thread_local std::string g_last_error;
+
+static int hip_fail(hipError_t e, const char *what) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return FUIFGPU_E_HIP;
+}
+#define HIPCHK(call)                                      \
+    do {                                                  \
+        hipError_t e__ = (call);                          \
+        if (e__ != hipSuccess) return hip_fail(e__, #call); \
+    } while (0)
+
+namespace fuifgpu {
+size_t maniac_scratch_bytes(int max_nodes, size_t *leaves_off, size_t *stack_off) {
+    size_t nodes = ((size_t)(max_nodes + 1) * 8 + 255) / 256 * 256;
+    size_t leaves = ((size_t)((max_nodes + 1) / 2 + 1) * kLeafStride * 2 + 255) / 256 * 256;
+    size_t stack = ((size_t)kTreeStackDepth * 24 + 255) / 256 * 256;
+    *leaves_off = nodes;
+    *stack_off = nodes + leaves;
+    return nodes + leaves + stack;
+}
+}  // namespace fuifgpu
+
+extern "C" {
+
+const char *fuifgpu_strerror(int code) {
+    switch (code) {
+        case FUIFGPU_OK: return "ok";
+        case FUIFGPU_E_NOT_FUIF: return "not a FUIF stream";
+        case FUIFGPU_E_CORRUPT: return "corrupt header or transform list";
+        case FUIFGPU_E_UNSUPPORTED: return "feature outside the MI355X hot-path scope";
+        case FUIFGPU_E_ARG: return "invalid argument";
+        case FUIFGPU_E_HIP: return "HIP runtime error";
+        case FUIFGPU_E_MISMATCH: return "stream does not match the batch plan";
+        case FUIFGPU_E_NOMEM: return "out of memory";
+        default: return "unknown error";
+    }
+}
+const char *fuifgpu_last_error(void) { return g_last_error.c_str(); }
+int fuifgpu_abi_version(void) { return FUIFGPU_ABI_VERSION; }
+
+void fuifgpu_build_chance_table(uint16_t *table8192, uint32_t alpha, int cut) { build_chance_table(table8192, alpha, cut); }
+
+int fuifgpu_plan_create(const uint8_t *blob, size_t size, fuifgpu_plan **out) {
+    if (!blob || !out) return FUIFGPU_E_ARG;
+    fuifgpu_plan *p = new fuifgpu_plan();
+    int r = parse_and_plan(blob, size, p->plan);
+    if (r != FUIFGPU_OK) {
+        g_last_error = p->plan.message;
+        delete p;
+        *out = nullptr;
+        return r;
+    }
+    *out = p;
+    return FUIFGPU_OK;
+}
+void fuifgpu_plan_destroy(fuifgpu_plan *plan) { delete plan; }
+
+int fuifgpu_plan_info(const fuifgpu_plan *plan, fuifgpu_image_info *info) {
+    if (!plan || !info) return FUIFGPU_E_ARG;
+    const Plan &p = plan->plan;
+    memset(info, 0, sizeof(*info));
+    info->w = p.w; info->h = p.h; info->bit_depth = p.bit_depth; info->maxval = p.maxval; info->nb_channels = p.nb_channels;
+    info->colormodel = p.colormodel; info->max_properties = p.max_properties; info->nb_frames = p.nb_frames;
+    info->nb_transforms = (int)p.transforms.size(); info->nb_coded_channels = (int)p.coded.size();
+    info->nb_output_channels = (int)p.outputs.size(); info->nb_ops = (int)p.ops.size();
+    for (int s = 0; s < 5; s++) info->responsive_offsets[s] = p.responsive_offsets[s];
+    info->data_start = (int)p.data_start;
+    info->coef_elems = p.coef_elems; info->out_elems = p.out_elems; info->tmp_elems = p.tmp_elems;
+    info->signature = p.signature;
+    return FUIFGPU_OK;
+}
+int fuifgpu_plan_coded_channel(const fuifgpu_plan *plan, int index, fuifgpu_channel_desc *d) {
+    if (!plan || !d || index < 0 || index >= (int)plan->plan.coded.size()) return FUIFGPU_E_ARG;
+    const ChannelGeom &g = plan->plan.coded[index];
+    d->w = g.w; d->h = g.h; d->hshift = g.hshift; d->vshift = g.vshift; d->hcshift = g.hcshift; d->vcshift = g.vcshift;
+    d->component = g.component; d->reserved = 0; d->offset = g.coef_off;
+    return FUIFGPU_OK;
+}
+int fuifgpu_plan_output_channel(const fuifgpu_plan *plan, int index, fuifgpu_channel_desc *d) {
+    if (!plan || !d || index < 0 || index >= (int)plan->plan.outputs.size()) return FUIFGPU_E_ARG;
+    const OutputChannel &o = plan->plan.outputs[index];
+    d->w = o.plane.w; d->h = o.plane.h; d->hshift = o.hshift; d->vshift = o.vshift; d->hcshift = o.hcshift; d->vcshift = o.vcshift;
+    d->component = o.component; d->reserved = 0; d->offset = o.plane.off;
+    return FUIFGPU_OK;
+}
+int fuifgpu_plan_transform(const fuifgpu_plan *plan, int index, int32_t *id, int32_t *params_out, int cap, int32_t *nparams) {
+    if (!plan || index < 0 || index >= (int)plan->plan.transforms.size()) return FUIFGPU_E_ARG;
+    const TransformDesc &t = plan->plan.transforms[index];
+    if (id) *id = t.id;
+    if (nparams) *nparams = (int)t.params.size();
+    if (params_out) for (int i = 0; i < (int)t.params.size() && i < cap; i++) params_out[i] = t.params[i];
+    return FUIFGPU_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+void fuifgpu_batch_destroy(fuifgpu_batch *b) {
+    if (!b) return;
+    hipFree(b->d_blobs); hipFree(b->d_jobs); hipFree(b->d_geom); hipFree(b->d_meta); hipFree(b->d_status); hipFree(b->d_consumed);
+    hipFree(b->d_tables); hipFree(b->d_scratch); hipFree(b->d_tmp); hipFree(b->d_list);
+    if (b->own_coef) hipFree(b->d_coef);
+    if (b->own_out) hipFree(b->d_out);
+    if (b->h_blobs) hipHostFree(b->h_blobs);
+    for (int i = 0; i < 4; i++) if (b->ev[i]) hipEventDestroy(b->ev[i]);
+    delete b;
+}
+
+int fuifgpu_batch_create(const fuifgpu_plan *plan, int n_images, size_t blob_capacity_bytes, int32_t *coef_ext, int32_t *out_ext,
+                         int tmp_images, fuifgpu_batch **out) {
+    if (!plan || !out || n_images < 1 || n_images > 65535) return FUIFGPU_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        g_last_error = "no HIP device visible: libfuifgpu has no CPU fallback";
+        return FUIFGPU_E_HIP;
+    }
+    fuifgpu_batch *b = new fuifgpu_batch();
+    b->plan = plan->plan;
+    b->n = n_images;
+    const Plan &p = b->plan;
+    const int nch = (int)p.coded.size();
+    b->blob_cap = blob_capacity_bytes + (size_t)n_images * 32 + 64;
+#define CHK(call)                                                        \
+    do {                                                                 \
+        hipError_t e__ = (call);                                         \
+        if (e__ != hipSuccess) { int rc = hip_fail(e__, #call); fuifgpu_batch_destroy(b); return rc; } \
+    } while (0)
+    CHK(hipMalloc((void **)&b->d_blobs, b->blob_cap));
+    CHK(hipHostMalloc((void **)&b->h_blobs, b->blob_cap, hipHostMallocDefault));
+    CHK(hipMalloc((void **)&b->d_jobs, sizeof(StreamJob) * n_images));
+    CHK(hipMalloc((void **)&b->d_geom, sizeof(ChannelGeom) * std::max(nch, 1)));
+    CHK(hipMemcpy(b->d_geom, p.coded.data(), sizeof(ChannelGeom) * nch, hipMemcpyHostToDevice));
+    CHK(hipMalloc((void **)&b->d_meta, sizeof(ChannelMeta) * (size_t)n_images * std::max(nch, 1)));
+    CHK(hipMalloc((void **)&b->d_status, sizeof(int32_t) * n_images));
+    CHK(hipMalloc((void **)&b->d_consumed, sizeof(uint32_t) * n_images));
+    {
+        std::vector<uint16_t> tables(16384);
+        build_chance_table(tables.data(), 0xFFFFFFFFu / 19, 2);        // tree coder: maniac/compound.h:262
+        build_chance_table(tables.data() + 8192, 0x0d000000u, 6);      // pixel coder: encoding/encoding.h:54-55
+        CHK(hipMalloc((void **)&b->d_tables, tables.size() * 2));
+        CHK(hipMemcpy(b->d_tables, tables.data(), tables.size() * 2, hipMemcpyHostToDevice));
+    }
+    b->scratch_stride = maniac_scratch_bytes(b->max_nodes, &b->leaves_off, &b->stack_off);
+    CHK(hipMalloc((void **)&b->d_scratch, b->scratch_stride * n_images));
+    if (coef_ext) b->d_coef = coef_ext;
+    else { CHK(hipMalloc((void **)&b->d_coef, sizeof(int32_t) * (size_t)std::max<int64_t>(p.coef_elems, 1) * n_images)); b->own_coef = true; }
+    if (out_ext) b->d_out = out_ext;
+    else { CHK(hipMalloc((void **)&b->d_out, sizeof(int32_t) * (size_t)std::max<int64_t>(p.out_elems, 1) * n_images)); b->own_out = true; }
+    if (tmp_images <= 0) {
+        // default: keep the TMP slab under ~8 GiB
+        int64_t per = std::max<int64_t>(p.tmp_elems, 1) * 4;
+        tmp_images = (int)std::max<int64_t>(1, std::min<int64_t>(n_images, (8LL << 30) / per));
+    }
+    b->tmp_images = std::min(tmp_images, n_images);
+    CHK(hipMalloc((void **)&b->d_tmp, sizeof(int32_t) * (size_t)std::max<int64_t>(p.tmp_elems, 1) * b->tmp_images));
+    if (!p.idct_src.empty()) {
+        CHK(hipMalloc((void **)&b->d_list, sizeof(PlaneRef) * p.idct_src.size()));
+        CHK(hipMemcpy(b->d_list, p.idct_src.data(), sizeof(PlaneRef) * p.idct_src.size(), hipMemcpyHostToDevice));
+    }
+    for (int i = 0; i < 4; i++) CHK(hipEventCreate(&b->ev[i]));
+#undef CHK
+    *out = b;
+    return FUIFGPU_OK;
+}
+
+int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const size_t *sizes, int n_images, int preview, void *stream) {
+    if (!b || !blobs || !sizes || n_images < 1 || n_images > b->n || preview < -1 || preview > 4) return FUIFGPU_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    b->jobs.assign(n_images, StreamJob{});
+    size_t off = 0;
+    Plan tmp;
+    for (int i = 0; i < n_images; i++) {
+        if (sizes[i] > 0xFFFFFFF0ull) return FUIFGPU_E_ARG;
+        // identical bytes => identical header: skip re-planning replicas of the previous blob
+        bool same_as_prev = i > 0 && sizes[i] == sizes[i - 1] && blobs[i] == blobs[i - 1];
+        if (!same_as_prev) {
+            int r = parse_and_plan(blobs[i], sizes[i], tmp);
+            if (r != FUIFGPU_OK) { g_last_error = tmp.message; return r; }
+            if (tmp.signature != b->plan.signature) { g_last_error = "image " + std::to_string(i) + " has a different geometry/transform chain"; return FUIFGPU_E_MISMATCH; }
+        }
+        size_t padded = (sizes[i] + 15) / 16 * 16 + 16;
+        if (off + padded > b->blob_cap) { g_last_error = "blob capacity exceeded"; return FUIFGPU_E_NOMEM; }
+        memcpy(b->h_blobs + off, blobs[i], sizes[i]);
+        memset(b->h_blobs + off + sizes[i], 0, padded - sizes[i]);
+        StreamJob &j = b->jobs[i];
+        j.blob_off = off; j.blob_size = (uint32_t)sizes[i]; j.data_start = (uint32_t)tmp.data_start;
+        j.limit = preview >= 0 ? (uint32_t)tmp.responsive_offsets[preview] : 0u;
+        j.flags = 0;
+        off += padded;
+    }
+    HIPCHK(hipMemcpyAsync(b->d_blobs, b->h_blobs, off, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b->d_jobs, b->jobs.data(), sizeof(StreamJob) * n_images, hipMemcpyHostToDevice, st));
+    b->n_loaded = n_images;
+    return FUIFGPU_OK;
+}
+
+int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
+    if (!b || b->n_loaded < 1) return FUIFGPU_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = (int)b->plan.coded.size();
+    HIPCHK(hipMemsetAsync(b->d_meta, 0, sizeof(ChannelMeta) * (size_t)b->n_loaded * std::max(nch, 1), st));
+    DecodeParams P{};
+    P.blobs = b->d_blobs; P.jobs = b->d_jobs; P.n_images = b->n_loaded; P.n_channels = nch; P.geom = b->d_geom;
+    P.coef = b->d_coef; P.coef_stride = b->plan.coef_elems; P.meta = b->d_meta; P.status = b->d_status; P.consumed = b->d_consumed;
+    P.tables = b->d_tables; P.scratch = b->d_scratch; P.scratch_stride = b->scratch_stride; P.leaves_off = b->leaves_off;
+    P.stack_off = b->stack_off; P.max_properties = b->plan.max_properties; P.max_nodes = b->max_nodes;
+    HIPCHK(hipEventRecord(b->ev[0], st));
+    launch_maniac_decode(P, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(b->ev[1], st));
+    b->decode_timed = true;
+    return FUIFGPU_OK;
+}
+
+int fuifgpu_batch_undo_transforms(fuifgpu_batch *b, void *stream) {
+    if (!b || b->n_loaded < 1) return FUIFGPU_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const Plan &p = b->plan;
+    const int nch = (int)p.coded.size();
+    HIPCHK(hipEventRecord(b->ev[2], st));
+    for (int i0 = 0; i0 < b->n_loaded; i0 += b->tmp_images) {
+        const int cnt = std::min(b->tmp_images, b->n_loaded - i0);
+        Bases bases;
+        bases.base[BUF_COEF] = b->d_coef + (int64_t)i0 * p.coef_elems; bases.stride[BUF_COEF] = p.coef_elems;
+        bases.base[BUF_OUT] = b->d_out + (int64_t)i0 * p.out_elems; bases.stride[BUF_OUT] = p.out_elems;
+        bases.base[BUF_TMP] = b->d_tmp; bases.stride[BUF_TMP] = p.tmp_elems;
+        for (const Op &op : p.ops) launch_op(op, bases, b->d_list, b->d_meta, nch, i0, cnt, st);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(b->ev[3], st));
+    b->transform_timed = true;
+    return FUIFGPU_OK;
+}
+
+int fuifgpu_batch_sync(fuifgpu_batch *b, void *stream) {
+    if (!b) return FUIFGPU_E_ARG;
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return FUIFGPU_OK;
+}
+
+int fuifgpu_batch_status(fuifgpu_batch *b, int32_t *status, uint32_t *bytes_consumed) {
+    if (!b || b->n_loaded < 1) return FUIFGPU_E_ARG;
+    HIPCHK(hipDeviceSynchronize());
+    if (status) HIPCHK(hipMemcpy(status, b->d_status, sizeof(int32_t) * b->n_loaded, hipMemcpyDeviceToHost));
+    if (bytes_consumed) HIPCHK(hipMemcpy(bytes_consumed, b->d_consumed, sizeof(uint32_t) * b->n_loaded, hipMemcpyDeviceToHost));
+    return FUIFGPU_OK;
+}
+
+int fuifgpu_batch_channel_meta(fuifgpu_batch *b, int image, int32_t *meta4) {
+    if (!b || image < 0 || image >= b->n_loaded || !meta4) return FUIFGPU_E_ARG;
+    const int nch = (int)b->plan.coded.size();
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(meta4, b->d_meta + (size_t)image * nch, sizeof(ChannelMeta) * nch, hipMemcpyDeviceToHost));
+    return FUIFGPU_OK;
+}
+
+int32_t *fuifgpu_batch_coef_ptr(fuifgpu_batch *b, int image) { return (b && image >= 0 && image < b->n) ? b->d_coef + (int64_t)image * b->plan.coef_elems : nullptr; }
+int32_t *fuifgpu_batch_out_ptr(fuifgpu_batch *b, int image) { return (b && image >= 0 && image < b->n) ? b->d_out + (int64_t)image * b->plan.out_elems : nullptr; }
+
+int fuifgpu_batch_download_coef(fuifgpu_batch *b, int image, int32_t *host, void *stream) {
+    if (!b || image < 0 || image >= b->n || !host) return FUIFGPU_E_ARG;
+    HIPCHK(hipMemcpyAsync(host, fuifgpu_batch_coef_ptr(b, image), sizeof(int32_t) * (size_t)b->plan.coef_elems, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return FUIFGPU_OK;
+}
+int fuifgpu_batch_download_out(fuifgpu_batch *b, int image, int32_t *host, void *stream) {
+    if (!b || image < 0 || image >= b->n || !host) return FUIFGPU_E_ARG;
+    HIPCHK(hipMemcpyAsync(host, fuifgpu_batch_out_ptr(b, image), sizeof(int32_t) * (size_t)b->plan.out_elems, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return FUIFGPU_OK;
+}
+
+int fuifgpu_batch_last_timing(fuifgpu_batch *b, float *decode_ms, float *transform_ms) {
+    if (!b) return FUIFGPU_E_ARG;
+    if (decode_ms) {
+        *decode_ms = -1.f;
+        if (b->decode_timed) { HIPCHK(hipEventSynchronize(b->ev[1])); HIPCHK(hipEventElapsedTime(decode_ms, b->ev[0], b->ev[1])); }
+    }
+    if (transform_ms) {
+        *transform_ms = -1.f;
+        if (b->transform_timed) { HIPCHK(hipEventSynchronize(b->ev[3])); HIPCHK(hipEventElapsedTime(transform_ms, b->ev[2], b->ev[3])); }
+    }
+    return FUIFGPU_OK;
+}
+
+// ---- single-transform entry points -----------------------------------------------------------
+static Op raw_op(int kind) {
+    Op op{};
+    op.kind = kind;
+    return op;
+}
+static PlaneRef raw_plane(int buf, int w, int h) {
+    PlaneRef p{};
+    p.buf = buf; p.w = w; p.h = h; p.qsrc = -1; p.off = 0;
+    return p;
+}
+
+int fuifgpu_inv_hsqueeze(const int32_t *avg, int w1, const int32_t *res, int w2, int h, int32_t *out, int n_planes, int64_t sa, int64_t sr,
+                         int64_t so, void *stream) {
+    if (!avg || !out || (!res && w2 > 0) || w1 < 1 || h < 1 || w1 - w2 < 0 || w1 - w2 > 1 || n_planes < 1 || n_planes > 65535) return FUIFGPU_E_ARG;
+    Bases b;
+    b.base[0] = const_cast<int32_t *>(avg); b.stride[0] = sa;
+    b.base[1] = const_cast<int32_t *>(res ? res : avg); b.stride[1] = sr;
+    b.base[2] = out; b.stride[2] = so;
+    Op op = raw_op(OP_HSQUEEZE);
+    op.src[0] = raw_plane(0, w1, h); op.src[1] = raw_plane(1, w2, h); op.dst[0] = raw_plane(2, w1 + w2, h);
+    launch_op(op, b, nullptr, nullptr, 0, 0, n_planes, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return FUIFGPU_OK;
+}
+int fuifgpu_inv_vsqueeze(const int32_t *avg, int h1, const int32_t *res, int h2, int w, int32_t *out, int n_planes, int64_t sa, int64_t sr,
+                         int64_t so, void *stream) {
+    if (!avg || !out || (!res && h2 > 0) || h1 < 1 || w < 1 || h1 - h2 < 0 || h1 - h2 > 1 || n_planes < 1 || n_planes > 65535) return FUIFGPU_E_ARG;
+    Bases b;
+    b.base[0] = const_cast<int32_t *>(avg); b.stride[0] = sa;
+    b.base[1] = const_cast<int32_t *>(res ? res : avg); b.stride[1] = sr;
+    b.base[2] = out; b.stride[2] = so;
+    Op op = raw_op(OP_VSQUEEZE);
+    op.src[0] = raw_plane(0, w, h1); op.src[1] = raw_plane(1, w, h2); op.dst[0] = raw_plane(2, w, h1 + h2);
+    launch_op(op, b, nullptr, nullptr, 0, 0, n_planes, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return FUIFGPU_OK;
+}
+static int color_raw(int kind, int32_t *c0, int32_t *c1, int32_t *c2, int w, int h, int p0, int p1, int p2, int minval, int maxval, void *stream) {
+    if (!c0 || !c1 || !c2 || w < 1 || h < 1 || p0 < w || p1 < w || p2 < w) return FUIFGPU_E_ARG;
+    Bases b;
+    b.base[0] = c0; b.base[1] = c1; b.base[2] = c2;
+    b.stride[0] = b.stride[1] = b.stride[2] = 0;
+    Op op = raw_op(kind);
+    op.src[0] = op.dst[0] = raw_plane(0, p0, h);
+    op.src[1] = op.dst[1] = raw_plane(1, p1, h);
+    op.src[2] = op.dst[2] = raw_plane(2, p2, h);
+    op.p0 = w; op.p1 = h; op.lo = minval; op.hi = maxval;
+    launch_op(op, b, nullptr, nullptr, 0, 0, 1, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return FUIFGPU_OK;
+}
+int fuifgpu_inv_ycocg(int32_t *c0, int32_t *c1, int32_t *c2, int w, int h, int p0, int p1, int p2, int maxval, void *stream) {
+    return color_raw(OP_YCOCG, c0, c1, c2, w, h, p0, p1, p2, 0, maxval, stream);
+}
+int fuifgpu_inv_ycbcr(int32_t *c0, int32_t *c1, int32_t *c2, int w, int h, int p0, int p1, int p2, int minval, int maxval, void *stream) {
+    return color_raw(OP_YCBCR, c0, c1, c2, w, h, p0, p1, p2, minval, maxval, stream);
+}
+int fuifgpu_idct8x8(const int32_t *const *src64, int bw, int bh, int32_t *out, int maxval, void *stream) {
+    if (!src64 || !out || bw < 1 || bh < 1) return FUIFGPU_E_ARG;
+    // planes are addressed as element offsets from a null base: every plane pointer is 4-byte aligned
+    std::vector<PlaneRef> list(64);
+    for (int i = 0; i < 64; i++) {
+        if (!src64[i]) return FUIFGPU_E_ARG;
+        list[i] = raw_plane(0, bw, bh);
+        list[i].off = (int64_t)(reinterpret_cast<uintptr_t>(src64[i]) / 4);
+    }
+    PlaneRef *d_list = nullptr;
+    HIPCHK(hipMalloc((void **)&d_list, sizeof(PlaneRef) * 64));
+    hipError_t e = hipMemcpy(d_list, list.data(), sizeof(PlaneRef) * 64, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(d_list); return hip_fail(e, "hipMemcpy"); }
+    Bases b;
+    b.base[0] = nullptr; b.stride[0] = 0; b.base[1] = out; b.stride[1] = 0; b.base[2] = nullptr; b.stride[2] = 0;
+    Op op = raw_op(OP_IDCT);
+    op.p0 = bw; op.p1 = bh; op.hi = maxval; op.idct_first = 0; op.pad = 64;
+    op.dst[0] = raw_plane(1, bw * 8, bh * 8);
+    launch_op(op, b, d_list, nullptr, 0, 0, 1, (hipStream_t)stream);
+    e = hipStreamSynchronize((hipStream_t)stream);
+    hipFree(d_list);
+    if (e != hipSuccess) return hip_fail(e, "idct8x8");
+    return FUIFGPU_OK;
+}
+int fuifgpu_upsample(const int32_t *in, int w, int h, int srh, int srv, int32_t *out, void *stream) {
+    if (!in || !out || w < 1 || h < 1 || srh < 1 || srh > 2 || srv < 1 || srv > 2) return FUIFGPU_E_ARG;
+    Bases b;
+    b.base[0] = const_cast<int32_t *>(in); b.stride[0] = 0; b.base[1] = out; b.stride[1] = 0; b.base[2] = nullptr; b.stride[2] = 0;
+    Op op = raw_op(OP_UPSAMPLE);
+    op.src[0] = raw_plane(0, w, h); op.dst[0] = raw_plane(1, w * srh, h * srv); op.p0 = srh; op.p1 = srv;
+    launch_op(op, b, nullptr, nullptr, 0, 0, 1, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return FUIFGPU_OK;
+}
+
+}  // extern "C"

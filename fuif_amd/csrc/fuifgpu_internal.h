@@ -1,0 +1,113 @@
+// fuif_amd/csrc/fuifgpu_internal.h -- structures shared by the host planner, the C-ABI layer and
+// the gfx950 kernels.  Everything here is plain-old-data so it can be passed to kernels by value.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace fuifgpu {
+
+// transform ids (reference: transform/transform.h:29-70)
+enum : int {
+    TR_YCBCR = 0, TR_YCOCG = 1, TR_SUBSAMPLE = 3, TR_DCT = 4, TR_QUANTIZE = 5,
+    TR_PALETTE = 6, TR_SQUEEZE = 7, TR_2DMATCH = 8, TR_PERMUTE = 9, TR_APPROXIMATE = 10
+};
+
+constexpr int kMaxBitDepth = 15;        // config.h:5 (MAX_BIT_DEPTH)
+constexpr int kNonRefProps = 13;        // encoding/context_predict.h:210
+constexpr int kMaxProps = 32;           // 2*6 reference properties + 13 local ones = 25 at default options
+constexpr int kMaxRefs = 8;
+constexpr int kMaxNodes = 65535;        // childID is uint16_t (maniac/compound.h:46)
+constexpr int kLeafStride = 32;         // 31 chances (maniac/symbol.h:72-77) padded to 64 bytes
+constexpr int kTreeStackDepth = 2048;   // explicit stack replacing the recursion of compound.h:277-308
+constexpr int kPlaneAlign = 64;         // planes start on 256-byte boundaries inside a slab
+
+// status word per image (bit flags)
+enum : int {
+    ST_OK = 0,
+    ST_TRUNCATED = 1,       // ran into EOF / the preview byte limit (not an error: encoding.cpp:209-219)
+    ST_CORRUPT = 2,         // the reference would return false
+    ST_UNSUPPORTED = 4,     // needs a feature outside SURVEY.md §8 (bit depth, tree size, ...)
+};
+
+// Geometry of one coded channel after all meta transforms (image/image.h:54-91 minus the data)
+struct ChannelGeom {
+    int32_t w, h;
+    int32_t hshift, vshift, hcshift, vcshift;
+    int32_t component;
+    int32_t pad;
+    int64_t coef_off;  // element offset of the plane inside one image's coefficient slab
+};
+
+// Per-image, per-coded-channel values that only the bitstream knows (written by the entropy kernel)
+struct ChannelMeta {
+    int32_t minval, maxval, q, decoded;  // decoded: 0 = untouched (reads as zeros), 1 = has data
+};
+
+// One compressed stream (= one image) of a batch
+struct StreamJob {
+    uint64_t blob_off;    // byte offset inside the batch's blob buffer (16-byte aligned)
+    uint32_t blob_size;
+    uint32_t data_start;  // first byte after the header = first channel group
+    uint32_t limit;       // bytes_to_load for responsive decodes (0 = none), encoding.cpp:704-705
+    uint32_t flags;       // bit 0: BlobReader EOF semantics (fileio.h:100-102) instead of FileIO/feof
+};
+
+// --- inverse-transform schedule ---------------------------------------------------------------
+enum : int { BUF_COEF = 0, BUF_OUT = 1, BUF_TMP = 2 };
+struct PlaneRef {
+    int32_t buf;
+    int32_t w, h;
+    int32_t qsrc;     // coded channel whose ChannelMeta::q this plane carries (Channel::q)
+    int64_t off;
+};
+enum : int {
+    OP_HSQUEEZE = 1, OP_VSQUEEZE = 2, OP_YCOCG = 3, OP_YCBCR = 4, OP_QUANT = 5, OP_IDCT = 6,
+    OP_UPSAMPLE = 7, OP_COPY_CLAMP = 8, OP_CLAMP = 9
+};
+struct Op {
+    int32_t kind;
+    int32_t clamp_out;         // fused final clamp (image/image.cpp:107-113) on the stores
+    int32_t lo, hi;            // clamp bounds / image minval,maxval
+    int32_t p0, p1;            // op specific (upsample: srh,srv)
+    PlaneRef src[3];
+    PlaneRef dst[3];
+    int32_t idct_first;        // OP_IDCT: index into Plan::idct_src of the 64 source planes
+    int32_t pad;
+};
+
+struct TransformDesc {
+    int id;
+    std::vector<int> params;
+};
+
+struct OutputChannel {
+    PlaneRef plane;   // always BUF_OUT
+    int32_t hshift, vshift, hcshift, vcshift, component;
+};
+
+struct Plan {
+    // header (encoding/encoding.cpp:599-657)
+    int w = 0, h = 0, bit_depth = 0, maxval = 0, minval = 0;
+    int nb_channels = 0, colormodel = 0, nb_frames = 1, max_properties = 0;
+    int responsive_offsets[5] = {0, 0, 0, 0, 0};
+    size_t data_start = 0;
+    std::vector<TransformDesc> transforms;      // with default parameters expanded like meta_apply does
+    std::vector<ChannelGeom> coded;             // channel table the entropy stage fills
+    int64_t coef_elems = 0;                     // per-image coefficient slab (int32 elements)
+    // inverse schedule (image/image.cpp:94-115)
+    std::vector<Op> ops;
+    std::vector<PlaneRef> idct_src;
+    std::vector<OutputChannel> outputs;
+    int64_t out_elems = 0, tmp_elems = 0;
+    uint64_t signature = 0;                     // equal signature <=> same geometry & schedule
+    int error = 0;                              // FUIFGPU_E_* (0 = ok)
+    std::string message;
+};
+
+// host planner (plan.cpp)
+int parse_and_plan(const uint8_t *blob, size_t n, Plan &plan);
+void build_chance_table(uint16_t *table8192, uint32_t alpha, int cut);
+
+}  // namespace fuifgpu

@@ -1,0 +1,664 @@
+// fuif_amd/csrc/plan.cpp -- host planner of the MI355X FUIF decode path.
+//
+// Turns the first ~100 bytes of a .fuif stream into everything the device needs that does NOT
+// depend on pixel data:
+//   1. header fields                       (reference: encoding/encoding.cpp:599-657)
+//   2. transform list + meta transforms    (encoding.cpp:673-693, transform/transform.cpp:66-81,
+//                                           squeeze.h:266-360, dct.h:209-246, subsample.h:33-69,135-157)
+//      -> the coded channel table (w,h,shifts, slab offsets) the entropy kernel fills
+//   3. a flat schedule of inverse-transform kernel launches equivalent to
+//      Image::undo_transforms(0)           (image/image.cpp:94-115, squeeze.h:363-388,
+//                                           quantize.h:32-49, dct.h:249-296, subsample.h:73-127)
+//      with plane lifetimes resolved to three per-image slabs: COEF (entropy output), OUT (final
+//      planes) and TMP (short-lived intermediates, first-fit with reuse).
+//
+// The planner is geometry only: two streams with the same header produce the same plan, which is
+// what lets one kernel launch process a whole batch of images (grid.z = image).
+#include <algorithm>
+#include <cstring>
+#include <map>
+
+#include "../../include/fuifgpu.h"
+#include "fuifgpu_internal.h"
+
+namespace fuifgpu {
+
+namespace {
+
+struct ByteReader {
+    const uint8_t *p;
+    size_t n, pos;
+    bool eof;
+    int get() {
+        if (pos >= n) { eof = true; return -1; }
+        return p[pos++];
+    }
+    // big-endian base-128 varint, at most 10 bytes, -1 on EOF (encoding/encoding.cpp:45-59)
+    int varint() {
+        uint32_t result = 0;
+        for (int k = 0; k < 10; k++) {
+            int b = get();
+            if (b < 0) return -1;
+            if (b < 128) return (int)(result + (uint32_t)b);
+            result = (result + (uint32_t)(b - 128)) << 7;
+        }
+        return -1;
+    }
+};
+
+struct PlaneInfo {
+    int w = 0, h = 0, qsrc = -1;
+    int buf = BUF_COEF;
+    int64_t off = 0;
+    int birth = -1;   // op index that creates the plane (-1: coded plane living in COEF)
+    int death = -1;   // last op index that reads it
+    bool is_final = false;
+};
+
+struct LiveChannel {
+    int plane;
+    int w, h, hshift, vshift, hcshift, vcshift, component;
+};
+
+struct ProtoOp {
+    int kind = 0;
+    int src[3] = {-1, -1, -1};
+    int dst[3] = {-1, -1, -1};
+    int p0 = 0, p1 = 0;
+    std::vector<int> list;  // OP_IDCT: 64 source planes; OP_QUANT: planes to scale
+};
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+// first-fit allocator with coalescing free list for the TMP slab
+struct Arena {
+    std::map<int64_t, int64_t> free_blocks;  // off -> size
+    int64_t top = 0, peak = 0;
+    int64_t alloc(int64_t size) {
+        size = align_up(std::max<int64_t>(size, 1), kPlaneAlign);
+        for (auto it = free_blocks.begin(); it != free_blocks.end(); ++it) {
+            if (it->second >= size) {
+                int64_t off = it->first, rest = it->second - size;
+                free_blocks.erase(it);
+                if (rest) free_blocks[off + size] = rest;
+                return off;
+            }
+        }
+        // grow: if the last free block touches the top, extend it
+        if (!free_blocks.empty()) {
+            auto last = std::prev(free_blocks.end());
+            if (last->first + last->second == top) {
+                int64_t off = last->first;
+                top = off + size;
+                free_blocks.erase(last);
+                peak = std::max(peak, top);
+                return off;
+            }
+        }
+        int64_t off = top;
+        top += size;
+        peak = std::max(peak, top);
+        return off;
+    }
+    void release(int64_t off, int64_t size) {
+        size = align_up(std::max<int64_t>(size, 1), kPlaneAlign);
+        auto it = free_blocks.emplace(off, size).first;
+        auto next = std::next(it);
+        if (next != free_blocks.end() && it->first + it->second == next->first) {
+            it->second += next->second;
+            free_blocks.erase(next);
+        }
+        if (it != free_blocks.begin()) {
+            auto prev = std::prev(it);
+            if (prev->first + prev->second == it->first) {
+                prev->second += it->second;
+                free_blocks.erase(it);
+            }
+        }
+    }
+};
+
+// reference zig-zag variant (transform/dct.h:120-129) and cumulative shifts (dct.h:159-171)
+const int kZigzag[64] = {0,  1,  4,  15, 16, 35, 36, 63, 2,  3,  5,  14, 17, 34, 37, 62, 8,  7,  6,  13, 18, 33,
+                         38, 61, 9,  10, 11, 12, 19, 32, 39, 60, 24, 23, 22, 21, 20, 31, 40, 59, 25, 26, 27, 28,
+                         29, 30, 41, 58, 48, 47, 46, 45, 44, 43, 42, 57, 49, 50, 51, 52, 53, 54, 55, 56};
+const int kDctCshift[64] = {3, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+
+bool has_parameters(int id) {  // transform/transform.h:85-102
+    switch (id) {
+        case TR_SUBSAMPLE: case TR_PALETTE: case TR_SQUEEZE: case TR_DCT: case TR_2DMATCH: case TR_PERMUTE: case TR_APPROXIMATE:
+            return true;
+        default:
+            return false;
+    }
+}
+
+// transform/subsample.h:33-69
+std::vector<int> expand_subsample(const std::vector<int> &in) {
+    std::vector<int> p = in;
+    if (p.size() == 1) {
+        switch (p[0]) {
+            case 0: p = {1, 2, 2, 2}; break;
+            case 1: p = {1, 2, 2, 1}; break;
+            case 2: p = {1, 2, 1, 2}; break;
+            case 3: p = {1, 2, 4, 1}; break;
+            default: break;
+        }
+    }
+    if (p.size() % 4) p.clear();
+    return p;
+}
+
+struct Builder {
+    Plan &plan;
+    std::vector<LiveChannel> live;
+    std::vector<PlaneInfo> planes;
+    std::vector<ProtoOp> ops;
+    int nb_meta = 0;  // no transform in scope creates meta channels
+
+    explicit Builder(Plan &p) : plan(p) {}
+
+    bool fail(int code, const std::string &msg) {
+        plan.error = code;
+        plan.message = msg;
+        return false;
+    }
+
+    // ---- forward geometry (meta_apply) ------------------------------------------------------
+    // transform/squeeze.h:266-321
+    void default_squeeze(std::vector<int> &params) {
+        params.clear();
+        int nb = plan.nb_channels;
+        int w = live[nb_meta].w, h = live[nb_meta].h;
+        bool wide = w > h;
+        if (nb > 2 && live[nb_meta + 1].w == w && live[nb_meta + 1].h == h) {
+            params.insert(params.end(), {3, nb_meta + 1, nb_meta + 2});
+            params.insert(params.end(), {2, nb_meta + 1, nb_meta + 2});
+        }
+        if (!wide && h > 8) {
+            params.insert(params.end(), {0, nb_meta, nb_meta + nb - 1});
+            h = (h + 1) / 2;
+        }
+        while (w > 8 || h > 8) {
+            if (w > 8) { params.insert(params.end(), {1, nb_meta, nb_meta + nb - 1}); w = (w + 1) / 2; }
+            if (h > 8) { params.insert(params.end(), {0, nb_meta, nb_meta + nb - 1}); h = (h + 1) / 2; }
+        }
+    }
+
+    // transform/squeeze.h:323-360
+    bool meta_squeeze(std::vector<int> &params) {
+        if (params.empty()) default_squeeze(params);
+        for (size_t i = 0; i + 2 < params.size(); i += 3) {
+            bool horizontal = params[i] & 1;
+            bool in_place = !(params[i] & 2);
+            int beginc = params[i + 1], endc = params[i + 2];
+            int offset = in_place ? endc + 1 : nb_meta + plan.nb_channels;
+            if (beginc < 0 || endc < beginc || endc >= (int)live.size() || offset > (int)live.size())
+                return fail(FUIFGPU_E_CORRUPT, "squeeze parameters address a missing channel");
+            for (int c = beginc; c <= endc; c++) {
+                LiveChannel d{};
+                d.plane = -1;
+                d.hcshift = live[c].hcshift; d.vcshift = live[c].vcshift; d.component = live[c].component;
+                if (horizontal) {
+                    int w = live[c].w;
+                    live[c].w = (w + 1) / 2; live[c].hshift++; live[c].hcshift++;
+                    d.w = w - (w + 1) / 2; d.h = live[c].h;
+                } else {
+                    int h = live[c].h;
+                    live[c].h = (h + 1) / 2; live[c].vshift++; live[c].vcshift++;
+                    d.h = h - (h + 1) / 2; d.w = live[c].w;
+                }
+                d.hshift = live[c].hshift; d.vshift = live[c].vshift;
+                int at = offset + c - beginc;
+                if (at > (int)live.size()) return fail(FUIFGPU_E_CORRUPT, "squeeze residual position out of range");
+                live.insert(live.begin() + at, d);
+            }
+        }
+        return true;
+    }
+
+    // transform/dct.h:209-246 (scan script dct.h:173-207: position p -> component p%nb, coefficient p/nb)
+    bool meta_dct(std::vector<int> &params) {
+        if (params.empty()) params = {0, plan.nb_channels - 1};
+        if (params.size() < 2) return fail(FUIFGPU_E_CORRUPT, "DCT needs two parameters");
+        int beginc = nb_meta + params[0], endc = nb_meta + params[1];
+        int nb = endc - beginc + 1;
+        if (beginc < 0 || nb < 1 || endc >= (int)live.size()) return fail(FUIFGPU_E_CORRUPT, "DCT channel range invalid");
+        for (int c = beginc; c <= endc; c++) {
+            live[c].w = (live[c].w + 7) / 8; live[c].h = (live[c].h + 7) / 8;
+            live[c].hshift += 3; live[c].vshift += 3; live[c].hcshift += 3; live[c].vcshift += 3;
+        }
+        for (int i = nb; i < 64 * nb; i++) {
+            int c = beginc + (i % nb), coeff = i / nb;
+            LiveChannel d{};
+            d.plane = -1;
+            d.w = live[c].w; d.h = live[c].h; d.hshift = live[c].hshift; d.vshift = live[c].vshift;
+            d.hcshift = kDctCshift[coeff] + live[c].hcshift - 3;
+            d.vcshift = kDctCshift[coeff] + live[c].vcshift - 3;
+            d.component = live[c].component;
+            live.push_back(d);
+        }
+        return true;
+    }
+
+    // transform/subsample.h:135-157
+    bool meta_subsample(const std::vector<int> &params) {
+        std::vector<int> p = expand_subsample(params);
+        for (size_t i = 0; i < p.size(); i += 4) {
+            int c1 = p[i], c2 = p[i + 1], srh = p[i + 2], srv = p[i + 3];
+            if (c1 < 0 || c2 >= (int)live.size() || srh < 1 || srh > 2 || srv < 1 || srv > 2)
+                return fail(FUIFGPU_E_UNSUPPORTED, "subsampling ratio other than 1 or 2");
+            for (int c = c1; c <= c2; c++) {
+                live[c].w = (live[c].w + srh - 1) / srh;
+                live[c].h = (live[c].h + srv - 1) / srv;
+                live[c].hshift += (srh == 1 ? 0 : 1);
+                live[c].vshift += (srv == 1 ? 0 : 1);
+            }
+        }
+        return true;
+    }
+
+    // ---- inverse schedule -------------------------------------------------------------------
+    int new_plane(int w, int h, int qsrc, int birth) {
+        PlaneInfo pi;
+        pi.w = w; pi.h = h; pi.qsrc = qsrc; pi.birth = birth; pi.buf = BUF_TMP;
+        planes.push_back(pi);
+        return (int)planes.size() - 1;
+    }
+    void touch(int plane, int op) { planes[plane].death = std::max(planes[plane].death, op); }
+
+    // transform/squeeze.h:363-388
+    bool inv_squeeze(const std::vector<int> &params) {
+        for (int i = (int)params.size() - 3; i >= 0; i -= 3) {
+            bool horizontal = params[i] & 1;
+            bool in_place = !(params[i] & 2);
+            int beginc = params[i + 1], endc = params[i + 2];
+            int offset = in_place ? endc + 1 : nb_meta + plan.nb_channels;
+            if (beginc < 0 || endc < beginc || offset + (endc - beginc) >= (int)live.size())
+                return fail(FUIFGPU_E_CORRUPT, "inverse squeeze: residual channels missing");
+            for (int c = beginc; c <= endc; c++) {
+                LiveChannel &a = live[c];
+                const LiveChannel &r = live[offset + c - beginc];
+                ProtoOp op;
+                op.kind = horizontal ? OP_HSQUEEZE : OP_VSQUEEZE;
+                int idx = (int)ops.size();
+                int nw = horizontal ? a.w + r.w : a.w, nh = horizontal ? a.h : a.h + r.h;
+                if (horizontal ? (a.h != r.h && r.w > 0) || (a.w - r.w < 0 || a.w - r.w > 1)
+                               : (a.w != r.w && r.h > 0) || (a.h - r.h < 0 || a.h - r.h > 1))
+                    return fail(FUIFGPU_E_UNSUPPORTED, "inverse squeeze: residual geometry not produced by meta_squeeze");
+                op.src[0] = a.plane; op.src[1] = r.plane;
+                op.dst[0] = new_plane(nw, nh, planes[a.plane].qsrc, idx);
+                touch(a.plane, idx); touch(r.plane, idx);
+                ops.push_back(op);
+                a.plane = op.dst[0];
+                a.w = nw; a.h = nh;
+                if (horizontal) { a.hshift--; a.hcshift--; } else { a.vshift--; a.vcshift--; }
+            }
+            live.erase(live.begin() + offset, live.begin() + offset + (endc - beginc + 1));
+        }
+        return true;
+    }
+
+    // transform/quantize.h:32-49 : one batched in-place op over every plane that still carries a q
+    bool inv_quantize() {
+        ProtoOp op;
+        op.kind = OP_QUANT;
+        int idx = (int)ops.size();
+        for (size_t c = nb_meta; c < live.size(); c++) {
+            int pl = live[c].plane;
+            if (planes[pl].qsrc < 0 || (int64_t)planes[pl].w * planes[pl].h == 0) continue;
+            op.list.push_back(pl);
+            touch(pl, idx);
+        }
+        if (!op.list.empty()) ops.push_back(op);
+        // Channel::q becomes 1 (quantize.h:47); recorded AFTER the op list captured the q source
+        if (!op.list.empty()) pending_q_clear = op.list;
+        return true;
+    }
+    std::vector<int> pending_q_clear;
+
+    // transform/dct.h:249-296
+    bool inv_dct(std::vector<int> &params) {
+        if (params.empty()) params = {0, plan.nb_channels - 1};
+        int beginc = nb_meta + params[0], endc = nb_meta + params[1];
+        int nb = endc - beginc + 1;
+        int offset = (int)live.size() - 63 * nb;
+        if (offset <= endc || nb < 1 || beginc < 0) return fail(FUIFGPU_E_CORRUPT, "invalid number of channels for inverse DCT");
+        for (int c = beginc; c <= endc; c++) {
+            LiveChannel &dc = live[c];
+            int bw = live[c - beginc + offset].w, bh = live[c - beginc + offset].h;
+            if (dc.w < bw) bw = dc.w;
+            if (dc.h < bh) bh = dc.h;
+            ProtoOp op;
+            op.kind = OP_IDCT;
+            int idx = (int)ops.size();
+            op.list.resize(64);
+            op.list[0] = dc.plane;
+            for (int i = 1; i < 64; i++) {
+                int ci = offset - nb + kZigzag[i] * nb + (c - beginc);  // ordering[c-beginc][zigzag[i]]
+                if (ci < 0 || ci >= (int)live.size()) return fail(FUIFGPU_E_CORRUPT, "inverse DCT: coefficient channel missing");
+                op.list[i] = live[ci].plane;
+            }
+            for (int i = 0; i < 64; i++) {
+                const PlaneInfo &pi = planes[op.list[i]];
+                if (pi.w < bw || pi.h < bh) return fail(FUIFGPU_E_UNSUPPORTED, "inverse DCT: coefficient planes smaller than the block grid");
+                touch(op.list[i], idx);
+            }
+            op.p0 = bw; op.p1 = bh;
+            op.dst[0] = new_plane(bw * 8, bh * 8, -1, idx);
+            ops.push_back(op);
+            int old_hc = dc.hcshift;
+            dc.plane = op.dst[0];
+            dc.w = bw * 8; dc.h = bh * 8;
+            dc.hshift -= 3; dc.vshift -= 3; dc.hcshift = old_hc - 3; dc.vcshift = old_hc - 3;  // sic, dct.h:280
+        }
+        live.erase(live.begin() + offset, live.begin() + offset + nb * 63);
+        return true;
+    }
+
+    // transform/subsample.h:73-127
+    bool inv_subsample(const std::vector<int> &params) {
+        std::vector<int> p = expand_subsample(params);
+        for (size_t i = 0; i < p.size(); i += 4) {
+            int c1 = p[i], c2 = p[i + 1], srh = p[i + 2], srv = p[i + 3];
+            for (int c = c1; c <= c2 && c < (int)live.size(); c++) {
+                LiveChannel &ch = live[c];
+                if (ch.w >= live[nb_meta].w && ch.h >= live[nb_meta].h) continue;  // subsample.h:87-91
+                if (srh > 2 || srv > 2) return fail(FUIFGPU_E_UNSUPPORTED, "box upsampling ratios > 2");
+                ProtoOp op;
+                op.kind = OP_UPSAMPLE;
+                int idx = (int)ops.size();
+                op.src[0] = ch.plane;
+                op.p0 = srh; op.p1 = srv;
+                op.dst[0] = new_plane(ch.w * srh, ch.h * srv, -1, idx);
+                touch(ch.plane, idx);
+                ops.push_back(op);
+                ch.plane = op.dst[0];
+                ch.w *= srh; ch.h *= srv;
+                ch.hshift = ch.vshift = ch.hcshift = ch.vcshift = 0;  // Channel(w,h,min,max) ctor defaults
+                ch.component = -1;
+            }
+        }
+        return true;
+    }
+
+    bool inv_color(int kind) {
+        // transform/ycocg.h:33-48 / ycbcr.h:33-47 preconditions
+        int m = (kind == OP_YCOCG) ? nb_meta : 0;
+        int have = (kind == OP_YCOCG) ? plan.nb_channels : (int)live.size();
+        if (have < 3 || (int)live.size() < m + 3) return fail(FUIFGPU_E_CORRUPT, "colour transform needs three channels");
+        int w = live[m].w, h = live[m].h;
+        if (live[m + 1].w < w || live[m + 1].h < h || live[m + 2].w < w || live[m + 2].h < h)
+            return fail(FUIFGPU_E_CORRUPT, "colour transform on subsampled chroma");
+        ProtoOp op;
+        op.kind = kind;
+        int idx = (int)ops.size();
+        for (int k = 0; k < 3; k++) { op.src[k] = op.dst[k] = live[m + k].plane; touch(live[m + k].plane, idx); }
+        op.p0 = w; op.p1 = h;
+        ops.push_back(op);
+        return true;
+    }
+
+    bool finalize() {
+        // every plane still referenced by a live channel is a final plane
+        int nops_before = (int)ops.size();
+        std::vector<int> last_writer(planes.size(), -1), last_kind(planes.size(), 0);
+        for (int k = 0; k < nops_before; k++) {
+            const ProtoOp &op = ops[k];
+            for (int d = 0; d < 3; d++) if (op.dst[d] >= 0) { last_writer[op.dst[d]] = k; last_kind[op.dst[d]] = op.kind; }
+            if (op.kind == OP_QUANT) for (int pl : op.list) { last_writer[pl] = k; last_kind[pl] = op.kind; }
+        }
+        // final planes that are still coded planes need a copy into OUT
+        for (auto &ch : live) {
+            if ((int64_t)ch.w * ch.h == 0) continue;
+            if (planes[ch.plane].birth < 0) {
+                ProtoOp op;
+                op.kind = OP_COPY_CLAMP;
+                int idx = (int)ops.size();
+                op.src[0] = ch.plane;
+                op.dst[0] = new_plane(ch.w, ch.h, planes[ch.plane].qsrc, idx);
+                touch(ch.plane, idx);
+                ops.push_back(op);
+                last_writer.push_back(idx); last_kind.push_back(OP_COPY_CLAMP);
+                ch.plane = op.dst[0];
+            }
+        }
+        // allocation: final planes -> OUT (bump), everything else born in an op -> TMP (first fit)
+        std::vector<bool> is_final(planes.size(), false);
+        int64_t out_top = 0;
+        for (auto &ch : live) {
+            if ((int64_t)ch.w * ch.h == 0) continue;
+            PlaneInfo &pi = planes[ch.plane];
+            if (is_final[ch.plane]) return fail(FUIFGPU_E_CORRUPT, "two channels share one plane");
+            is_final[ch.plane] = true;
+            pi.is_final = true;
+            pi.buf = BUF_OUT;
+            pi.off = out_top;
+            out_top += align_up((int64_t)pi.w * pi.h, kPlaneAlign);
+        }
+        plan.out_elems = out_top;
+        Arena arena;
+        std::vector<std::vector<int>> dying(ops.size());
+        for (size_t p = 0; p < planes.size(); p++)
+            if (planes[p].birth >= 0 && !planes[p].is_final && planes[p].death >= 0) dying[planes[p].death].push_back((int)p);
+        for (size_t k = 0; k < ops.size(); k++) {
+            for (int d = 0; d < 3; d++) {
+                int pl = ops[k].dst[d];
+                if (pl >= 0 && planes[pl].birth == (int)k && !planes[pl].is_final)
+                    planes[pl].off = arena.alloc((int64_t)planes[pl].w * planes[pl].h);
+            }
+            for (int pl : dying[k]) arena.release(planes[pl].off, (int64_t)planes[pl].w * planes[pl].h);
+        }
+        plan.tmp_elems = arena.peak;
+
+        // final clamp (image/image.cpp:107-113): fuse into the producing op when it is the last
+        // writer, skip when the last writer already clamps to [minval,maxval], else clamp in place
+        std::vector<int> clamp_fused(ops.size(), 0);
+        for (auto &ch : live) {
+            if ((int64_t)ch.w * ch.h == 0) continue;
+            int pl = ch.plane;
+            int lw = last_writer[pl], lk = last_kind[pl];
+            bool range_ok = (lk == OP_YCBCR) || (lk == OP_YCOCG && plan.minval == 0);
+            if (range_ok) continue;
+            if (lw >= 0 && planes[pl].birth == lw &&
+                (lk == OP_HSQUEEZE || lk == OP_VSQUEEZE || lk == OP_IDCT || lk == OP_UPSAMPLE || lk == OP_COPY_CLAMP)) {
+                clamp_fused[lw] = 1;
+            } else {
+                ProtoOp op;
+                op.kind = OP_CLAMP;
+                op.src[0] = op.dst[0] = pl;
+                ops.push_back(op);
+                clamp_fused.push_back(0);
+            }
+        }
+
+        // resolve to flat ops
+        auto ref = [&](int pl) {
+            PlaneRef r{};
+            if (pl < 0) { r.buf = -1; return r; }
+            r.buf = planes[pl].buf; r.w = planes[pl].w; r.h = planes[pl].h; r.qsrc = planes[pl].qsrc; r.off = planes[pl].off;
+            return r;
+        };
+        plan.ops.clear();
+        plan.idct_src.clear();
+        for (size_t k = 0; k < ops.size(); k++) {
+            const ProtoOp &po = ops[k];
+            Op op{};
+            op.kind = po.kind;
+            op.clamp_out = clamp_fused[k];
+            op.lo = plan.minval; op.hi = plan.maxval;
+            op.p0 = po.p0; op.p1 = po.p1;
+            for (int d = 0; d < 3; d++) { op.src[d] = ref(po.src[d]); op.dst[d] = ref(po.dst[d]); }
+            op.idct_first = (int)plan.idct_src.size();
+            op.pad = (int)po.list.size();
+            for (int pl : po.list) plan.idct_src.push_back(ref(pl));
+            plan.ops.push_back(op);
+        }
+        plan.outputs.clear();
+        for (auto &ch : live) {
+            OutputChannel oc{};
+            if ((int64_t)ch.w * ch.h == 0) { oc.plane.buf = BUF_OUT; oc.plane.w = ch.w; oc.plane.h = ch.h; oc.plane.off = 0; }
+            else oc.plane = ref(ch.plane);
+            oc.hshift = ch.hshift; oc.vshift = ch.vshift; oc.hcshift = ch.hcshift; oc.vcshift = ch.vcshift; oc.component = ch.component;
+            plan.outputs.push_back(oc);
+        }
+        return true;
+    }
+};
+
+uint64_t fnv1a(uint64_t h, const void *data, size_t n) {
+    const uint8_t *p = (const uint8_t *)data;
+    for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+}  // namespace
+
+// maniac/chance.cpp:31-65 (state transition table of the 12-bit adaptive bit chance);
+// table[2*chance + bit] = next chance.  32.32 fixed point like the reference.
+void build_chance_table(uint16_t *t, uint32_t factor, int cut) {
+    const int64_t one = 1LL << 32;
+    const unsigned size = 4096, max_p = 4096 - cut;
+    memset(t, 0, sizeof(uint16_t) * size * 2);
+    unsigned last_p8 = 0;
+    int64_t p = one / 2;
+    for (unsigned i = 0; i < size / 2; i++) {
+        unsigned p8 = (unsigned)((size * p + one / 2) >> 32);
+        if (p8 <= last_p8) p8 = last_p8 + 1;
+        if (last_p8 && last_p8 < size && p8 <= max_p) t[last_p8 * 2 + 1] = (uint16_t)p8;
+        p += ((one - p) * factor + one / 2) >> 32;
+        last_p8 = p8;
+    }
+    for (unsigned i = size - max_p; i <= max_p; i++) {
+        if (t[i * 2 + 1]) continue;
+        p = ((int64_t)i * one + size / 2) / size;
+        p += ((one - p) * factor + one / 2) >> 32;
+        unsigned p8 = (unsigned)((size * p + one / 2) >> 32);
+        if (p8 <= i) p8 = i + 1;
+        if (p8 > max_p) p8 = max_p;
+        t[i * 2 + 1] = (uint16_t)p8;
+    }
+    for (unsigned i = 1; i < size; i++) t[i * 2] = (uint16_t)(size - t[(size - i) * 2 + 1]);
+}
+
+int parse_and_plan(const uint8_t *blob, size_t n, Plan &plan) {
+    plan = Plan();
+    ByteReader io{blob, n, 0, false};
+    if (n < 4 || (memcmp(blob, "FUIF", 4) && memcmp(blob, "FUAF", 4))) {
+        plan.error = FUIFGPU_E_NOT_FUIF;
+        plan.message = "not a FUIF stream";
+        return plan.error;
+    }
+    bool multi = !memcmp(blob, "FUAF", 4);
+    io.pos = 4;
+    plan.nb_channels = io.varint() - '0';
+    plan.bit_depth = io.varint() - '&';
+    plan.w = io.varint() + 1;
+    plan.h = io.varint() + 1;
+    if (multi) {
+        plan.nb_frames = io.varint() + 2;
+        (void)io.varint();
+        int numerator = io.varint();
+        if (numerator) for (int i = 1; i < plan.nb_frames; i++) (void)io.varint();
+        (void)io.varint();
+    }
+    plan.colormodel = io.varint();
+    plan.max_properties = io.varint();
+    if (io.eof || plan.nb_channels < 1 || plan.nb_channels > 64 || plan.bit_depth < 1 || plan.bit_depth > 30 || plan.w < 1 ||
+        plan.h < 1 || (int64_t)plan.w * plan.h > 0x7fffffffLL || plan.max_properties < 0 ||
+        plan.max_properties > 2 * kMaxRefs) {
+        plan.error = (plan.max_properties > 2 * kMaxRefs) ? FUIFGPU_E_UNSUPPORTED : FUIFGPU_E_CORRUPT;
+        plan.message = "implausible header";
+        return plan.error;
+    }
+    plan.minval = 0;
+    plan.maxval = (1 << plan.bit_depth) - 1;
+    int rel = 0;
+    for (int s = 0; s < 5; s++) { plan.responsive_offsets[s] = io.varint() + rel; rel = plan.responsive_offsets[s]; }
+    rel = (int)io.pos;
+    for (int s = 0; s < 5; s++) plan.responsive_offsets[s] += rel;
+
+    Builder b(plan);
+    for (int c = 0; c < plan.nb_channels; c++) {  // Image(w,h,maxval,nb_channels): image/image.h:117-122
+        LiveChannel ch{};
+        ch.plane = -1; ch.w = plan.w; ch.h = plan.h; ch.component = c;
+        b.live.push_back(ch);
+    }
+    int nb_transforms = io.varint();
+    if (nb_transforms < 0 || nb_transforms > 256) { plan.error = FUIFGPU_E_CORRUPT; plan.message = "bad transform count"; return plan.error; }
+    for (int i = 0; i < nb_transforms; i++) {
+        int v = io.varint();
+        if (v < 0) { plan.error = FUIFGPU_E_CORRUPT; plan.message = "truncated transform list"; return plan.error; }
+        TransformDesc t;
+        t.id = v & 0xf;
+        if (has_parameters(t.id)) {
+            int np = v >> 4;
+            for (int j = 0; j < np; j++) t.params.push_back(io.varint());
+        }
+        bool ok = true;
+        switch (t.id) {
+            case TR_YCBCR: case TR_YCOCG: case TR_QUANTIZE: break;
+            case TR_SUBSAMPLE: ok = b.meta_subsample(t.params); break;
+            case TR_DCT: ok = b.meta_dct(t.params); break;
+            case TR_SQUEEZE: ok = b.meta_squeeze(t.params); break;
+            default:
+                plan.error = FUIFGPU_E_UNSUPPORTED;
+                plan.message = "transform id " + std::to_string(t.id) + " is outside the MI355X hot-path scope";
+                return plan.error;
+        }
+        if (!ok) return plan.error;
+        plan.transforms.push_back(t);
+    }
+    if (io.eof) { plan.error = FUIFGPU_E_CORRUPT; plan.message = "truncated header"; return plan.error; }
+    plan.data_start = io.pos;
+
+    // coded channel table + coefficient slab layout
+    int64_t off = 0;
+    for (size_t c = 0; c < b.live.size(); c++) {
+        LiveChannel &ch = b.live[c];
+        ChannelGeom g{};
+        g.w = ch.w; g.h = ch.h; g.hshift = ch.hshift; g.vshift = ch.vshift; g.hcshift = ch.hcshift; g.vcshift = ch.vcshift;
+        g.component = ch.component;
+        g.coef_off = off;
+        off += align_up((int64_t)ch.w * ch.h, kPlaneAlign);
+        plan.coded.push_back(g);
+        PlaneInfo pi;
+        pi.w = ch.w; pi.h = ch.h; pi.qsrc = (int)c; pi.buf = BUF_COEF; pi.off = g.coef_off;
+        b.planes.push_back(pi);
+        ch.plane = (int)c;
+    }
+    plan.coef_elems = off;
+
+    // inverse schedule: Image::undo_transforms pops the list from the back (image/image.cpp:95-106)
+    for (int i = (int)plan.transforms.size() - 1; i >= 0; i--) {
+        TransformDesc &t = plan.transforms[i];
+        bool ok = true;
+        switch (t.id) {
+            case TR_SQUEEZE: ok = b.inv_squeeze(t.params); break;
+            case TR_QUANTIZE:
+                ok = b.inv_quantize();
+                for (int pl : b.pending_q_clear) b.planes[pl].qsrc = -1;
+                b.pending_q_clear.clear();
+                break;
+            case TR_DCT: ok = b.inv_dct(t.params); break;
+            case TR_SUBSAMPLE: ok = b.inv_subsample(t.params); break;
+            case TR_YCOCG: ok = b.inv_color(OP_YCOCG); break;
+            case TR_YCBCR: ok = b.inv_color(OP_YCBCR); break;
+            default: ok = false; break;
+        }
+        if (!ok) return plan.error ? plan.error : (plan.error = FUIFGPU_E_CORRUPT);
+    }
+    if (!b.finalize()) return plan.error;
+
+    uint64_t hsh = 1469598103934665603ull;
+    int hdr[8] = {plan.w, plan.h, plan.bit_depth, plan.nb_channels, plan.max_properties, plan.nb_frames, (int)plan.transforms.size(), 0};
+    hsh = fnv1a(hsh, hdr, sizeof(hdr));
+    for (auto &t : plan.transforms) {
+        hsh = fnv1a(hsh, &t.id, sizeof(int));
+        if (!t.params.empty()) hsh = fnv1a(hsh, t.params.data(), t.params.size() * sizeof(int));
+    }
+    plan.signature = hsh;
+    return FUIFGPU_OK;
+}
+
+}  // namespace fuifgpu

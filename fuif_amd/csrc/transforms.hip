@@ -1,0 +1,350 @@
+// fuif_amd/csrc/transforms.hip -- inverse-transform kernels of the FUIF decode path for gfx950.
+//
+// All of these are integer/FP64 streaming kernels bound by HBM bandwidth; none is GEMM-shaped, so
+// no MFMA.  Planes are row-major int32.  One launch processes one schedule op for a whole chunk
+// of images: grid.z = image, address = base[buf] + z*stride[buf] + plane offset.
+//
+//   k_inv_vsqueeze   transform/squeeze.h:173-224   one lane per column, serial down the rows
+//   k_inv_hsqueeze   transform/squeeze.h:81-132    one lane per row (the recurrence runs along x),
+//                                                  tiles staged through LDS so HBM sees full rows
+//   k_inv_ycocg      transform/ycocg.h:49-61       elementwise on three planes (+ clamp)
+//   k_inv_ycbcr      transform/ycbcr.h:49-60       float operands, double arithmetic, no FMA
+//   k_dequant        transform/quantize.h:32-49    elementwise * Channel::q (per image, per plane)
+//   k_idct8x8        transform/dct.h:88-107,282-291 FP64, reference summation order, no FMA
+//   k_upsample       transform/subsample.h:90-115  "fancy" 2x chroma upsampling
+//   k_clamp / k_copy_clamp   image/image.cpp:107-113
+#include <hip/hip_runtime.h>
+
+#include "fuifgpu_internal.h"
+#include "transforms.h"
+
+namespace fuifgpu {
+
+namespace {
+
+#define DEV __device__ __forceinline__
+
+DEV int32_t *plane_ptr(const Bases &b, const PlaneRef &p, int z) { return b.base[p.buf] + (int64_t)z * b.stride[p.buf] + p.off; }
+DEV int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// transform/squeeze.h:61-77.  C '/' truncates toward zero; the two clamps per branch are order dependent.
+DEV int smooth_tendency(int B, int a, int n) {
+    int diff = 0;
+    if (B >= a && a >= n) {
+        diff = (4 * B - 3 * n - a + 6) / 12;
+        if (diff - (diff & 1) > 2 * (B - a)) diff = 2 * (B - a) + 1;
+        if (diff + (diff & 1) > 2 * (a - n)) diff = 2 * (a - n);
+    } else if (B <= a && a <= n) {
+        diff = (4 * B - 3 * n - a - 6) / 12;
+        if (diff + (diff & 1) < 2 * (B - a)) diff = 2 * (B - a) - 1;
+        if (diff - (diff & 1) < 2 * (a - n)) diff = 2 * (a - n);
+    }
+    return diff;
+}
+// squeeze.h:103-107: A = ((avg<<1)+diff+(diff>0?-(diff&1):(diff&1)))>>1 ; B = A-diff
+DEV void unsqueeze_pair(int avg, int diff, int &A, int &B) {
+    A = ((avg << 1) + diff + (diff > 0 ? -(diff & 1) : (diff & 1))) >> 1;
+    B = A - diff;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// vertical unsqueeze: avg (w x h1) + residual (w x h2) -> out (w x (h1+h2)), h1-h2 in {0,1}
+__global__ __launch_bounds__(256) void k_inv_vsqueeze(Bases b, PlaneRef pa, PlaneRef pr, PlaneRef po, int clamp, int lo, int hi) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = pa.w, h1 = pa.h, h2 = pr.h;
+    if (x >= w) return;
+    const int32_t *a = plane_ptr(b, pa, blockIdx.z) + x;
+    const int32_t *r = plane_ptr(b, pr, blockIdx.z) + x;
+    int32_t *o = plane_ptr(b, po, blockIdx.z) + x;
+    int avg = a[0];
+    int prevB = avg;  // first pair uses tendency(avg,avg,next): squeeze.h:186
+    for (int y = 0; y < h2; y++) {
+        const int next_avg = (y + 1 < h1) ? a[(int64_t)(y + 1) * w] : avg;
+        const int res = r[(int64_t)y * w];
+        const int diff = res + smooth_tendency(prevB, avg, next_avg);
+        int A, B;
+        unsqueeze_pair(avg, diff, A, B);
+        o[(int64_t)(2 * y) * w] = clamp ? clampi(A, lo, hi) : A;
+        o[(int64_t)(2 * y + 1) * w] = clamp ? clampi(B, lo, hi) : B;
+        prevB = B;
+        avg = next_avg;
+    }
+    if ((h1 + h2) & 1) {  // squeeze.h:217-222
+        const int v = a[(int64_t)(h1 - 1) * w];
+        o[(int64_t)(2 * (h1 - 1)) * w] = clamp ? clampi(v, lo, hi) : v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// horizontal unsqueeze: avg (w1 x h) + residual (w2 x h) -> out ((w1+w2) x h), w1-w2 in {0,1}.
+// One wave per 64 rows; the row recurrence (left = previous B) is serial along x, so lanes own
+// rows.  Chunks of 32 pairs are staged through LDS: HBM sees contiguous 128/256-byte row segments,
+// LDS is read with an odd pitch (conflict free for one-row-per-lane access).
+constexpr int HS_ROWS = 64, HS_PAIRS = 32;
+__global__ __launch_bounds__(64) void k_inv_hsqueeze(Bases b, PlaneRef pa, PlaneRef pr, PlaneRef po, int clamp, int lo, int hi) {
+    __shared__ int s_avg[HS_ROWS * (HS_PAIRS + 1)];
+    __shared__ int s_res[HS_ROWS * (HS_PAIRS + 1)];
+    __shared__ int s_out[HS_ROWS * (2 * HS_PAIRS + 1)];
+    const int lane = threadIdx.x;
+    const int w1 = pa.w, w2 = pr.w, h = pa.h, wo = w1 + w2;
+    const int y0 = blockIdx.x * HS_ROWS;
+    const int32_t *a = plane_ptr(b, pa, blockIdx.z);
+    const int32_t *r = plane_ptr(b, pr, blockIdx.z);
+    int32_t *o = plane_ptr(b, po, blockIdx.z);
+    const int rows = min(HS_ROWS, h - y0);
+    const int myrow = y0 + lane;
+    int left = 0;       // previous B of my row
+    int avg_carry = 0;  // avg[x] for the first pair of the next chunk
+    if (lane < rows) avg_carry = a[(int64_t)myrow * w1];
+    for (int x0 = 0; x0 < w2; x0 += HS_PAIRS) {
+        const int np = min(HS_PAIRS, w2 - x0);
+        // cooperative loads: 2 rows x 32 columns per iteration
+        for (int it = 0; it < HS_ROWS / 2; it++) {
+            const int rr = it * 2 + (lane >> 5), cc = lane & 31;
+            if (rr < rows) {
+                const int64_t rowoff = (int64_t)(y0 + rr);
+                if (cc < np) s_res[rr * (HS_PAIRS + 1) + cc] = r[rowoff * w2 + x0 + cc];
+                // next averages: avg[x0+1 .. x0+np] (clamped to the row end: squeeze.h:100)
+                const int ax = x0 + 1 + cc;
+                if (cc < np) s_avg[rr * (HS_PAIRS + 1) + cc] = a[rowoff * w1 + (ax < w1 ? ax : w1 - 1)];
+            }
+        }
+        __syncthreads();
+        if (lane < rows) {
+            int avg = avg_carry;
+            for (int k = 0; k < np; k++) {
+                const int x = x0 + k;
+                int next_avg = s_avg[lane * (HS_PAIRS + 1) + k];
+                if (x + 1 >= w1) next_avg = avg;
+                const int B0 = (x == 0) ? avg : left;  // first pair: tendency(avg,avg,next) squeeze.h:89
+                const int diff = s_res[lane * (HS_PAIRS + 1) + k] + smooth_tendency(B0, avg, next_avg);
+                int A, B;
+                unsqueeze_pair(avg, diff, A, B);
+                s_out[lane * (2 * HS_PAIRS + 1) + 2 * k] = clamp ? clampi(A, lo, hi) : A;
+                s_out[lane * (2 * HS_PAIRS + 1) + 2 * k + 1] = clamp ? clampi(B, lo, hi) : B;
+                left = B;
+                avg = next_avg;
+            }
+            avg_carry = avg;
+        }
+        __syncthreads();
+        // cooperative stores: one 256-byte row segment per iteration
+        for (int rr = 0; rr < rows; rr++) {
+            if (lane < 2 * np) o[(int64_t)(y0 + rr) * wo + 2 * x0 + lane] = s_out[rr * (2 * HS_PAIRS + 1) + lane];
+        }
+        __syncthreads();
+    }
+    if ((wo & 1) && lane < rows) {  // squeeze.h:129
+        const int v = a[(int64_t)myrow * w1 + w1 - 1];
+        o[(int64_t)myrow * wo + wo - 1] = clamp ? clampi(v, lo, hi) : v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// transform/ycocg.h:49-61, in place on three planes (own row pitches), region w x h
+__global__ __launch_bounds__(256) void k_inv_ycocg(Bases b, PlaneRef p0, PlaneRef p1, PlaneRef p2, int w, int h, int maxval) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    int32_t *c0 = plane_ptr(b, p0, blockIdx.z) + (int64_t)y * p0.w + x;
+    int32_t *c1 = plane_ptr(b, p1, blockIdx.z) + (int64_t)y * p1.w + x;
+    int32_t *c2 = plane_ptr(b, p2, blockIdx.z) + (int64_t)y * p2.w + x;
+    const int Y = clampi(*c0, 0, maxval);
+    const int Co = *c1, Cg = *c2;
+    const int G = clampi(Y - ((-Cg) >> 1), 0, maxval);
+    const int B = clampi(Y + ((1 - Cg) >> 1) - (Co >> 1), 0, maxval);
+    const int R = clampi(Co + B, 0, maxval);
+    *c0 = R; *c1 = G; *c2 = B;
+}
+
+// transform/ycbcr.h:49-60: `float` operands, double arithmetic left to right, no contraction,
+// CLAMP in double, truncating conversion to the integer sample.
+__global__ __launch_bounds__(256) void k_inv_ycbcr(Bases b, PlaneRef p0, PlaneRef p1, PlaneRef p2, int w, int h, int minval, int maxval) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    int32_t *c0 = plane_ptr(b, p0, blockIdx.z) + (int64_t)y * p0.w + x;
+    int32_t *c1 = plane_ptr(b, p1, blockIdx.z) + (int64_t)y * p1.w + x;
+    int32_t *c2 = plane_ptr(b, p2, blockIdx.z) + (int64_t)y * p2.w + x;
+    const float half = (float)((maxval + 1) / 2);
+    const float yy = (float)*c0;
+    const float cb = __fsub_rn((float)*c1, half);
+    const float cr = __fsub_rn((float)*c2, half);
+    const double dy = (double)yy, dcb = (double)cb, dcr = (double)cr;
+    double r = __dadd_rn(__dadd_rn(dy, __dmul_rn(1.402, dcr)), 0.5);
+    double g = __dadd_rn(__dsub_rn(__dsub_rn(dy, __dmul_rn(0.344136, dcb)), __dmul_rn(0.714136, dcr)), 0.5);
+    double bl = __dadd_rn(__dadd_rn(dy, __dmul_rn(1.772, dcb)), 0.5);
+    const double mn = (double)minval, mx = (double)maxval;
+    r = r < mn ? mn : (r > mx ? mx : r);
+    g = g < mn ? mn : (g > mx ? mx : g);
+    bl = bl < mn ? mn : (bl > mx ? mx : bl);
+    *c0 = (int)r; *c1 = (int)g; *c2 = (int)bl;
+}
+
+// ---------------------------------------------------------------------------------------------
+// transform/quantize.h:32-49: plane *= q, q = ChannelMeta::q of the plane's source channel.
+// grid.y walks the op's plane list.
+__global__ __launch_bounds__(256) void k_dequant(Bases b, const PlaneRef *list, const ChannelMeta *meta, int n_channels, int img_first) {
+    const PlaneRef p = list[blockIdx.y];
+    const int q = meta[(int64_t)(img_first + blockIdx.z) * n_channels + p.qsrc].q;
+    if (q == 1) return;
+    const int64_t n = (int64_t)p.w * p.h;
+    int32_t *d = plane_ptr(b, p, blockIdx.z);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] *= q;
+}
+
+__global__ __launch_bounds__(256) void k_clamp(Bases b, PlaneRef src, PlaneRef dst, int lo, int hi) {
+    const int64_t n = (int64_t)dst.w * dst.h;
+    const int32_t *s = plane_ptr(b, src, blockIdx.z);
+    int32_t *d = plane_ptr(b, dst, blockIdx.z);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = clampi(s[i], lo, hi);
+}
+
+// ---------------------------------------------------------------------------------------------
+// transform/dct.h:60-77 -- the constants exactly as the reference prints them
+__constant__ double kDCT[64] = {
+    0.3535533906, 0.3535533906, 0.3535533906, 0.3535533906, 0.3535533906, 0.3535533906, 0.3535533906, 0.3535533906,
+    0.4903926402, 0.4157348062, 0.2777851165, 0.0975451610, -0.0975451610, -0.2777851165, -0.4157348062, -0.4903926402,
+    0.4619397663, 0.1913417162, -0.1913417162, -0.4619397663, -0.4619397663, -0.1913417162, 0.1913417162, 0.4619397663,
+    0.4157348062, -0.0975451610, -0.4903926402, -0.2777851165, 0.2777851165, 0.4903926402, 0.0975451610, -0.4157348062,
+    0.3535533906, -0.3535533906, -0.3535533906, 0.3535533906, 0.3535533906, -0.3535533906, -0.3535533906, 0.3535533906,
+    0.2777851165, -0.4903926402, 0.0975451610, 0.4157348062, -0.4157348062, -0.0975451610, 0.4903926402, -0.2777851165,
+    0.1913417162, -0.4619397663, 0.4619397663, -0.1913417162, -0.1913417162, 0.4619397663, -0.4619397663, 0.1913417162,
+    0.0975451610, -0.2777851165, 0.4157348062, -0.4903926402, 0.4903926402, -0.4157348062, 0.2777851165, -0.0975451610,
+};
+
+// One lane per 8x8 block.  Column pass then row pass (dct.h:101-106); every output is
+// 0.0 + sum_{u=0..7} k[8u+o]*in[u] accumulated left to right in double with separate mul and add
+// (the x86-64 reference build has no FMA), DC gets the float DC offset in float arithmetic
+// (dct.h:281,285), result rounded half away from zero (dct.h:289).
+__global__ __launch_bounds__(64) void k_idct8x8(Bases b, const PlaneRef *list, PlaneRef po, int bw, int bh, int maxval, int clamp, int lo, int hi) {
+    const int bx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int by = blockIdx.y;
+    if (bx >= bw || by >= bh) return;
+    double blk[64];
+    const float dcoff = (float)(((double)maxval + 1.0) * 4.0);
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        const PlaneRef p = list[i];
+        const int v = plane_ptr(b, p, blockIdx.z)[(int64_t)by * p.w + bx];
+        blk[i] = (i == 0) ? (double)__fadd_rn((float)v, dcoff) : (double)v;
+    }
+    double tmp[64];
+#pragma unroll
+    for (int x = 0; x < 8; x++) {
+#pragma unroll
+        for (int o = 0; o < 8; o++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc = __dadd_rn(acc, __dmul_rn(kDCT[8 * u + o], blk[u * 8 + x]));
+            tmp[o * 8 + x] = acc;
+        }
+    }
+    int32_t *o = plane_ptr(b, po, blockIdx.z) + (int64_t)(by * 8) * po.w + bx * 8;
+#pragma unroll
+    for (int y = 0; y < 8; y++) {
+        int outv[8];
+#pragma unroll
+        for (int oo = 0; oo < 8; oo++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc = __dadd_rn(acc, __dmul_rn(kDCT[8 * u + oo], tmp[8 * y + u]));
+            int v = (int)round(acc);
+            outv[oo] = clamp ? clampi(v, lo, hi) : v;
+        }
+        int4 *dst = reinterpret_cast<int4 *>(o + (int64_t)y * po.w);
+        dst[0] = make_int4(outv[0], outv[1], outv[2], outv[3]);
+        dst[1] = make_int4(outv[4], outv[5], outv[6], outv[7]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// transform/subsample.h:90-115: horizontal pass (3a+b+1)>>2 / (3a+c+2)>>2 with edge replication,
+// then the same vertically on the horizontally upsampled rows.  One lane per output sample.
+__global__ __launch_bounds__(256) void k_upsample(Bases b, PlaneRef pi, PlaneRef po, int srh, int srv, int clamp, int lo, int hi) {
+    const int X = blockIdx.x * blockDim.x + threadIdx.x;
+    const int Y = blockIdx.y;
+    const int ow = pi.w, oh = pi.h;
+    if (X >= po.w || Y >= po.h) return;
+    const int32_t *in = plane_ptr(b, pi, blockIdx.z);
+    auto hval = [&](int y, int Xo) -> int {  // value of the horizontally upsampled row y at column Xo
+        if (srh == 2) {
+            const int x = Xo >> 1;
+            const int c = in[(int64_t)y * ow + x];
+            if (Xo & 1) return (3 * c + in[(int64_t)y * ow + (x + 1 < ow ? x + 1 : x)] + 2) >> 2;
+            return (3 * c + in[(int64_t)y * ow + (x ? x - 1 : 0)] + 1) >> 2;
+        }
+        return in[(int64_t)y * ow + Xo];
+    };
+    int v;
+    if (srv == 2) {
+        const int y = Y >> 1;
+        const int c = hval(y, X);
+        if (Y & 1) v = (3 * c + hval(y + 1 < oh ? y + 1 : y, X) + 2) >> 2;
+        else v = (3 * c + hval(y ? y - 1 : 0, X) + 1) >> 2;
+    } else {
+        v = hval(Y, X);
+    }
+    plane_ptr(b, po, blockIdx.z)[(int64_t)Y * po.w + X] = clamp ? clampi(v, lo, hi) : v;
+}
+
+// ---------------------------------------------------------------------------------------------
+static inline dim3 grid1d(int64_t n, int block, int z, int y = 1) {
+    int64_t g = (n + block - 1) / block;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return dim3((unsigned)g, (unsigned)y, (unsigned)z);
+}
+
+void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, const ChannelMeta *meta, int n_channels, int img_first,
+               int n_images, hipStream_t stream) {
+    switch (op.kind) {
+        case OP_VSQUEEZE: {
+            const int w = op.src[0].w;
+            if (w <= 0 || op.dst[0].h <= 0) break;
+            hipLaunchKernelGGL(k_inv_vsqueeze, dim3((w + 255) / 256, 1, n_images), dim3(256), 0, stream, b, op.src[0], op.src[1], op.dst[0],
+                               op.clamp_out, op.lo, op.hi);
+            break;
+        }
+        case OP_HSQUEEZE: {
+            const int h = op.src[0].h;
+            if (h <= 0 || op.dst[0].w <= 0) break;
+            hipLaunchKernelGGL(k_inv_hsqueeze, dim3((h + HS_ROWS - 1) / HS_ROWS, 1, n_images), dim3(64), 0, stream, b, op.src[0], op.src[1],
+                               op.dst[0], op.clamp_out, op.lo, op.hi);
+            break;
+        }
+        case OP_YCOCG:
+            hipLaunchKernelGGL(k_inv_ycocg, dim3((op.p0 + 255) / 256, op.p1, n_images), dim3(256), 0, stream, b, op.src[0], op.src[1], op.src[2],
+                               op.p0, op.p1, op.hi);
+            break;
+        case OP_YCBCR:
+            hipLaunchKernelGGL(k_inv_ycbcr, dim3((op.p0 + 255) / 256, op.p1, n_images), dim3(256), 0, stream, b, op.src[0], op.src[1], op.src[2],
+                               op.p0, op.p1, op.lo, op.hi);
+            break;
+        case OP_QUANT: {
+            // grid.y = plane of the op's list; 64 grid-striding blocks per plane
+            hipLaunchKernelGGL(k_dequant, dim3(64, op.pad, n_images), dim3(256), 0, stream, b, dev_list + op.idct_first, meta, n_channels,
+                               img_first);
+            break;
+        }
+        case OP_IDCT:
+            hipLaunchKernelGGL(k_idct8x8, dim3((op.p0 + 63) / 64, op.p1, n_images), dim3(64), 0, stream, b, dev_list + op.idct_first, op.dst[0],
+                               op.p0, op.p1, op.hi, op.clamp_out, op.lo, op.hi);
+            break;
+        case OP_UPSAMPLE:
+            hipLaunchKernelGGL(k_upsample, dim3((op.dst[0].w + 255) / 256, op.dst[0].h, n_images), dim3(256), 0, stream, b, op.src[0], op.dst[0],
+                               op.p0, op.p1, op.clamp_out, op.lo, op.hi);
+            break;
+        case OP_COPY_CLAMP:
+        case OP_CLAMP:
+            hipLaunchKernelGGL(k_clamp, grid1d((int64_t)op.dst[0].w * op.dst[0].h, 256, n_images), dim3(256), 0, stream, b, op.src[0], op.dst[0],
+                               op.lo, op.hi);
+            break;
+        default:
+            break;
+    }
+}
+
+}  // namespace fuifgpu

@@ -1,0 +1,137 @@
+/* include/fuifgpu.h -- C-ABI of libfuifgpu.so: the MI355X (gfx950) FUIF decode path.
+ *
+ * This is the drop-in boundary for the ONE hot path of cloudinary/fuif: channel-group entropy
+ * decode followed by the inverse transform chain.  Each entry point names the reference
+ * interface it replaces (paths relative to the reference tree).  Plain pointers and sizes only;
+ * no C++ or torch types cross this boundary.  See INTEGRATION.md for the reference-side binding.
+ *
+ * Threading: a fuifgpu_batch is owned by one host thread at a time.  All device work is enqueued
+ * on the hipStream_t passed as `void *stream` (NULL = the default stream).
+ */
+#ifndef FUIFGPU_H
+#define FUIFGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FUIFGPU_ABI_VERSION 1
+
+/* error codes (0 = success).  The reference reports these conditions as `return false` +
+ * e_printf (encoding/encoding.cpp:601-605, 276-279, 697-700). */
+#define FUIFGPU_OK 0
+#define FUIFGPU_E_NOT_FUIF 1      /* bad magic / short header */
+#define FUIFGPU_E_CORRUPT 2       /* header or transform list is inconsistent */
+#define FUIFGPU_E_UNSUPPORTED 3   /* transform outside the hot-path scope (palette, 2D-match, ...) */
+#define FUIFGPU_E_ARG 4
+#define FUIFGPU_E_HIP 5           /* a HIP runtime call failed; see fuifgpu_last_error() */
+#define FUIFGPU_E_MISMATCH 6      /* image does not share the batch's plan signature */
+#define FUIFGPU_E_NOMEM 7
+
+/* per-image status bits written by the entropy kernel (fuifgpu_batch_status) */
+#define FUIFGPU_ST_TRUNCATED 1    /* EOF or preview limit reached: remaining samples are zero-filled
+                                     (not an error, encoding/encoding.cpp:209-219) */
+#define FUIFGPU_ST_CORRUPT 2      /* the reference would return false */
+#define FUIFGPU_ST_UNSUPPORTED 4
+
+typedef struct fuifgpu_plan fuifgpu_plan;    /* host: parsed header + channel table + inverse schedule */
+typedef struct fuifgpu_batch fuifgpu_batch;  /* device: buffers and state for N same-geometry images */
+
+/* replaces the header half of fuif_decode<IO>() (encoding/encoding.cpp:599-702): what
+ * `Image(w,h,maxval,nb_channels)` + every Transform::meta_apply() (transform/transform.cpp:66-81)
+ * compute, without touching pixel data. */
+typedef struct {
+    int32_t w, h, bit_depth, maxval, nb_channels, colormodel, max_properties, nb_frames;
+    int32_t nb_transforms, nb_coded_channels, nb_output_channels, nb_ops;
+    int32_t responsive_offsets[5];
+    int32_t data_start;
+    int64_t coef_elems, out_elems, tmp_elems; /* int32 elements per image */
+    uint64_t signature;
+} fuifgpu_image_info;
+
+/* mirrors the geometry fields of `class Channel` (image/image.h:54-91) */
+typedef struct {
+    int32_t w, h, hshift, vshift, hcshift, vcshift, component, reserved;
+    int64_t offset; /* element offset inside the per-image coefficient (coded) or output slab */
+} fuifgpu_channel_desc;
+
+const char *fuifgpu_strerror(int code);
+const char *fuifgpu_last_error(void);
+int fuifgpu_abi_version(void);
+
+/* ---- host side: header parse + planning (no GPU needed) ------------------------------------ */
+int fuifgpu_plan_create(const uint8_t *blob, size_t size, fuifgpu_plan **out);
+void fuifgpu_plan_destroy(fuifgpu_plan *plan);
+int fuifgpu_plan_info(const fuifgpu_plan *plan, fuifgpu_image_info *info);
+int fuifgpu_plan_coded_channel(const fuifgpu_plan *plan, int index, fuifgpu_channel_desc *desc);
+int fuifgpu_plan_output_channel(const fuifgpu_plan *plan, int index, fuifgpu_channel_desc *desc);
+/* transform list as stored in Image::transform after meta_apply (encoding.cpp:673-693);
+ * params_out receives at most cap ints, *nparams the real count */
+int fuifgpu_plan_transform(const fuifgpu_plan *plan, int index, int32_t *id, int32_t *params_out, int cap, int32_t *nparams);
+/* maniac/chance.cpp:31-65 build_table(), table[2*chance+bit]; host helper used by tests */
+void fuifgpu_build_chance_table(uint16_t *table8192, uint32_t alpha, int cut);
+
+/* ---- device side --------------------------------------------------------------------------- */
+/* Creates device state for `n_images` streams that all share `plan`'s signature.
+ * coef_ext / out_ext: optional caller-owned device slabs of n_images*coef_elems /
+ * n_images*out_elems int32 (e.g. a torch tensor's data_ptr); NULL = allocated by the library.
+ * tmp_images: number of images whose inverse-transform scratch is resident at once (0 = default). */
+int fuifgpu_batch_create(const fuifgpu_plan *plan, int n_images, size_t blob_capacity_bytes,
+                         int32_t *coef_ext, int32_t *out_ext, int tmp_images, fuifgpu_batch **out);
+void fuifgpu_batch_destroy(fuifgpu_batch *batch);
+
+/* Stage compressed streams (host pointers) into HBM.  Every blob must parse to the batch's
+ * signature.  preview: -1 = full decode, 0..4 = responsive truncation point
+ * (fuif_options::preview, encoding/encoding.h:34).  Replaces the IO object handed to
+ * fuif_decode<IO>() (fileio.h:33-143). */
+int fuifgpu_batch_upload(fuifgpu_batch *batch, const uint8_t *const *blobs, const size_t *sizes,
+                         int n_images, int preview, void *stream);
+
+/* replaces the channel loop of fuif_decode (encoding/encoding.cpp:708-717) and
+ * fuif_decode_channel (encoding/encoding.cpp:259-429) for every stream of the batch:
+ * fills the coefficient slab and the per-channel {minval,maxval,q}. */
+int fuifgpu_batch_decode(fuifgpu_batch *batch, void *stream);
+
+/* replaces Image::undo_transforms(0) (image/image.cpp:94-115) for every image of the batch:
+ * inverse Squeeze / Quantize / DCT / ChromaSubsample / YCoCg / YCbCr + final clamp into the
+ * output slab. */
+int fuifgpu_batch_undo_transforms(fuifgpu_batch *batch, void *stream);
+
+int fuifgpu_batch_sync(fuifgpu_batch *batch, void *stream);
+/* status[n_images] (FUIFGPU_ST_* bits), bytes_consumed[n_images] (io.ftell() at the end) */
+int fuifgpu_batch_status(fuifgpu_batch *batch, int32_t *status, uint32_t *bytes_consumed);
+/* {minval,maxval,q,decoded} of every coded channel of one image (Channel::minval/maxval/q) */
+int fuifgpu_batch_channel_meta(fuifgpu_batch *batch, int image, int32_t *meta4_per_channel);
+int32_t *fuifgpu_batch_coef_ptr(fuifgpu_batch *batch, int image);   /* device pointer */
+int32_t *fuifgpu_batch_out_ptr(fuifgpu_batch *batch, int image);    /* device pointer */
+int fuifgpu_batch_download_coef(fuifgpu_batch *batch, int image, int32_t *host, void *stream);
+int fuifgpu_batch_download_out(fuifgpu_batch *batch, int image, int32_t *host, void *stream);
+/* kernel time of the last decode / undo_transforms launch set, measured with hipEvents on the
+ * caller's stream (ms); used by bench.py for the roofline */
+int fuifgpu_batch_last_timing(fuifgpu_batch *batch, float *decode_ms, float *transform_ms);
+
+/* ---- single-transform entry points on raw device planes (row-major int32) ------------------
+ * These are what Transform::apply(image, true) (transform/transform.cpp:48-63) dispatches to;
+ * the C++ boundary layer (fuif_amd/csrc/boundary) and the unit parity tests call them. */
+/* transform/squeeze.h:81-132 inv_hsqueeze: avg w1 x h + residual w2 x h -> out (w1+w2) x h */
+int fuifgpu_inv_hsqueeze(const int32_t *avg, int w1, const int32_t *res, int w2, int h, int32_t *out, int n_planes,
+                         int64_t avg_stride, int64_t res_stride, int64_t out_stride, void *stream);
+/* transform/squeeze.h:173-224 inv_vsqueeze: avg w x h1 + residual w x h2 -> out w x (h1+h2) */
+int fuifgpu_inv_vsqueeze(const int32_t *avg, int h1, const int32_t *res, int h2, int w, int32_t *out, int n_planes,
+                         int64_t avg_stride, int64_t res_stride, int64_t out_stride, void *stream);
+/* transform/ycocg.h:33-63 inv_YCoCg, in place on three planes with row pitches p0,p1,p2 */
+int fuifgpu_inv_ycocg(int32_t *c0, int32_t *c1, int32_t *c2, int w, int h, int p0, int p1, int p2, int maxval, void *stream);
+/* transform/ycbcr.h:33-63 inv_YCbCr */
+int fuifgpu_inv_ycbcr(int32_t *c0, int32_t *c1, int32_t *c2, int w, int h, int p0, int p1, int p2, int minval, int maxval, void *stream);
+/* transform/dct.h:88-107 + 282-291: 64 coefficient planes (bw x bh each, src[i] in the
+ * reference's own zig-zag position order i=0..63) -> (8bw) x (8bh) samples; DC offset (maxval+1)*4 */
+int fuifgpu_idct8x8(const int32_t *const *src64_dev, int bw, int bh, int32_t *out, int maxval, void *stream);
+/* transform/subsample.h:90-115 "fancy" chroma upsampling, srh/srv in {1,2} */
+int fuifgpu_upsample(const int32_t *in, int w, int h, int srh, int srv, int32_t *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FUIFGPU_H */

@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures with the REAL reference (run in the build container only).
+
+  inputs  : seeded synthetic images (fuif_amd/synth.py) written as PNM/PAM (or JPEG via Pillow)
+  encoder : the unmodified reference CLI  oracle/_ref/fuif   (built by oracle/Makefile from /root/reference)
+  expected: per-plane SHA-256 (int32 little-endian bytes) + geometry of every channel BEFORE and AFTER
+            Image::undo_transforms(), produced by the real reference decoder (oracle/_ref/libfuifref.so,
+            FileIO semantics = what `fuif -d` uses), for full decodes, responsive previews (-R k) and
+            byte-truncated files.
+
+Nothing here is reference source; the .fuif files and hashes are data.  Re-run: python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from fuif_amd.synth import photographic, write_pnm  # noqa: E402
+from oracle_py import Ref, run_ref_cli  # noqa: E402
+
+
+def plane_hash(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype="<i4").tobytes()).hexdigest()
+
+
+def describe(dec):
+    out = []
+    for c in dec.channels:
+        m = {k: c[k] for k in ("w", "h", "minval", "maxval", "q", "hshift", "vshift", "hcshift", "vcshift", "component", "size")}
+        m["sha256"] = plane_hash(c["data"])
+        out.append(m)
+    return out
+
+
+# name, generator args, CLI flags
+SPECS = [
+    ("c1_rgb8_512x512", dict(w=512, h=512, channels=3, bits=8, seed=1), []),
+    ("rgb8_97x61", dict(w=97, h=61, channels=3, bits=8, seed=2), []),
+    ("gray8_64x48", dict(w=64, h=48, channels=1, bits=8, seed=3), []),
+    ("rgba14_80x72", dict(w=80, h=72, channels=4, bits=14, seed=4), ["-K", "0", "-X", "0", "-Y", "0"]),
+    ("raw14x4_64x64_squeezeonly", dict(w=64, h=64, channels=4, bits=14, seed=5), ["-C", "0", "-K", "0", "-X", "0", "-Y", "0"]),
+    ("rgb8_128x128_I0", dict(w=128, h=128, channels=3, bits=8, seed=6), ["-I", "0"]),
+    ("rgb8_128x128_E0", dict(w=128, h=128, channels=3, bits=8, seed=6), ["-E", "0"]),
+    ("rgb8_64x64_U", dict(w=64, h=64, channels=3, bits=8, seed=7), ["-U"]),
+    ("rgb8_160x120_Q80", dict(w=160, h=120, channels=3, bits=8, seed=8), ["-Q", "80"]),
+    ("rgb8_96x96_nosqueeze", dict(w=96, h=96, channels=3, bits=8, seed=9), ["-R", "0"]),
+    ("rgb8_tall_40x200", dict(w=40, h=200, channels=3, bits=8, seed=10), []),
+    ("rgb8_smooth_256x256", dict(w=256, h=256, channels=3, bits=8, seed=11, sigma=0.0), []),
+]
+JPEG_SPECS = [
+    ("jpeg420_256x192_q90", dict(w=256, h=192, channels=3, bits=8, seed=20), dict(quality=90, subsampling=2)),
+    ("jpeg444_136x120_q85", dict(w=136, h=120, channels=3, bits=8, seed=21), dict(quality=85, subsampling=0)),
+    ("jpeggray_120x88_q80", dict(w=120, h=88, channels=1, bits=8, seed=22), dict(quality=80)),
+]
+PREVIEWS = {"c1_rgb8_512x512": [0, 1, 2, 3, 4], "rgb8_97x61": [0, 2, 4], "jpeg420_256x192_q90": [0, 1, 2, 3, 4]}
+TRUNCATE = {"rgb8_97x61": [0.2, 0.55, 0.93], "rgb8_128x128_I0": [0.5], "jpeg420_256x192_q90": [0.4], "rgb8_64x64_U": [0.6]}
+
+
+def main():
+    ref = Ref()
+    manifest = {"generator": "tests/golden/make_golden.py", "reference": "cloudinary/fuif @ /root/reference (unmodified)", "fixtures": []}
+    tmp = tempfile.mkdtemp()
+    for name, gen, flags in SPECS + [(n, g, j) for n, g, j in JPEG_SPECS]:
+        img = photographic(**gen)
+        maxval = (1 << gen["bits"]) - 1
+        out = os.path.join(HERE, name + ".fuif")
+        if isinstance(flags, dict):
+            from PIL import Image
+            arr = np.moveaxis(img, 0, -1).astype(np.uint8)
+            pil = Image.fromarray(arr[..., 0] if gen["channels"] == 1 else arr)
+            src = os.path.join(tmp, name + ".jpg")
+            pil.save(src, **flags)
+            cli_flags = []
+        else:
+            src = os.path.join(tmp, name + (".pam" if gen["channels"] in (2, 4) else ".ppm" if gen["channels"] == 3 else ".pgm"))
+            write_pnm(src, img, maxval)
+            cli_flags = flags
+        r = run_ref_cli(cli_flags + [src, out])
+        if r.returncode != 0 or not os.path.exists(out):
+            raise SystemExit("reference CLI failed for %s: %s %s" % (name, r.stdout[-400:], r.stderr[-400:]))
+        blob = open(out, "rb").read()
+        entry = {"name": name, "file": name + ".fuif", "bytes": len(blob), "file_sha256": hashlib.sha256(blob).hexdigest(),
+                 "source": gen, "cli_flags": cli_flags if not isinstance(flags, dict) else ["<jpeg>", json.dumps(flags)], "cases": []}
+        cases = [("full", -1, len(blob))]
+        cases += [("preview%d" % k, k, len(blob)) for k in PREVIEWS.get(name, [])]
+        cases += [("trunc%02d" % int(f * 100), -1, int(len(blob) * f)) for f in TRUNCATE.get(name, [])]
+        for cname, preview, nbytes in cases:
+            pre, post = ref.decode_both(blob[:nbytes], preview=preview, io_kind=0)
+            entry["cases"].append({"case": cname, "preview": preview, "nbytes": nbytes, "ok": bool(pre.ok),
+                                   "info": pre.info, "transforms": pre.transforms, "pre": describe(pre), "post": describe(post)})
+        # lossless fixtures must reproduce the source pixels
+        if not isinstance(flags, dict) and "-Q" not in flags:
+            full = entry["cases"][0]
+            _, post = ref.decode_both(blob)
+            assert all(np.array_equal(post.channels[c]["data"], img[c]) for c in range(gen["channels"])), name
+            full["lossless_roundtrip"] = True
+        manifest["fixtures"].append(entry)
+        print("%-32s %7d bytes  %d cases  channels=%d" % (name, len(blob), len(entry["cases"]), entry["cases"][0]["info"]["nch"]))
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=0, separators=(",", ":"))
+    print("total fixture bytes:", sum(e["bytes"] for e in manifest["fixtures"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,77 @@
+"""CPU: the C-ABI library loads, exports every symbol include/fuifgpu.h declares, and its host
+planner reproduces the reference's channel geometry (no compute calls: no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, all_cases, golden_blob
+
+
+def test_header_symbols_exported(gpulib):
+    hdr = open(os.path.join(ROOT, "include", "fuifgpu.h")).read()
+    declared = set(re.findall(r"\b(fuifgpu_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(gpulib.ABI_SYMBOLS), declared ^ set(gpulib.ABI_SYMBOLS)
+    L = ctypes.CDLL(os.path.join(ROOT, "fuif_amd", "libfuifgpu.so"))
+    for s in declared:
+        assert hasattr(L, s), s
+    assert gpulib.lib().fuifgpu_abi_version() == 1
+
+
+def test_plan_matches_reference_geometry(gpulib, manifest):
+    keys = ("w", "h", "hshift", "vshift", "hcshift", "vcshift", "component")
+    for e in manifest["fixtures"]:
+        c = e["cases"][0]
+        blob = golden_blob(e, c)
+        p = gpulib.Plan(blob)
+        assert (p.info.w, p.info.h, p.info.maxval) == (c["info"]["w"], c["info"]["h"], c["info"]["maxval"])
+        assert [[t[0], t[1]] for t in p.transforms] == [[t[0], t[1]] for t in c["transforms"]], e["name"]
+        coded = p.coded_channels
+        assert len(coded) == len(c["pre"]), e["name"]
+        for a, b in zip(coded, c["pre"]):
+            assert tuple(a[k] for k in keys) == tuple(b[k] for k in keys), e["name"]
+        outs = p.output_channels
+        assert len(outs) == len(c["post"]), e["name"]
+        for a, b in zip(outs, c["post"]):
+            assert (a["w"], a["h"]) == (b["w"], b["h"]), e["name"]
+        # slabs: planes do not overlap and stay inside the slab
+        spans = sorted((ch["offset"], ch["offset"] + ch["w"] * ch["h"]) for ch in coded if ch["w"] * ch["h"])
+        assert all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))
+        assert spans[-1][1] <= p.info.coef_elems
+
+
+def test_plan_rejects_garbage(gpulib):
+    with pytest.raises(gpulib.FuifGpuError) as ei:
+        gpulib.Plan(b"not a fuif file at all")
+    assert ei.value.code == 1
+    with pytest.raises(gpulib.FuifGpuError):
+        gpulib.Plan(b"FUIF")
+
+
+def test_chance_tables_known_answers(gpulib):
+    """build_table known answers: SHA-256 / spot values of the tables the REAL reference's
+    build_table (maniac/chance.cpp:31-65) produced in the build container (oracle/_ref), plus the
+    spot values listed in SURVEY.md Appendix E.1."""
+    import hashlib
+    t = np.zeros(8192, np.uint16)
+    gpulib.lib().fuifgpu_build_chance_table(t.ctypes.data, 0x0d000000, 6)
+    assert hashlib.sha256(t.astype("<u2").tobytes()).hexdigest() == "acb83c93de3338dd8b92e21122b2be1d428010240f48ce11b2128283cd3f99cc"
+    assert [(int(t[2 * i]), int(t[2 * i + 1])) for i in (1, 6, 100, 1024, 2048, 3072, 4000, 4090, 4095)] == \
+        [(4096, 0), (6, 214), (95, 303), (972, 1180), (1944, 2152), (2916, 3124), (3797, 4005), (3882, 4090), (4096, 0)]
+    assert int(t.astype(np.int64).sum()) == 16773120
+    gpulib.lib().fuifgpu_build_chance_table(t.ctypes.data, 0xFFFFFFFF // 19, 2)
+    assert hashlib.sha256(t.astype("<u2").tobytes()).hexdigest() == "fb750fe49057a7a8059e8798e2935ce8909007c55ab401747b72096636439528"
+    assert [(int(t[2 * i]), int(t[2 * i + 1])) for i in (2, 6, 100, 1024, 2048, 4091)] == \
+        [(2, 217), (5, 221), (95, 310), (970, 1186), (1940, 2156), (3876, 4092)]
+
+
+def test_no_gpu_fails_loudly(gpulib, manifest):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    e = manifest["fixtures"][1]
+    with pytest.raises(gpulib.FuifGpuError) as ei:
+        gpulib.decode_batch([golden_blob(e, e["cases"][0])])
+    assert ei.value.code == 5  # FUIFGPU_E_HIP: no CPU fallback

@@ -1,0 +1,77 @@
+"""GPU parity (-m gpu): the HIP path through the C-ABI vs the golden vectors of the real reference
+and vs the oracle restatement, bit-exact, before and after the inverse transform chain."""
+import numpy as np
+import pytest
+
+from conftest import all_cases, golden_blob, plane_hash
+
+pytestmark = pytest.mark.gpu
+
+
+def _decode_case(gpulib, blob, preview):
+    plan = gpulib.Plan(blob)
+    batch = gpulib.Batch(plan, 1, len(blob))
+    try:
+        batch.upload([blob], preview)
+        batch.decode()
+        batch.sync()
+        st, used = batch.status()
+        pre = batch.coef_planes(0)
+        meta = batch.channel_meta(0)
+        batch.undo_transforms()
+        batch.sync()
+        post = batch.out_planes(0)
+        return pre, meta, post, int(st[0]), int(used[0])
+    finally:
+        batch.close()
+
+
+def test_golden_fixtures_bit_exact(gpulib, manifest, port):
+    failures = []
+    for e, c in all_cases(manifest):
+        blob = golden_blob(e, c)
+        what = "%s/%s" % (e["name"], c["case"])
+        pre, meta, post, st, used = _decode_case(gpulib, blob, c["preview"])
+        assert (st & 2) == 0, what
+        for i, (g, exp) in enumerate(zip(pre, c["pre"])):
+            if exp["size"] == 0:
+                ok = not g.any()          # undecoded channel reads as zeros
+            elif exp["size"] != exp["w"] * exp["h"]:
+                continue                  # constructor-sized plane the stream never reached
+            else:
+                ok = plane_hash(g) == exp["sha256"]
+            if not ok:
+                failures.append("%s pre channel %d" % (what, i))
+                break
+        assert len(post) == len(c["post"]), what
+        for i, (g, exp) in enumerate(zip(post, c["post"])):
+            if plane_hash(g) != exp["sha256"]:
+                failures.append("%s post channel %d" % (what, i))
+                break
+    assert not failures, failures[:10]
+
+
+def test_channel_meta_matches_oracle(gpulib, manifest, port):
+    for e in manifest["fixtures"]:
+        c = e["cases"][0]
+        blob = golden_blob(e, c)
+        pre, meta, post, st, used = _decode_case(gpulib, blob, -1)
+        d = port.decode(blob, undo=False)
+        assert used == d.stats["bytes"], e["name"]
+        for i, ch in enumerate(d.channels):
+            if ch["size"]:
+                assert (meta[i][0], meta[i][1], meta[i][2]) == (ch["minval"], ch["maxval"], ch["q"]), (e["name"], i)
+
+
+def test_batch_of_replicas_and_distinct_images(gpulib, manifest, port):
+    """several streams of one geometry in one launch: every stream decodes independently"""
+    e = next(x for x in manifest["fixtures"] if x["name"] == "rgb8_128x128_E0")
+    e2 = next(x for x in manifest["fixtures"] if x["name"] == "rgb8_128x128_I0")
+    b1 = golden_blob(e, e["cases"][0])
+    b2 = golden_blob(e2, e2["cases"][0])
+    blobs = [b1, b2, b1, b2, b2, b1, b1]
+    outs, st = gpulib.decode_batch(blobs)
+    assert not st.any()
+    exp = {id(b1): [c["sha256"] for c in e["cases"][0]["post"]], id(b2): [c["sha256"] for c in e2["cases"][0]["post"]]}
+    for b, planes in zip(blobs, outs):
+        assert [plane_hash(p) for p in planes] == exp[id(b)]
