@@ -22,7 +22,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libfuifgpu.so")
-_SOURCES = ["plan.cpp", "maniac_decode.hip", "transforms.hip", "capi.hip"]
+_SOURCES = ["plan.cpp", "writer.cpp", "maniac_decode.hip", "transforms.hip", "capi.hip"]
 _lib = None
 
 
@@ -62,6 +62,11 @@ class ChannelDesc(C.Structure):
                 ("offset", C.c_int64)]
 
 
+class EncodeOptions(C.Structure):
+    _fields_ = [("ycocg", C.c_int32), ("squeeze", C.c_int32), ("max_properties", C.c_int32), ("tree_mode", C.c_int32),
+                ("max_tree_nodes", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
 # every symbol include/fuifgpu.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
     "fuifgpu_strerror", "fuifgpu_last_error", "fuifgpu_abi_version", "fuifgpu_plan_create", "fuifgpu_plan_destroy",
@@ -70,7 +75,7 @@ ABI_SYMBOLS = [
     "fuifgpu_batch_decode", "fuifgpu_batch_undo_transforms", "fuifgpu_batch_sync", "fuifgpu_batch_status",
     "fuifgpu_batch_channel_meta", "fuifgpu_batch_coef_ptr", "fuifgpu_batch_out_ptr", "fuifgpu_batch_download_coef",
     "fuifgpu_batch_download_out", "fuifgpu_batch_last_timing", "fuifgpu_inv_hsqueeze", "fuifgpu_inv_vsqueeze",
-    "fuifgpu_inv_ycocg", "fuifgpu_inv_ycbcr", "fuifgpu_idct8x8", "fuifgpu_upsample",
+    "fuifgpu_inv_ycocg", "fuifgpu_inv_ycbcr", "fuifgpu_idct8x8", "fuifgpu_upsample", "fuifgpu_encode_image", "fuifgpu_free_blob",
 ]
 
 
@@ -113,6 +118,8 @@ def lib():
     L.fuifgpu_inv_ycbcr.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.fuifgpu_idct8x8.argtypes = [C.POINTER(vp), C.c_int, C.c_int, vp, C.c_int, vp]
     L.fuifgpu_upsample.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.fuifgpu_encode_image.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(EncodeOptions), C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.fuifgpu_free_blob.argtypes = [vp]; L.fuifgpu_free_blob.restype = None
     _lib = L
     return L
 
@@ -253,3 +260,16 @@ def decode_batch(blobs, preview=-1, undo=True):
         return outs, st
     finally:
         batch.close()
+
+
+def encode_image(planes, bit_depth=8, ycocg=True, squeeze=True, max_properties=12, tree_mode=1, max_tree_nodes=4095):
+    """(C,H,W) int32 planes -> lossless .fuif bytes (host C++ writer, csrc/writer.cpp)."""
+    planes = np.ascontiguousarray(planes, dtype=np.int32)
+    c, h, w = planes.shape
+    opt = EncodeOptions(int(ycocg), int(squeeze), max_properties, tree_mode, max_tree_nodes, (C.c_int32 * 3)(0, 0, 0))
+    out = C.c_void_p()
+    n = C.c_size_t(0)
+    _check(lib().fuifgpu_encode_image(planes.ctypes.data, w, h, c, bit_depth, C.byref(opt), C.byref(out), C.byref(n)))
+    blob = C.string_at(out.value, n.value)
+    lib().fuifgpu_free_blob(out)
+    return blob

@@ -178,7 +178,6 @@ int fuifgpu_batch_create(const fuifgpu_plan *plan, int n_images, size_t blob_cap
         if (e__ != hipSuccess) { int rc = hip_fail(e__, #call); fuifgpu_batch_destroy(b); return rc; } \
     } while (0)
     CHK(hipMalloc((void **)&b->d_blobs, b->blob_cap));
-    CHK(hipHostMalloc((void **)&b->h_blobs, b->blob_cap, hipHostMallocDefault));
     CHK(hipMalloc((void **)&b->d_jobs, sizeof(StreamJob) * n_images));
     CHK(hipMalloc((void **)&b->d_geom, sizeof(ChannelGeom) * std::max(nch, 1)));
     CHK(hipMemcpy(b->d_geom, p.coded.data(), sizeof(ChannelGeom) * nch, hipMemcpyHostToDevice));
@@ -221,26 +220,35 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
     b->jobs.assign(n_images, StreamJob{});
     size_t off = 0;
     Plan tmp;
+    // Distinct host blobs are copied H2D once; replicas (same host pointer) are duplicated D2D so a
+    // 1024-image batch built from K distinct streams moves K streams over PCIe, not 1024.
+    std::vector<std::pair<const uint8_t *, int>> seen;
+    HIPCHK(hipStreamSynchronize(st));
     for (int i = 0; i < n_images; i++) {
         if (sizes[i] > 0xFFFFFFF0ull) return FUIFGPU_E_ARG;
-        // identical bytes => identical header: skip re-planning replicas of the previous blob
-        bool same_as_prev = i > 0 && sizes[i] == sizes[i - 1] && blobs[i] == blobs[i - 1];
-        if (!same_as_prev) {
+        int src = -1;
+        for (auto &sp : seen) if (sp.first == blobs[i] && b->jobs[sp.second].blob_size == sizes[i]) { src = sp.second; break; }
+        size_t padded = (sizes[i] + 15) / 16 * 16 + 16;
+        if (off + padded > b->blob_cap) { g_last_error = "blob capacity exceeded"; return FUIFGPU_E_NOMEM; }
+        StreamJob &j = b->jobs[i];
+        if (src < 0) {
             int r = parse_and_plan(blobs[i], sizes[i], tmp);
             if (r != FUIFGPU_OK) { g_last_error = tmp.message; return r; }
             if (tmp.signature != b->plan.signature) { g_last_error = "image " + std::to_string(i) + " has a different geometry/transform chain"; return FUIFGPU_E_MISMATCH; }
+            HIPCHK(hipMemsetAsync(b->d_blobs + off + (padded - 32), 0, 32, st));
+            HIPCHK(hipMemcpyAsync(b->d_blobs + off, blobs[i], sizes[i], hipMemcpyHostToDevice, st));
+            j.data_start = (uint32_t)tmp.data_start;
+            j.limit = preview >= 0 ? (uint32_t)tmp.responsive_offsets[preview] : 0u;
+            seen.emplace_back(blobs[i], i);
+        } else {
+            HIPCHK(hipMemcpyAsync(b->d_blobs + off, b->d_blobs + b->jobs[src].blob_off, padded, hipMemcpyDeviceToDevice, st));
+            j.data_start = b->jobs[src].data_start;
+            j.limit = b->jobs[src].limit;
         }
-        size_t padded = (sizes[i] + 15) / 16 * 16 + 16;
-        if (off + padded > b->blob_cap) { g_last_error = "blob capacity exceeded"; return FUIFGPU_E_NOMEM; }
-        memcpy(b->h_blobs + off, blobs[i], sizes[i]);
-        memset(b->h_blobs + off + sizes[i], 0, padded - sizes[i]);
-        StreamJob &j = b->jobs[i];
-        j.blob_off = off; j.blob_size = (uint32_t)sizes[i]; j.data_start = (uint32_t)tmp.data_start;
-        j.limit = preview >= 0 ? (uint32_t)tmp.responsive_offsets[preview] : 0u;
+        j.blob_off = off; j.blob_size = (uint32_t)sizes[i];
         j.flags = 0;
         off += padded;
     }
-    HIPCHK(hipMemcpyAsync(b->d_blobs, b->h_blobs, off, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(b->d_jobs, b->jobs.data(), sizeof(StreamJob) * n_images, hipMemcpyHostToDevice, st));
     b->n_loaded = n_images;
     return FUIFGPU_OK;

@@ -65,7 +65,8 @@ struct ProtoOp {
     int src[3] = {-1, -1, -1};
     int dst[3] = {-1, -1, -1};
     int p0 = 0, p1 = 0;
-    std::vector<int> list;  // OP_IDCT: 64 source planes; OP_QUANT: planes to scale
+    std::vector<int> list;    // OP_IDCT: 64 source planes; OP_QUANT: planes to scale
+    std::vector<int> list_q;  // OP_QUANT: Channel::q source of each listed plane at the time of the op
 };
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
@@ -308,6 +309,7 @@ struct Builder {
             int pl = live[c].plane;
             if (planes[pl].qsrc < 0 || (int64_t)planes[pl].w * planes[pl].h == 0) continue;
             op.list.push_back(pl);
+            op.list_q.push_back(planes[pl].qsrc);
             touch(pl, idx);
         }
         if (!op.list.empty()) ops.push_back(op);
@@ -491,7 +493,11 @@ struct Builder {
             for (int d = 0; d < 3; d++) { op.src[d] = ref(po.src[d]); op.dst[d] = ref(po.dst[d]); }
             op.idct_first = (int)plan.idct_src.size();
             op.pad = (int)po.list.size();
-            for (int pl : po.list) plan.idct_src.push_back(ref(pl));
+            for (size_t li = 0; li < po.list.size(); li++) {
+                PlaneRef r = ref(po.list[li]);
+                if (li < po.list_q.size()) r.qsrc = po.list_q[li];
+                plan.idct_src.push_back(r);
+            }
             plan.ops.push_back(op);
         }
         plan.outputs.clear();

@@ -131,6 +131,23 @@ int fuifgpu_idct8x8(const int32_t *const *src64_dev, int bw, int bh, int32_t *ou
 /* transform/subsample.h:90-115 "fancy" chroma upsampling, srh/srv in {1,2} */
 int fuifgpu_upsample(const int32_t *in, int w, int h, int srh, int srv, int32_t *out, void *stream);
 
+/* ---- stream writer (host C++; the input generator) --------------------
+ * Writes a lossless FUIF stream the reference decoder accepts, with the format decisions of the
+ * reference CLI for photographic PNM input (fuif.cpp:380-455,580-588; encoding/encoding.cpp:455-573).
+ * tree_mode 0 = single-leaf MANIAC trees (byte-identical to `fuif -I 0`), 1 = trees learned by the
+ * writer's own greedy learner.  *blob_out is malloc'd; release with fuifgpu_free_blob. */
+typedef struct {
+    int32_t ycocg;          /* 1: YCoCg when nch >= 3 (CLI default) */
+    int32_t squeeze;        /* 1: default Squeeze (CLI default "responsive") */
+    int32_t max_properties; /* CLI default 12 (-E) */
+    int32_t tree_mode;      /* 0 none, 1 learned */
+    int32_t max_tree_nodes; /* cap for learned trees (<= 65535) */
+    int32_t reserved[3];
+} fuifgpu_encode_options;
+int fuifgpu_encode_image(const int32_t *planes, int w, int h, int nch, int bit_depth, const fuifgpu_encode_options *opt,
+                         uint8_t **blob_out, size_t *size_out);
+void fuifgpu_free_blob(uint8_t *blob);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,15 +63,16 @@ def test_channel_meta_matches_oracle(gpulib, manifest, port):
                 assert (meta[i][0], meta[i][1], meta[i][2]) == (ch["minval"], ch["maxval"], ch["q"]), (e["name"], i)
 
 
-def test_batch_of_replicas_and_distinct_images(gpulib, manifest, port):
-    """several streams of one geometry in one launch: every stream decodes independently"""
-    e = next(x for x in manifest["fixtures"] if x["name"] == "rgb8_128x128_E0")
-    e2 = next(x for x in manifest["fixtures"] if x["name"] == "rgb8_128x128_I0")
-    b1 = golden_blob(e, e["cases"][0])
-    b2 = golden_blob(e2, e2["cases"][0])
+def test_batch_of_replicas_and_distinct_streams(gpulib, manifest):
+    """several streams of one geometry in one launch: every stream decodes independently
+    (full stream, byte-truncated stream and replicas of both share one batch)"""
+    e = next(x for x in manifest["fixtures"] if x["name"] == "rgb8_128x128_I0")
+    full = next(c for c in e["cases"] if c["case"] == "full")
+    trunc = next(c for c in e["cases"] if c["case"] == "trunc50")
+    b1, b2 = golden_blob(e, full), golden_blob(e, trunc)
     blobs = [b1, b2, b1, b2, b2, b1, b1]
     outs, st = gpulib.decode_batch(blobs)
-    assert not st.any()
-    exp = {id(b1): [c["sha256"] for c in e["cases"][0]["post"]], id(b2): [c["sha256"] for c in e2["cases"][0]["post"]]}
-    for b, planes in zip(blobs, outs):
+    exp = {id(b1): [c["sha256"] for c in full["post"]], id(b2): [c["sha256"] for c in trunc["post"]]}
+    for b, planes, s in zip(blobs, outs, st):
         assert [plane_hash(p) for p in planes] == exp[id(b)]
+        assert (s & 1) == (1 if b is b2 else 0)

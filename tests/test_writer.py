@@ -1,0 +1,52 @@
+"""CPU: the product's FUIF writer (csrc/writer.cpp) against the REAL reference (oracle/_ref) and the oracle.
+
+* tree_mode 0 output is byte-identical to what the reference CLI writes with `-I 0` (pins RAC
+  encoder, binarisation, header, forward YCoCg/Squeeze, responsive offsets);
+* learned-tree output decodes with the real reference decoder back to the source pixels."""
+import os
+
+import numpy as np
+import pytest
+
+from fuif_amd.synth import photographic, write_pnm
+
+CASES = [(97, 61, 3, 8, 2), (64, 48, 1, 8, 3), (80, 72, 4, 14, 4), (33, 130, 3, 8, 12), (200, 9, 3, 8, 13)]
+
+
+@pytest.mark.parametrize("w,h,c,bits,seed", CASES)
+def test_writer_roundtrip_through_oracle(gpulib, port, w, h, c, bits, seed):
+    img = photographic(w, h, c, bits, seed=seed)
+    for tree_mode in (0, 1):
+        blob = gpulib.encode_image(img, bits, tree_mode=tree_mode)
+        d = port.decode(blob)
+        assert d.ok and d.stats["bytes"] == len(blob)
+        assert all(np.array_equal(d.channels[i]["data"], img[i]) for i in range(c))
+
+
+def test_writer_learns_real_trees(gpulib, port):
+    img = photographic(512, 384, 3, 8, seed=30)
+    blob = gpulib.encode_image(img, 8, tree_mode=1)
+    d = port.decode(blob)
+    assert all(np.array_equal(d.channels[i]["data"], img[i]) for i in range(3))
+    assert d.stats["tree_steps"] / d.stats["symbols"] > 0.5  # slow track with non-trivial trees
+
+
+@pytest.mark.parametrize("w,h,c,bits,seed", CASES[:3])
+def test_writer_accepted_by_real_reference(gpulib, ref, tmp_path, w, h, c, bits, seed):
+    from oracle_py import ref_cli, run_ref_cli
+    img = photographic(w, h, c, bits, seed=seed)
+    for tree_mode in (0, 1):
+        blob = gpulib.encode_image(img, bits, tree_mode=tree_mode)
+        d = ref.decode(blob)
+        assert d.ok and all(np.array_equal(d.channels[i]["data"], img[i]) for i in range(c))
+    if ref_cli() is None:
+        pytest.skip("reference CLI not built")
+    src = str(tmp_path / ("in.pam" if c in (2, 4) else "in.ppm" if c == 3 else "in.pgm"))
+    write_pnm(src, img, (1 << bits) - 1)
+    out = str(tmp_path / "ref.fuif")
+    r = run_ref_cli(["-I", "0", "-K", "0", "-X", "0", "-Y", "0", src, out])
+    assert r.returncode == 0, r.stderr
+    refblob = open(out, "rb").read()
+    mine = gpulib.encode_image(img, bits, tree_mode=0)
+    # the reference appends one stray byte (BlobIO::bytes_used = seek_pos+1, fileio.h:252-254)
+    assert mine == refblob[: len(mine)] and len(refblob) - len(mine) <= 1
