@@ -21,7 +21,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libfuifgpu.so")
+_LIB_PATH = os.environ.get("FUIF_AMD_LIB") or os.path.join(_HERE, "libfuifgpu.so")  # FUIF_AMD_LIB: diagnostic (-DFUIF_PROF) build
 _SOURCES = ["plan.cpp", "writer.cpp", "maniac_decode.hip", "transforms.hip", "capi.hip"]
 _lib = None
 
@@ -37,6 +37,8 @@ def build(force=False, verbose=False):
     srcs = [os.path.join(_HERE, "csrc", s) for s in _SOURCES]
     deps = srcs + [os.path.join(_HERE, "csrc", h) for h in ("fuifgpu_internal.h", "maniac_decode.h", "transforms.h")]
     deps.append(os.path.join(_HERE, "..", "include", "fuifgpu.h"))
+    if os.environ.get("FUIF_AMD_LIB"):
+        return _LIB_PATH
     if not force and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return _LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
@@ -74,7 +76,7 @@ ABI_SYMBOLS = [
     "fuifgpu_build_chance_table", "fuifgpu_batch_create", "fuifgpu_batch_destroy", "fuifgpu_batch_upload",
     "fuifgpu_batch_decode", "fuifgpu_batch_undo_transforms", "fuifgpu_batch_sync", "fuifgpu_batch_status",
     "fuifgpu_batch_channel_meta", "fuifgpu_batch_coef_ptr", "fuifgpu_batch_out_ptr", "fuifgpu_batch_download_coef",
-    "fuifgpu_batch_download_out", "fuifgpu_batch_last_timing", "fuifgpu_inv_hsqueeze", "fuifgpu_inv_vsqueeze",
+    "fuifgpu_batch_download_out", "fuifgpu_batch_last_timing", "fuifgpu_batch_profile", "fuifgpu_inv_hsqueeze", "fuifgpu_inv_vsqueeze",
     "fuifgpu_inv_ycocg", "fuifgpu_inv_ycbcr", "fuifgpu_idct8x8", "fuifgpu_upsample", "fuifgpu_encode_image", "fuifgpu_free_blob",
 ]
 
@@ -112,6 +114,7 @@ def lib():
     L.fuifgpu_batch_download_coef.argtypes = [vp, C.c_int, vp, vp]
     L.fuifgpu_batch_download_out.argtypes = [vp, C.c_int, vp, vp]
     L.fuifgpu_batch_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.fuifgpu_batch_profile.argtypes = [vp, vp]
     L.fuifgpu_inv_hsqueeze.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, vp]
     L.fuifgpu_inv_vsqueeze.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, vp]
     L.fuifgpu_inv_ycocg.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
@@ -231,6 +234,12 @@ class Batch:
         a, b = C.c_float(), C.c_float()
         _check(lib().fuifgpu_batch_last_timing(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def profile(self):
+        """(n_loaded, 8) uint64 phase cycle counters of the last decode (diagnostic builds only)"""
+        out = np.zeros((self.n_loaded, 8), np.uint64)
+        _check(lib().fuifgpu_batch_profile(self._h, out.ctypes.data))
+        return out
 
     def coef_planes(self, image):
         """coded channel planes of one image as a list of (h,w) int32 arrays (device -> host)"""

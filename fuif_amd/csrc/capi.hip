@@ -37,12 +37,13 @@ struct fuifgpu_batch {
     uint32_t *d_consumed = nullptr;
     uint16_t *d_tables = nullptr;
     uint8_t *d_scratch = nullptr;
-    size_t scratch_stride = 0, leaves_off = 0, stack_off = 0;
+    size_t scratch_stride = 0, bfs_off = 0, leaves_off = 0, stack_off = 0, queue_off = 0;
     int max_nodes = kMaxNodes;
     int32_t *d_coef = nullptr, *d_out = nullptr, *d_tmp = nullptr;
     bool own_coef = false, own_out = false;
     int tmp_images = 0;
     PlaneRef *d_list = nullptr;
+    unsigned long long *d_prof = nullptr;
     // host staging (pinned)
     uint8_t *h_blobs = nullptr;
     std::vector<StreamJob> jobs;
@@ -63,13 +64,17 @@ static int hip_fail(hipError_t e, const char *what) {
     } while (0)
 
 namespace fuifgpu {
-size_t maniac_scratch_bytes(int max_nodes, size_t *leaves_off, size_t *stack_off) {
-    size_t nodes = ((size_t)(max_nodes + 1) * 8 + 255) / 256 * 256;
-    size_t leaves = ((size_t)((max_nodes + 1) / 2 + 1) * kLeafStride * 2 + 255) / 256 * 256;
-    size_t stack = ((size_t)kTreeStackDepth * 24 + 255) / 256 * 256;
-    *leaves_off = nodes;
-    *stack_off = nodes + leaves;
-    return nodes + leaves + stack;
+size_t maniac_scratch_bytes(int max_nodes, size_t *bfs_off, size_t *leaves_off, size_t *stack_off, size_t *queue_off) {
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    size_t nodes = up((size_t)(max_nodes + 1) * 8);
+    size_t leaves = up((size_t)((max_nodes + 1) / 2 + 1) * kLeafStride * 2);
+    size_t stack = up((size_t)kTreeStackDepth * 24);
+    size_t queue = up((size_t)(max_nodes + 1) * 4);
+    *bfs_off = nodes;
+    *leaves_off = 2 * nodes;
+    *stack_off = 2 * nodes + leaves;
+    *queue_off = 2 * nodes + leaves + stack;
+    return 2 * nodes + leaves + stack + queue;
 }
 }  // namespace fuifgpu
 
@@ -149,7 +154,7 @@ int fuifgpu_plan_transform(const fuifgpu_plan *plan, int index, int32_t *id, int
 void fuifgpu_batch_destroy(fuifgpu_batch *b) {
     if (!b) return;
     hipFree(b->d_blobs); hipFree(b->d_jobs); hipFree(b->d_geom); hipFree(b->d_meta); hipFree(b->d_status); hipFree(b->d_consumed);
-    hipFree(b->d_tables); hipFree(b->d_scratch); hipFree(b->d_tmp); hipFree(b->d_list);
+    hipFree(b->d_tables); hipFree(b->d_scratch); hipFree(b->d_tmp); hipFree(b->d_list); hipFree(b->d_prof);
     if (b->own_coef) hipFree(b->d_coef);
     if (b->own_out) hipFree(b->d_out);
     if (b->h_blobs) hipHostFree(b->h_blobs);
@@ -171,7 +176,7 @@ int fuifgpu_batch_create(const fuifgpu_plan *plan, int n_images, size_t blob_cap
     b->n = n_images;
     const Plan &p = b->plan;
     const int nch = (int)p.coded.size();
-    b->blob_cap = blob_capacity_bytes + (size_t)n_images * 32 + 64;
+    b->blob_cap = blob_capacity_bytes + (size_t)n_images * 32 + 1024;  // + slack for the 256-byte read window
 #define CHK(call)                                                        \
     do {                                                                 \
         hipError_t e__ = (call);                                         \
@@ -191,7 +196,7 @@ int fuifgpu_batch_create(const fuifgpu_plan *plan, int n_images, size_t blob_cap
         CHK(hipMalloc((void **)&b->d_tables, tables.size() * 2));
         CHK(hipMemcpy(b->d_tables, tables.data(), tables.size() * 2, hipMemcpyHostToDevice));
     }
-    b->scratch_stride = maniac_scratch_bytes(b->max_nodes, &b->leaves_off, &b->stack_off);
+    b->scratch_stride = maniac_scratch_bytes(b->max_nodes, &b->bfs_off, &b->leaves_off, &b->stack_off, &b->queue_off);
     CHK(hipMalloc((void **)&b->d_scratch, b->scratch_stride * n_images));
     if (coef_ext) b->d_coef = coef_ext;
     else { CHK(hipMalloc((void **)&b->d_coef, sizeof(int32_t) * (size_t)std::max<int64_t>(p.coef_elems, 1) * n_images)); b->own_coef = true; }
@@ -208,6 +213,8 @@ int fuifgpu_batch_create(const fuifgpu_plan *plan, int n_images, size_t blob_cap
         CHK(hipMalloc((void **)&b->d_list, sizeof(PlaneRef) * p.idct_src.size()));
         CHK(hipMemcpy(b->d_list, p.idct_src.data(), sizeof(PlaneRef) * p.idct_src.size(), hipMemcpyHostToDevice));
     }
+    CHK(hipMalloc((void **)&b->d_prof, sizeof(unsigned long long) * 8 * n_images));
+    CHK(hipMemset(b->d_prof, 0, sizeof(unsigned long long) * 8 * n_images));
     for (int i = 0; i < 4; i++) CHK(hipEventCreate(&b->ev[i]));
 #undef CHK
     *out = b;
@@ -262,8 +269,8 @@ int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
     DecodeParams P{};
     P.blobs = b->d_blobs; P.jobs = b->d_jobs; P.n_images = b->n_loaded; P.n_channels = nch; P.geom = b->d_geom;
     P.coef = b->d_coef; P.coef_stride = b->plan.coef_elems; P.meta = b->d_meta; P.status = b->d_status; P.consumed = b->d_consumed;
-    P.tables = b->d_tables; P.scratch = b->d_scratch; P.scratch_stride = b->scratch_stride; P.leaves_off = b->leaves_off;
-    P.stack_off = b->stack_off; P.max_properties = b->plan.max_properties; P.max_nodes = b->max_nodes;
+    P.tables = b->d_tables; P.scratch = b->d_scratch; P.scratch_stride = b->scratch_stride; P.bfs_off = b->bfs_off; P.leaves_off = b->leaves_off;
+    P.stack_off = b->stack_off; P.queue_off = b->queue_off; P.max_properties = b->plan.max_properties; P.max_nodes = b->max_nodes; P.prof = b->d_prof;
     HIPCHK(hipEventRecord(b->ev[0], st));
     launch_maniac_decode(P, st);
     HIPCHK(hipGetLastError());
@@ -340,6 +347,14 @@ int fuifgpu_batch_last_timing(fuifgpu_batch *b, float *decode_ms, float *transfo
         *transform_ms = -1.f;
         if (b->transform_timed) { HIPCHK(hipEventSynchronize(b->ev[3])); HIPCHK(hipEventElapsedTime(transform_ms, b->ev[2], b->ev[3])); }
     }
+    return FUIFGPU_OK;
+}
+
+// diagnostic: per-stream phase cycle counters of the last decode (only filled by -DFUIF_PROF builds)
+int fuifgpu_batch_profile(fuifgpu_batch *b, uint64_t *out8_per_image) {
+    if (!b || !out8_per_image || b->n_loaded < 1) return FUIFGPU_E_ARG;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out8_per_image, b->d_prof, sizeof(unsigned long long) * 8 * b->n_loaded, hipMemcpyDeviceToHost));
     return FUIFGPU_OK;
 }
 

@@ -2,10 +2,26 @@
 //
 // One 64-lane wavefront (= one workgroup) per stream.  The format has no intra-stream entry
 // points (a channel group's first byte is only known once the previous group is fully decoded,
-// maniac/rac.h:70-104), so a stream is an inherently serial chain; the batch provides the
-// parallelism (>=1024 streams = one per SIMD on 256 CUs).  Within the wave, control flow is
-// wave-uniform: every lane executes the same scalar program; lanes are used as a vector unit for
-// the bulk work (table staging, plane fills, leaf initialisation).
+// maniac/rac.h:70-104), so a stream is an inherently serial chain: the batch provides the
+// parallelism (1024 streams = one wave per SIMD on 256 CUs) and the kernel's job is to make the
+// per-symbol dependency chain as short as the hardware allows.  The wave is used as one scalar
+// processor (range coder state, tree position: SGPRs via readlane/readfirstlane) plus a 64-lane
+// vector unit:
+//   * compressed bytes: one coalesced 256-byte window per refill, lane i holds dword i,
+//     bytes are picked with v_readlane (no per-byte memory access);
+//   * context tree: nodes re-laid out breadth first after parsing, the first kLdsNodes of them
+//     live in LDS (one ds_read_b64 per level), deeper ones spill to the per-stream HBM scratch;
+//   * the properties of 64 consecutive pixels that do not depend on the pixel being decoded
+//     (reference channels, top row, position) are computed by 64 lanes at once and parked in LDS;
+//     per pixel one ds_read puts property p into lane p, the 7 left-dependent ones are patched
+//     with v_writelane, and the tree walk picks properties with v_readlane;
+//   * the 31 adaptive chances of the current leaf sit in lanes 0..30; a symbol's binary
+//     decisions only read them (v_readlane) and record (index,bit) in two scalar masks; all
+//     touched chances are advanced together by one vector table lookup after the symbol;
+//   * decoded pixels are collected in a VGPR (v_writelane) and stored 64 at a time.
+// LDS budget 39 KB per wave so that 4 streams share a CU (160 KB): 29 KB of tree nodes,
+// 8.4 KB of chunk properties, the rest small state.  The 16 KB chance transition table is read
+// through L1/L2 instead: its lookups are off the dependency chain thanks to the batched update.
 //
 // What it replaces in the reference:
 //   fuif_decode channel loop            encoding/encoding.cpp:708-717
@@ -19,6 +35,8 @@
 //   SimpleBitChance::put                maniac/chance.h:77-79
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "fuifgpu_internal.h"
 #include "maniac_decode.h"
 
@@ -28,37 +46,80 @@ namespace {
 
 #define DEV __device__ __forceinline__
 
-constexpr int CH_ZERO = 0, CH_SIGN = 1, CH_EXP = 2, CH_MANT = 16, CH_N = 31;
+// -DFUIF_PROF: per-phase shader-cycle counters (s_memtime) written to DecodeParams::prof[img*8+k]
+#ifdef FUIF_PROF
+#define PROF_DECL unsigned long long prof_t0 = 0, prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF_START() prof_t0 = __builtin_readcyclecounter()
+#define PROF_LAP(k) do { unsigned long long t__ = __builtin_readcyclecounter(); prof_acc[k] += t__ - prof_t0; prof_t0 = t__; } while (0)
+#else
+#define PROF_DECL
+#define PROF_START()
+#define PROF_LAP(k)
+#endif
 
-struct Node {  // maniac/compound.h:41-51
-    int16_t property;
-    uint16_t child;
+constexpr int CH_ZERO = 0, CH_SIGN = 1, CH_EXP = 2, CH_MANT = 16, CH_N = 31;
+constexpr int kLdsNodes = 3712;   // 29 KB of breadth-first tree nodes in LDS
+constexpr int kPropPitch = 33;    // odd pitch: conflict-free column writes / row reads
+
+DEV int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+DEV uint32_t rflu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+DEV int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+// clang for ROCm 7.2 has no writelane builtin: a uniform compare + v_cndmask does the same job
+DEV int wrlane(int val, int l, int old) { return ((int)threadIdx.x == l) ? val : old; }
+
+struct Node {  // maniac/compound.h:41-51; property -1 = leaf, child = leaf id
     int32_t splitval;
+    uint16_t child;
+    int16_t property;
 };
+
+// One 64-bit load per tree level.  hipcc otherwise splits the node into two dependent 32-bit
+// loads (it sinks the splitval load behind the leaf test), doubling the per-level latency.
+DEV uint2 lds_load_node(uint32_t lds_byte_addr) {
+    uint2 v;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_byte_addr) : "memory");
+    return v;
+}
+DEV uint2 global_load_node(const void *p) {
+    uint2 v;
+    asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
 
 struct Frame {  // one pending inner node of the pre-order tree parse
     int32_t p, oldmin, oldmax, splitval, child, stage;
 };
 
+// Byte source with FileIO / BlobReader end-of-stream semantics (fileio.h:33-143).  `win` is the
+// only per-lane member: lane i holds bytes [win_base+4i, win_base+4i+4) of the stream.
 struct Stream {
     const uint8_t *p;
-    uint32_t size, pos, limit;
+    uint32_t size, pos, limit, win_base;
+    uint32_t win;
     int eof_flag;   // FileIO::isEOF() = feof(): only after a failed read (fileio.h:55-63)
     int blob_mode;  // BlobReader::isEOF(): pos >= size (fileio.h:100-102)
 };
 
-DEV int s_getc(Stream &s) {
+DEV int s_getc(Stream &s, int lane) {
     if (s.pos >= s.size) { s.eof_flag = 1; return -1; }
-    return s.p[s.pos++];
+    uint32_t idx = s.pos - s.win_base;
+    if (idx >= 256u) {
+        s.win_base = s.pos & ~255u;
+        s.win = reinterpret_cast<const uint32_t *>(s.p + s.win_base)[lane];
+        idx = s.pos - s.win_base;
+    }
+    const uint32_t word = (uint32_t)rdlane((int)s.win, (int)(idx >> 2));
+    s.pos++;
+    return (int)((word >> ((idx & 3u) * 8u)) & 0xFFu);
 }
 DEV bool s_eof(const Stream &s) { return s.blob_mode ? (s.pos >= s.size) : (s.eof_flag != 0); }
 DEV bool s_limit_hit(const Stream &s) { return s_eof(s) || (s.limit && s.pos >= s.limit); }
 
 // encoding/encoding.cpp:45-59
-DEV int s_varint(Stream &s) {
+DEV int s_varint(Stream &s, int lane) {
     uint32_t result = 0;
     for (int k = 0; k < 10; k++) {
-        int b = s_getc(s);
+        int b = s_getc(s, lane);
         if (b < 0) return -1;
         if (b < 128) return (int)(result + (uint32_t)b);
         result = (result + (uint32_t)(b - 128)) << 7;
@@ -67,10 +128,11 @@ DEV int s_varint(Stream &s) {
 }
 
 DEV int ilog2u(uint32_t l) { return l == 0 ? 0 : 31 - __clz((int)l); }
-DEV int slog(int x) {  // encoding/context_predict.h:53-61
-    if (x == 0) return 0;
-    if (x > 0) return 32 - __clz(x);
-    return -(32 - __clz(-x));
+DEV int slog(int x) {  // encoding/context_predict.h:53-61, branch free: sign(x) * bit_length(|x|)
+    const int m = x >> 31;
+    const int a = (x ^ m) - m;
+    const int r = 32 - __clz(a);  // __clz(0) == 32
+    return (r ^ m) - m;
 }
 DEV int iabs(int x) { return x < 0 ? -x : x; }
 DEV int median3(int a, int b, int c) {  // util.h:9-23
@@ -85,71 +147,111 @@ DEV int median3(int a, int b, int c) {  // util.h:9-23
 struct Rac {
     uint32_t range, low;
 };
-DEV void rac_input(Rac &r, Stream &s) {
-    if (r.range <= 0x10000u) { r.low <<= 8; r.range <<= 8; r.low |= (uint32_t)s_getc(s); }
-    if (r.range <= 0x10000u) { r.low <<= 8; r.range <<= 8; r.low |= (uint32_t)s_getc(s); }
+DEV void rac_input(Rac &r, Stream &s, int lane) {
+    if (r.range <= 0x10000u) { r.low <<= 8; r.range <<= 8; r.low |= (uint32_t)s_getc(s, lane); }
+    if (r.range <= 0x10000u) { r.low <<= 8; r.range <<= 8; r.low |= (uint32_t)s_getc(s, lane); }
 }
-DEV int rac_get(Rac &r, Stream &s, uint32_t chance) {
-    uint32_t thr = r.range - chance;
+DEV int rac_get(Rac &r, Stream &s, int lane, uint32_t chance) {
+    const uint32_t thr = r.range - chance;
     int bit;
     if (r.low >= thr) { r.low -= thr; r.range = chance; bit = 1; }
     else { r.range = thr; bit = 0; }
-    rac_input(r, s);
+    rac_input(r, s, lane);
     return bit;
 }
-DEV void rac_init(Rac &r, Stream &s) {
+DEV void rac_init(Rac &r, Stream &s, int lane) {
     r.range = 1u << 24; r.low = 0;
-    for (int k = 0; k < 3; k++) { r.low <<= 8; r.low |= (uint32_t)s_getc(s); }
+    for (int k = 0; k < 3; k++) { r.low <<= 8; r.low |= (uint32_t)s_getc(s, lane); }
 }
 // rac.h:43-52: (range*b12+0x800)>>12 without a 64-bit product
 DEV uint32_t chance12(uint32_t range, uint32_t b12) { return (((range & 0xFFFu) * b12 + 0x800u) >> 12) + ((range >> 12) * b12); }
-DEV int rac_bit(Rac &r, Stream &s) { return rac_get(r, s, r.range >> 1); }
+DEV int rac_bit(Rac &r, Stream &s, int lane) { return rac_get(r, s, lane, r.range >> 1); }
 
 // maniac/symbol.h:44-57
-DEV int uniform_read(Rac &r, Stream &s, int min, int len) {
+DEV int uniform_read(Rac &r, Stream &s, int lane, int min, int len) {
     while (len != 0) {
         int med = len / 2;
-        if (rac_bit(r, s)) { min = min + med + 1; len = len - (med + 1); }
+        if (rac_bit(r, s, lane)) { min = min + med + 1; len = len - (med + 1); }
         else len = med;
     }
     return min;
 }
 
-// One adaptive decision (compound.h:90-95 + chance.h:77-79).  CH: chance storage, TB: table.
-template <typename CH, typename TB>
-DEV int coder_bit(Rac &r, Stream &s, CH ch, int idx, TB table) {
-    uint32_t c = ch[idx];
-    int bit = rac_get(r, s, chance12(r.range, c));
-    ch[idx] = table[c * 2 + bit];
+// ---- memory-resident contexts (tree coder): compound.h:90-95 + chance.h:77-79 -------------------
+DEV int ctx_bit(Rac &r, Stream &s, int lane, uint16_t *ch, int idx, const uint16_t *table) {
+    const uint32_t c = rflu(ch[idx]);
+    const int bit = rac_get(r, s, lane, chance12(r.range, c));
+    const uint32_t nc = rflu(table[c * 2 + bit]);
+    if (lane == 0) ch[idx] = (uint16_t)nc;
     return bit;
 }
-
-// maniac/symbol.h:154-185
-template <typename CH, typename TB>
-DEV int read_symbol(Rac &r, Stream &s, CH ch, TB table, int min, int max) {
+// maniac/symbol.h:154-185 on an LDS context
+DEV int ctx_symbol(Rac &r, Stream &s, int lane, uint16_t *ch, const uint16_t *table, int min, int max) {
     if (min == max) return min;
-    if (coder_bit(r, s, ch, CH_ZERO, table)) return 0;
+    if (ctx_bit(r, s, lane, ch, CH_ZERO, table)) return 0;
     int sign;
-    if (min < 0) { if (max > 0) sign = coder_bit(r, s, ch, CH_SIGN, table); else sign = 0; }
+    if (min < 0) { if (max > 0) sign = ctx_bit(r, s, lane, ch, CH_SIGN, table); else sign = 0; }
     else sign = 1;
     const int amax = sign ? max : -min;
     const int emax = ilog2u((uint32_t)amax);
     int e = 0;
-    for (; e < emax; e++) if (coder_bit(r, s, ch, CH_EXP + e, table)) break;
+    for (; e < emax; e++) if (ctx_bit(r, s, lane, ch, CH_EXP + e, table)) break;
     int have = 1 << e;
     for (int pos = e; pos > 0;) {
         pos--;
         int minabs1 = have | (1 << pos);
         if (minabs1 > amax) continue;
-        if (coder_bit(r, s, ch, CH_MANT + pos, table)) have = minabs1;
+        if (ctx_bit(r, s, lane, ch, CH_MANT + pos, table)) have = minabs1;
     }
     return sign ? have : -have;
 }
-template <typename CH, typename TB>
-DEV int read_symbol2(Rac &r, Stream &s, CH ch, TB table, int min, int max) {  // symbol.h:235-239
-    if (min > 0) return read_symbol(r, s, ch, table, 0, max - min) + min;
-    if (max < 0) return read_symbol(r, s, ch, table, min - max, 0) + max;
-    return read_symbol(r, s, ch, table, min, max);
+DEV int ctx_symbol2(Rac &r, Stream &s, int lane, uint16_t *ch, const uint16_t *table, int min, int max) {  // symbol.h:235-239
+    if (min > 0) return ctx_symbol(r, s, lane, ch, table, 0, max - min) + min;
+    if (max < 0) return ctx_symbol(r, s, lane, ch, table, min - max, 0) + max;
+    return ctx_symbol(r, s, lane, ch, table, min, max);
+}
+
+// ---- register-resident leaf (pixel coder) --------------------------------------------------------
+// lane i (< 31) of `leafv` holds chance i of the current leaf.  A decision reads it with
+// v_readlane and records (index, bit) in the scalar masks; leaf_commit() advances every touched
+// chance at once with one vector lookup in the transition table.
+struct LeafRegs {
+    int leafv;          // per lane
+    uint32_t touched;   // scalar
+    uint32_t bits;      // scalar
+};
+DEV int leaf_bit(Rac &r, Stream &s, int lane, LeafRegs &L, int idx) {
+    const uint32_t c = (uint32_t)rdlane(L.leafv, idx);
+    const int bit = rac_get(r, s, lane, chance12(r.range, c));
+    L.touched |= 1u << idx;
+    L.bits |= (uint32_t)bit << idx;
+    return bit;
+}
+// maniac/symbol.h:154-185
+DEV int leaf_symbol(Rac &r, Stream &s, int lane, LeafRegs &L, int min, int max) {
+    if (min == max) return min;
+    if (leaf_bit(r, s, lane, L, CH_ZERO)) return 0;
+    int sign;
+    if (min < 0) { if (max > 0) sign = leaf_bit(r, s, lane, L, CH_SIGN); else sign = 0; }
+    else sign = 1;
+    const int amax = sign ? max : -min;
+    const int emax = ilog2u((uint32_t)amax);
+    int e = 0;
+    for (; e < emax; e++) if (leaf_bit(r, s, lane, L, CH_EXP + e)) break;
+    int have = 1 << e;
+    for (int pos = e; pos > 0;) {
+        pos--;
+        int minabs1 = have | (1 << pos);
+        if (minabs1 > amax) continue;
+        if (leaf_bit(r, s, lane, L, CH_MANT + pos)) have = minabs1;
+    }
+    return sign ? have : -have;
+}
+DEV void leaf_commit(LeafRegs &L, int lane, const uint16_t *table) {
+    if (L.touched) {
+        if ((L.touched >> lane) & 1u) L.leafv = table[L.leafv * 2 + ((L.bits >> lane) & 1u)];
+        L.touched = 0; L.bits = 0;
+    }
 }
 
 // maniac/symbol.h:115-138
@@ -176,15 +278,16 @@ DEV bool check_bit_depth(int minv, int maxv, int predictor) {
 }
 
 struct RefChan {  // one reference channel of the current group (context_predict.h:233-289)
-    const int32_t *data;
+    int64_t off;  // element offset of the plane inside the image's coefficient slab
     int32_t w, h, hshift, vshift;
 };
 
 struct Shared {
-    uint16_t table[8192];        // pixel-coder transition table (cut 6, alpha 0x0d000000)
-    uint16_t meta_ctx[3][32];    // three SimpleSymbolCoder contexts of the tree coder
-    int32_t props[kMaxProps];
+    Node nodes[kLdsNodes];               // breadth-first top of the context tree
+    int32_t cprops[64 * kPropPitch];     // [pixel of the chunk][property]
+    uint16_t meta_ctx[3][32];            // three SimpleSymbolCoder contexts of the tree coder
     int32_t lo[kMaxProps], hi[kMaxProps];
+    RefChan refs[kMaxRefs];
 };
 
 DEV void fill_plane(int32_t *plane, int64_t first, int64_t count, int v, int lane) {
@@ -199,76 +302,77 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
     const int lane = threadIdx.x;
     if (img >= P.n_images) return;
 
-    // stage the pixel-coder transition table in LDS (16 KB, 128-bit loads)
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(P.tables + 8192);
-        uint4 *dst = reinterpret_cast<uint4 *>(sh.table);
-        for (int i = lane; i < 1024; i += 64) dst[i] = src[i];
-    }
-    __syncthreads();
-    const uint16_t *tree_table = P.tables;  // cut 2, alpha 0xFFFFFFFF/19 (compound.h:262); only used while parsing trees
+    const uint16_t *tree_table = P.tables;          // cut 2, alpha 0xFFFFFFFF/19 (compound.h:262)
+    const uint16_t *pixel_table = P.tables + 8192;  // cut 6, alpha 0x0d000000 (encoding.h:54-55)
 
     const StreamJob job = P.jobs[img];
     Stream s;
     s.p = P.blobs + job.blob_off;
-    s.size = job.blob_size;
-    s.pos = job.data_start;
-    s.limit = job.limit;
+    s.size = rflu(job.blob_size);
+    s.pos = rflu(job.data_start);
+    s.limit = rflu(job.limit);
+    s.win_base = 0xFFFFFF00u;
+    s.win = 0;
     s.eof_flag = 0;
-    s.blob_mode = (int)(job.flags & 1u);
+    s.blob_mode = rfl((int)(job.flags & 1u));
 
     int32_t *coef = P.coef + (int64_t)img * P.coef_stride;
     ChannelMeta *meta = P.meta + (int64_t)img * P.n_channels;
     uint8_t *scratch = P.scratch + (size_t)img * P.scratch_stride;
-    Node *nodes = reinterpret_cast<Node *>(scratch);
+    Node *nodes = reinterpret_cast<Node *>(scratch);                          // parse-order nodes
+    Node *bfs_nodes = reinterpret_cast<Node *>(scratch + P.bfs_off);          // breadth-first nodes
     uint16_t *leaves = reinterpret_cast<uint16_t *>(scratch + P.leaves_off);
     Frame *stack = reinterpret_cast<Frame *>(scratch + P.stack_off);
+    int32_t *queue = reinterpret_cast<int32_t *>(scratch + P.queue_off);      // breadth-first work list
     const ChannelGeom *geom = P.geom;
     const int nch = P.n_channels;
     int status = 0;
+    PROF_DECL;
+    const uint32_t lds_nodes_addr = (uint32_t)(uintptr_t)(&sh.nodes[0]);  // LDS byte offset (low half of the flat address)
 
     // ---- fuif_decode channel loop: encoding.cpp:708-717 -------------------------------------
     for (int ci = 0; ci < nch; ci++) {
         if (!((s.limit == 0 || s.pos < s.limit) && !s_eof(s))) break;
-        if (!geom[ci].w || !geom[ci].h) continue;
+        if (!rfl(geom[ci].w) || !rfl(geom[ci].h)) continue;
 
         // ---- fuif_decode_channel: encoding.cpp:259-429 --------------------------------------
         const int beginc = ci;
         if (s_limit_hit(s)) continue;
-        int firstbyte = s_varint(s);
+        int firstbyte = s_varint(s, lane);
         if (s_limit_hit(s)) continue;
         const int endc = beginc + (firstbyte >> 4);
         const int compress = firstbyte & 1;
         const int predictor = (firstbyte & 14) >> 1;
-        int global_minv = 1 - s_varint(s);
+        int global_minv = 1 - s_varint(s, lane);
         if (s_limit_hit(s)) continue;
-        if (global_minv == 1) global_minv = s_varint(s);
+        if (global_minv == 1) global_minv = s_varint(s, lane);
         if (s_limit_hit(s)) continue;
-        const int global_maxv = global_minv + s_varint(s);
+        const int global_maxv = global_minv + s_varint(s, lane);
         if (s_limit_hit(s)) continue;
         if (endc >= nch || endc < beginc) { status |= ST_CORRUPT; break; }
 
         int firstrealc = beginc;
         bool fatal = false, early = false;
         for (int i = beginc; i <= endc; i++) {
-            const ChannelGeom g = geom[i];
-            if ((int64_t)g.w * g.h <= 0) continue;
+            const int gw = rfl(geom[i].w), gh = rfl(geom[i].h);
+            const int64_t goff = geom[i].coef_off;
+            if ((int64_t)gw * gh <= 0) continue;
             int minv = global_minv, maxv = global_maxv;
             if (endc > beginc && global_minv < global_maxv) {
-                minv += s_varint(s);
-                maxv = minv + s_varint(s);
+                minv += s_varint(s, lane);
+                maxv = minv + s_varint(s, lane);
             }
             int q = 1;
             if (minv == maxv) {
-                fill_plane(coef + g.coef_off, 0, (int64_t)g.w * g.h, minv, lane);
+                fill_plane(coef + goff, 0, (int64_t)gw * gh, minv, lane);
                 firstrealc++;
             }
             bool have_q = !(minv == 0 && maxv == 0);
-            if (have_q) q = s_varint(s);
+            if (have_q) q = s_varint(s, lane);
             if (lane == 0) { meta[i].minval = minv; meta[i].maxval = maxv; meta[i].q = q; meta[i].decoded = (minv == maxv) ? 1 : 0; }
             if (!have_q) continue;
             if (s_limit_hit(s)) {  // corrupt_or_truncated: encoding.cpp:209-219 (isEOF or limit => zero-fill, true)
-                fill_plane(coef + g.coef_off, 0, (int64_t)g.w * g.h, 0, lane);
+                fill_plane(coef + goff, 0, (int64_t)gw * gh, 0, lane);
                 if (lane == 0) meta[i].decoded = 1;
                 status |= ST_TRUNCATED;
                 early = true;
@@ -282,36 +386,37 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
         if (firstrealc > endc) { ci = endc; continue; }
 
         // ---- init_properties: context_predict.h:67-120 --------------------------------------
-        RefChan refs[kMaxRefs];
         int nrefs = 0;
         int nprops = 0;
         {
             int offset = 0;
             for (int j = beginc - 1; j >= 0 && offset < P.max_properties; j--) {
-                const int jmin = meta[j].minval, jmax = meta[j].maxval;
+                const int jmin = rfl(meta[j].minval), jmax = rfl(meta[j].maxval);
                 if (jmin == jmax) continue;
-                if (geom[j].hshift < 0) continue;
+                if (rfl(geom[j].hshift) < 0) continue;
                 int mn = jmin; if (mn > 0) mn = 0;
                 int mx = jmax; if (mx < 0) mx = 0;
                 if (lane == 0) {
                     sh.lo[nprops] = 0; sh.hi[nprops] = iabs(mx > -mn ? mx : mn);
                     sh.lo[nprops + 1] = slog(mn); sh.hi[nprops + 1] = slog(mx);
+                    RefChan rc;
+                    rc.off = geom[j].coef_off;
+                    rc.w = geom[j].w; rc.h = geom[j].h; rc.hshift = geom[j].hshift; rc.vshift = geom[j].vshift;
+                    sh.refs[nrefs] = rc;
                 }
                 nprops += 2; offset += 2;
-                refs[nrefs].data = coef + geom[j].coef_off;
-                refs[nrefs].w = geom[j].w; refs[nrefs].h = geom[j].h;
-                refs[nrefs].hshift = geom[j].hshift; refs[nrefs].vshift = geom[j].vshift;
                 nrefs++;
             }
             int mn = 0x7FFFFFFF, mx = (int)0x80000001, maxh = 0, maxw = 0;
             for (int j = beginc; j <= endc; j++) {
-                const int jmin = meta[j].minval, jmax = meta[j].maxval;
-                // note: zero-pixel channels keep their constructor range (0,0 for inserted
-                // residual channels) in the reference; meta[] is zero-initialised likewise
+                // zero-pixel channels keep their constructor range (0,0 for inserted residual
+                // channels) in the reference; meta[] is zero-initialised likewise
+                const int jmin = rfl(meta[j].minval), jmax = rfl(meta[j].maxval);
                 if (jmin < mn) mn = jmin;
                 if (jmax > mx) mx = jmax;
-                if (geom[j].h > maxh) maxh = geom[j].h;
-                if (geom[j].w > maxw) maxw = geom[j].w;
+                const int jh = rfl(geom[j].h), jw = rfl(geom[j].w);
+                if (jh > maxh) maxh = jh;
+                if (jw > maxw) maxw = jw;
             }
             if (mn > 0) mn = 0;
             if (mx < 0) mx = 0;
@@ -334,11 +439,10 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
 
         int predictability = 2048;
         if (predictor == 0 && compress) {
-            int rounded = s_varint(s);
+            int rounded = s_varint(s, lane);
             if (rounded < 1 || rounded > 127) {
                 if (s_limit_hit(s)) {
-                    const ChannelGeom g = geom[firstrealc];
-                    fill_plane(coef + g.coef_off, 0, (int64_t)g.w * g.h, 0, lane);
+                    fill_plane(coef + geom[firstrealc].coef_off, 0, (int64_t)geom[firstrealc].w * geom[firstrealc].h, 0, lane);
                     if (lane == 0) meta[firstrealc].decoded = 1;
                     status |= ST_TRUNCATED;
                     continue;
@@ -350,25 +454,27 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
         }
 
         Rac rac;
-        rac_init(rac, s);
+        rac_init(rac, s, lane);
 
         if (!compress) {
             // uncompressed group: encoding.cpp:334-354
             for (int i = beginc; i <= endc; i++) {
-                const ChannelGeom g = geom[i];
-                const int minv = meta[i].minval, maxv = meta[i].maxval;
+                const int gw = rfl(geom[i].w), gh = rfl(geom[i].h);
+                const int minv = rfl(meta[i].minval), maxv = rfl(meta[i].maxval);
                 if (minv == maxv) continue;
-                int32_t *plane = coef + g.coef_off;
+                int32_t *plane = coef + geom[i].coef_off;
                 const int zero = minv > 0 ? minv : (maxv < 0 ? maxv : 0);
                 int y = 0;
-                for (; y < g.h; y++) {
+                for (; y < gh; y++) {
                     if (s_limit_hit(s)) break;
-                    for (int x = 0; x < g.w; x++) {
-                        int v = uniform_read(rac, s, minv, maxv - minv);
-                        if (lane == 0) plane[(int64_t)y * g.w + x] = v;
+                    for (int x0 = 0; x0 < gw; x0 += 64) {
+                        const int nx = min(64, gw - x0);
+                        int rowv = 0;
+                        for (int j = 0; j < nx; j++) rowv = wrlane(uniform_read(rac, s, lane, minv, maxv - minv), j, rowv);
+                        if (lane < nx) plane[(int64_t)y * gw + x0 + lane] = rowv;
                     }
                 }
-                if (y < g.h) { fill_plane(plane, (int64_t)y * g.w, (int64_t)(g.h - y) * g.w, zero, lane); status |= ST_TRUNCATED; }
+                if (y < gh) { fill_plane(plane, (int64_t)y * gw, (int64_t)(gh - y) * gw, zero, lane); status |= ST_TRUNCATED; }
                 if (lane == 0) meta[i].decoded = 1;
                 if (s_limit_hit(s)) break;
             }
@@ -378,7 +484,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
         }
 
         // ---- MANIAC tree: compound.h:277-320 with an explicit stack -------------------------
-        __syncthreads();  // sh.lo/hi
+        __syncthreads();  // sh.lo/hi, sh.refs
         for (int k = lane; k < 3 * 32; k += 64) sh.meta_ctx[k / 32][k % 32] = 0;
         __syncthreads();
         if (lane == 0) for (int k = 0; k < 3; k++) symbol_chance_init(sh.meta_ctx[k], 1024);
@@ -388,11 +494,11 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
         {
             int pos = 0, depth = 0;
             while (true) {
-                int p = read_symbol2(rac, s, sh.meta_ctx[0], tree_table, 0, nprops) - 1;
+                int p = ctx_symbol2(rac, s, lane, sh.meta_ctx[0], tree_table, 0, nprops) - 1;
                 if (p != -1) {
-                    const int oldmin = sh.lo[p], oldmax = sh.hi[p];
+                    const int oldmin = rfl(sh.lo[p]), oldmax = rfl(sh.hi[p]);
                     if (oldmin >= oldmax) { tree_ok = false; break; }
-                    const int splitval = read_symbol2(rac, s, sh.meta_ctx[2], tree_table, oldmin, oldmax - 1);
+                    const int splitval = ctx_symbol2(rac, s, lane, sh.meta_ctx[2], tree_table, oldmin, oldmax - 1);
                     const int child = tree_size;
                     if (tree_size + 2 > P.max_nodes || depth >= kTreeStackDepth) { tree_ok = false; status |= ST_UNSUPPORTED; break; }
                     if (lane == 0) {
@@ -413,13 +519,13 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                 bool done = false;
                 while (true) {
                     if (depth == 0) { done = true; break; }
-                    Frame f = stack[depth - 1];
-                    if (f.stage == 0) {
-                        if (lane == 0) { sh.lo[f.p] = f.oldmin; sh.hi[f.p] = f.splitval; stack[depth - 1].stage = 1; }
-                        pos = f.child + 1;
+                    const int fstage = rfl(stack[depth - 1].stage), fp = rfl(stack[depth - 1].p);
+                    if (fstage == 0) {
+                        if (lane == 0) { sh.lo[fp] = stack[depth - 1].oldmin; sh.hi[fp] = stack[depth - 1].splitval; stack[depth - 1].stage = 1; }
+                        pos = rfl(stack[depth - 1].child) + 1;
                         break;
                     }
-                    if (lane == 0) sh.hi[f.p] = f.oldmax;
+                    if (lane == 0) sh.hi[fp] = stack[depth - 1].oldmax;
                     depth--;
                 }
                 __syncthreads();
@@ -430,8 +536,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
         if (!tree_ok) {
             // corrupt_or_truncated(io, image.channel[beginc], ...): encoding.cpp:358
             if (s_limit_hit(s)) {
-                const ChannelGeom g = geom[beginc];
-                fill_plane(coef + g.coef_off, 0, (int64_t)g.w * g.h, 0, lane);
+                fill_plane(coef + geom[beginc].coef_off, 0, (int64_t)geom[beginc].w * geom[beginc].h, 0, lane);
                 if (lane == 0) meta[beginc].decoded = 1;
                 status |= ST_TRUNCATED;
                 continue;
@@ -440,112 +545,206 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
             break;
         }
 
-        // ---- FinalPropertySymbolCoder ctor: compound.h:213-225 ------------------------------
+        // ---- breadth-first re-layout + leaf numbering -----------------------------------------
+        // Leaf ids only have to be a bijection (each leaf owns its chances, compound.h:213-225):
+        // number them in breadth-first order.  Children stay adjacent (child, child+1).
         const int nleaves = (tree_size + 1) / 2;
         {
-            // leaf numbering in node-array order
-            if (lane == 0) {
-                int leaf_id = 0;
-                for (int i = 0; i < tree_size; i++)
-                    if (nodes[i].property == -1) { nodes[i].child = (uint16_t)leaf_id; leaf_id++; }
-                symbol_chance_init(leaves, predictability);
-                leaves[31] = 0;
-            }
+            if (lane == 0) queue[0] = 0;
             __syncthreads();
-            // replicate leaf 0 (64 bytes) into all leaves, one 32-bit word per lane-slot
+            int head = 0, tail = 1, leaf_id = 0;
+            while (head < tail) {
+                const int o = rfl(queue[head]);
+                const Node n = nodes[o];
+                const int prop = rfl((int)n.property);
+                Node out;
+                out.property = (int16_t)prop;
+                out.splitval = rfl(n.splitval);
+                if (prop >= 0) {
+                    const int c = rfl((int)n.child);
+                    out.child = (uint16_t)tail;
+                    if (lane == 0) { queue[tail] = c; queue[tail + 1] = c + 1; }
+                    tail += 2;
+                } else {
+                    out.child = (uint16_t)leaf_id;
+                    leaf_id++;
+                }
+                if (lane == 0) {
+                    bfs_nodes[head] = out;
+                    if (head < kLdsNodes) sh.nodes[head] = out;
+                }
+                head++;
+                __syncthreads();
+            }
+        }
+        // FinalPropertySymbolCoder ctor: every leaf starts from SymbolChance(zero_chance) (compound.h:213-219)
+        {
+            if (lane == 0) { symbol_chance_init(leaves, predictability); leaves[31] = 0; }
+            __syncthreads();
             const uint32_t *l0 = reinterpret_cast<const uint32_t *>(leaves);
             uint32_t *lw = reinterpret_cast<uint32_t *>(leaves);
             const uint32_t mine = l0[lane & 15];
             for (int64_t i = 16 + lane; i < (int64_t)nleaves * 16; i += 64) lw[i] = mine;  // (i & 15) == (lane & 15)
             __syncthreads();
         }
+        LeafRegs L;
+        L.leafv = (lane < 32) ? (int)leaves[lane] : 0;
+        L.touched = 0; L.bits = 0;
+        int cur_leaf = 0;
+        auto switch_leaf = [&](int id) {
+            if (id != cur_leaf) {
+                if (lane < 32) {
+                    leaves[(int64_t)cur_leaf * kLeafStride + lane] = (uint16_t)L.leafv;
+                    L.leafv = (int)leaves[(int64_t)id * kLeafStride + lane];
+                }
+                cur_leaf = id;
+            }
+        };
 
         // ---- pixel loops: encoding.cpp:365-425 ----------------------------------------------
         for (int i = beginc; i <= endc; i++) {
-            const ChannelGeom g = geom[i];
-            const int minv = meta[i].minval, maxv = meta[i].maxval;
+            const int w = rfl(geom[i].w), h = rfl(geom[i].h);
+            const int ghs = rfl(geom[i].hshift), gvs = rfl(geom[i].vshift);
+            const int minv = rfl(meta[i].minval), maxv = rfl(meta[i].maxval);
             if (minv == maxv) continue;
-            int32_t *plane = coef + g.coef_off;
+            int32_t *plane = coef + geom[i].coef_off;
             const int zero = minv > 0 ? minv : (maxv < 0 ? maxv : 0);
-            const int w = g.w, h = g.h;
             int y = 0;
             if (tree_size == 1 && predictor == 0 && zero == 0) {
-                // fast track: encoding.cpp:371-383
+                // fast track: encoding.cpp:371-383 (single leaf, no properties)
                 for (; y < h; y++) {
                     if (s_limit_hit(s)) break;
-                    for (int x = 0; x < w; x++) {
-                        int v = read_symbol(rac, s, leaves, sh.table, minv, maxv);
-                        if (lane == 0) plane[(int64_t)y * w + x] = v;
+                    for (int x0 = 0; x0 < w; x0 += 64) {
+                        const int nx = min(64, w - x0);
+                        int rowv = 0;
+                        for (int j = 0; j < nx; j++) {
+                            rowv = wrlane(leaf_symbol(rac, s, lane, L, minv, maxv), j, rowv);
+                            leaf_commit(L, lane, pixel_table);
+                        }
+                        if (lane < nx) plane[(int64_t)y * w + x0 + lane] = rowv;
                     }
                 }
             } else {
-                for (; y < h; y++) {
-                    if (s_limit_hit(s)) break;
-                    __syncthreads();  // previous row's stores (lane 0) become visible to the loads below
-                    // reference rows for this y (context_predict.h:236-240)
-                    const int32_t *refrow[kMaxRefs];
-                    for (int k = 0; k < nrefs; k++) {
-                        int ry = (y << g.vshift) >> refs[k].vshift;
-                        if (ry >= refs[k].h) ry = refs[k].h - 1;
-                        refrow[k] = refs[k].data + (int64_t)ry * refs[k].w;
-                    }
-                    const int32_t *row = plane + (int64_t)y * w;
-                    const int32_t *row1 = row - w;        // y-1
-                    const int32_t *row2 = row - 2 * (int64_t)w;  // y-2
-                    int left = zero, leftleft = zero;
-                    for (int x = 0; x < w; x++) {
-                        // reference-channel properties: rx = min((x<<hshift)>>ref.hshift, ref.w-1)
-                        // covers the three cases of context_predict.h:241-284
-                        for (int k = 0; k < nrefs; k++) {
-                            int rx = (x << g.hshift) >> refs[k].hshift;
-                            if (rx >= refs[k].w) rx = refs[k].w - 1;
-                            const int v = refrow[k][rx];
-                            if (lane == 0) { sh.props[2 * k] = iabs(v); sh.props[2 * k + 1] = slog(v); }
-                        }
-                        // local neighbourhood: context_predict.h:126-133
-                        const int l = x ? left : zero;
-                        const int top = y ? row1[x] : zero;
-                        const int topleft = (x && y) ? row1[x - 1] : l;
-                        const int topright = (x + 1 < w && y) ? row1[x + 1] : top;
-                        const int ll = x > 1 ? leftleft : l;
-                        const int toptop = y > 1 ? row2[x] : top;
-                        if (lane == 0) {
-                            int32_t *p = sh.props + nrefprops;
-                            p[0] = iabs(top); p[1] = iabs(l); p[2] = slog(top); p[3] = slog(l);
-                            p[4] = y; p[5] = x;
-                            p[6] = l + top - topleft; p[7] = topleft + topright - top;
-                            p[8] = slog(l - topleft); p[9] = slog(topleft - top); p[10] = slog(top - topright);
-                            p[11] = slog(top - toptop); p[12] = slog(l - ll);
-                        }
-                        int guess;
-                        switch (predictor) {  // context_predict.h:157-166
-                            case 0: guess = zero; break;
-                            case 1: guess = (l + top) / 2; break;
-                            case 2: guess = median3(l + top - topleft, l, top); break;
-                            case 3: guess = l; break;
-                            case 4: guess = top; break;
-                            case 5: guess = (l + topleft + top + topright) / 4; break;
-                            case 6: { int t = l + top - topleft; guess = t < minv ? minv : (t > maxv ? maxv : t); break; }
-                            default: guess = median3(l + top - topleft, l, top); break;
-                        }
-                        __syncthreads();
-                        const int mn = minv - guess, mx = maxv - guess;
-                        int diff;
-                        if (mn == mx) diff = mn;  // compound.h:228
-                        else {
-                            int pos = 0;  // find_leaf: compound.h:142-153
-                            while (true) {
-                                const Node n = nodes[pos];
-                                if (n.property == -1) { pos = n.child; break; }
-                                pos = (sh.props[n.property] > n.splitval) ? n.child : n.child + 1;
+                // PRED0 = predictor 0 (all Squeeze residual / DCT coefficient channels): guess is a constant
+                auto rows = [&](auto pred0_tag) {
+                    constexpr bool PRED0 = decltype(pred0_tag)::value;
+                    for (; y < h; y++) {
+                        if (s_limit_hit(s)) break;
+                        __syncthreads();  // the previous row's stores are complete before it is re-read as `top`
+                        const int32_t *row1 = plane + (int64_t)(y - 1) * w;
+                        const int32_t *row2 = plane + (int64_t)(y - 2) * w;
+                        // left / leftleft start as `zero`, which is exactly what the edge rules
+                        // give at x == 0 (context_predict.h:126,131)
+                        int left = zero, leftleft = zero;
+                        for (int x0 = 0; x0 < w; x0 += 64) {
+                            const int nx = min(64, w - x0);
+                            // ---- vector phase: lane j prepares pixel x0+j ------------------------
+                            PROF_START();
+                            const int x = min(x0 + lane, w - 1);
+                            const int vtop = y ? row1[x] : zero;
+                            const int vtl = (y && x) ? row1[x - 1] : zero;                 // x == 0: topleft = left = zero
+                            const int vtr = (x + 1 < w && y) ? row1[x + 1] : vtop;         // context_predict.h:129
+                            const int vtt = y > 1 ? row2[x] : vtop;                        // :133
+                            {
+                                int32_t *cp = sh.cprops + lane * kPropPitch;
+#pragma unroll
+                                for (int k = 0; k < kMaxRefs; k++) {
+                                    if (k < nrefs) {
+                                        // rx = min((x<<hshift)>>ref.hshift, ref.w-1) covers the three cases of context_predict.h:241-284
+                                        const RefChan rc = sh.refs[k];
+                                        int ry = (y << gvs) >> rc.vshift; if (ry >= rc.h) ry = rc.h - 1;
+                                        int rx = (x << ghs) >> rc.hshift; if (rx >= rc.w) rx = rc.w - 1;
+                                        const int v = coef[rc.off + (int64_t)ry * rc.w + rx];
+                                        cp[2 * k] = iabs(v); cp[2 * k + 1] = slog(v);
+                                    }
+                                }
+                                int32_t *q = cp + nrefprops;
+                                q[0] = iabs(vtop); q[2] = slog(vtop); q[4] = y; q[5] = x0 + lane;
+                                q[10] = slog(vtop - vtr); q[11] = slog(vtop - vtt);
                             }
-                            diff = read_symbol(rac, s, leaves + (int64_t)pos * kLeafStride, sh.table, mn, mx);
+                            __syncthreads();
+                            PROF_LAP(0);
+                            int rowv = 0;
+                            // ---- scalar phase: one pixel at a time ---------------------------------
+                            for (int j = 0; j < nx; j++) {
+                                PROF_START();
+                                int pv = sh.cprops[j * kPropPitch + (lane & 31)];
+                                const int l = left;
+                                const int top = rdlane(vtop, j);
+                                const int tlraw = rdlane(vtl, j);
+                                const int topleft = y ? tlraw : l;           // y == 0: topleft = left (context_predict.h:128)
+                                const int topright = rdlane(vtr, j);
+                                const int ll = leftleft;
+                                // the left-dependent properties (context_predict.h:136-154)
+                                pv = wrlane(iabs(l), nrefprops + 1, pv);
+                                pv = wrlane(slog(l), nrefprops + 3, pv);
+                                pv = wrlane(l + top - topleft, nrefprops + 6, pv);
+                                pv = wrlane(topleft + topright - top, nrefprops + 7, pv);
+                                pv = wrlane(slog(l - topleft), nrefprops + 8, pv);
+                                pv = wrlane(slog(topleft - top), nrefprops + 9, pv);
+                                pv = wrlane(slog(l - ll), nrefprops + 12, pv);
+                                int guess = zero;
+                                if (!PRED0) {
+                                    switch (predictor) {  // context_predict.h:157-166
+                                        case 0: guess = zero; break;
+                                        case 1: guess = (l + top) / 2; break;
+                                        case 2: guess = median3(l + top - topleft, l, top); break;
+                                        case 3: guess = l; break;
+                                        case 4: guess = top; break;
+                                        case 5: guess = (l + topleft + top + topright) / 4; break;
+                                        case 6: { int t = l + top - topleft; guess = t < minv ? minv : (t > maxv ? maxv : t); break; }
+                                        default: guess = median3(l + top - topleft, l, top); break;
+                                    }
+                                }
+                                const int mn = minv - guess, mx = maxv - guess;
+                                int diff = mn;  // compound.h:228: min == max needs no symbol
+                                PROF_LAP(1);
+                                if (mn != mx) {
+                                    // find_leaf: compound.h:142-153.  Breadth-first numbering: once the walk leaves
+                                    // the LDS-resident top of the tree it stays in the HBM part.
+                                    int pos = 0, leaf = -1;
+                                    while (pos < kLdsNodes) {
+                                        const uint2 raw = lds_load_node(lds_nodes_addr + (uint32_t)pos * 8u);
+                                        const int meta_w = rfl((int)raw.y);           // child | property << 16
+                                        const int child = meta_w & 0xFFFF;
+                                        const int prop = meta_w >> 16;
+                                        if (prop < 0) { leaf = child; break; }
+                                        pos = child + ((rdlane(pv, prop) > rfl((int)raw.x)) ? 0 : 1);
+                                    }
+                                    while (leaf < 0) {
+                                        const uint2 raw = global_load_node(&bfs_nodes[pos]);
+                                        const int meta_w = rfl((int)raw.y);
+                                        const int child = meta_w & 0xFFFF;
+                                        const int prop = meta_w >> 16;
+                                        if (prop < 0) { leaf = child; break; }
+                                        pos = child + ((rdlane(pv, prop) > rfl((int)raw.x)) ? 0 : 1);
+                                    }
+                                    PROF_LAP(2);
+                                    switch_leaf(leaf);
+#ifdef FUIF_PROF
+                                    prof_acc[7] += (unsigned)rdlane(L.leafv, 0) & 0u;  // force the leaf load to complete inside this lap
+#endif
+                                    PROF_LAP(3);
+                                    diff = leaf_symbol(rac, s, lane, L, mn, mx);
+                                    PROF_LAP(4);
+                                    // advance the touched chances now: the table lookup overlaps the next pixel's tree walk
+                                    leaf_commit(L, lane, pixel_table);
+                                }
+                                const int v = diff + guess;
+                                rowv = wrlane(v, j, rowv);
+                                // leftleft = value at x-1 for the next pixel; at x == 0 the rule is leftleft = left
+                                leftleft = (x0 + j) ? l : v;
+                                left = v;
+                                PROF_LAP(5);
+                            }
+                            PROF_START();
+                            if (lane < nx) plane[(int64_t)y * w + x0 + lane] = rowv;
+                            __syncthreads();  // cprops is rewritten by the next chunk
+                            PROF_LAP(6);
                         }
-                        const int v = diff + guess;
-                        if (lane == 0) plane[(int64_t)y * w + x] = v;
-                        leftleft = l; left = v;
                     }
-                }
+                };
+                if (predictor == 0) rows(std::true_type{}); else rows(std::false_type{});
             }
             if (y < h) { __syncthreads(); fill_plane(plane, (int64_t)y * w, (int64_t)(h - y) * w, zero, lane); status |= ST_TRUNCATED; }
             if (lane == 0) meta[i].decoded = 1;
@@ -559,10 +758,13 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
     // image/image.h:82-85; zero-filled residuals, transform/squeeze.h:379-383)
     __syncthreads();
     for (int c = 0; c < nch; c++) {
-        const ChannelGeom g = geom[c];
-        if ((int64_t)g.w * g.h > 0 && meta[c].decoded == 0) fill_plane(coef + g.coef_off, 0, (int64_t)g.w * g.h, 0, lane);
+        const int gw = rfl(geom[c].w), gh = rfl(geom[c].h);
+        if ((int64_t)gw * gh > 0 && rfl(meta[c].decoded) == 0) fill_plane(coef + geom[c].coef_off, 0, (int64_t)gw * gh, 0, lane);
     }
     if (lane == 0) { P.status[img] = status; P.consumed[img] = s.pos; }
+#ifdef FUIF_PROF
+    if (lane == 0 && P.prof) for (int k = 0; k < 8; k++) P.prof[(size_t)img * 8 + k] = prof_acc[k];
+#endif
 }
 
 void launch_maniac_decode(const DecodeParams &P, hipStream_t stream) {

@@ -111,6 +111,10 @@ int fuifgpu_batch_download_out(fuifgpu_batch *batch, int image, int32_t *host, v
 /* kernel time of the last decode / undo_transforms launch set, measured with hipEvents on the
  * caller's stream (ms); used by bench.py for the roofline */
 int fuifgpu_batch_last_timing(fuifgpu_batch *batch, float *decode_ms, float *transform_ms);
+/* diagnostic builds (-DFUIF_PROF) only: 8 shader-cycle counters per stream of the last decode
+ * {vector phase, property patch, tree walk, leaf switch, symbol decode, per-pixel rest, row store, -};
+ * all zero in release builds */
+int fuifgpu_batch_profile(fuifgpu_batch *batch, uint64_t *out8_per_image);
 
 /* ---- single-transform entry points on raw device planes (row-major int32) ------------------
  * These are what Transform::apply(image, true) (transform/transform.cpp:48-63) dispatches to;

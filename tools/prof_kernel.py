@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Per-phase cycle breakdown of k_maniac_decode (diagnostic -DFUIF_PROF build).
+
+  hipcc ... -DFUIF_PROF -o fuif_amd/libfuifgpu_prof.so ;  FUIF_AMD_LIB=fuif_amd/libfuifgpu_prof.so python tools/prof_kernel.py [n_streams]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("FUIF_AMD_LIB", os.path.join(ROOT, "fuif_amd", "libfuifgpu_prof.so"))
+import fuif_amd  # noqa: E402
+from bench import make_inputs  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (3840, 2160)
+inputs = make_inputs(min(n, 8), w, h, 3, 8, 1000, "/tmp/fuif_bench_cache")
+blobs = [inputs[i % len(inputs)][1] for i in range(n)]
+plan = fuif_amd.Plan(blobs[0])
+batch = fuif_amd.Batch(plan, n, sum(len(b) for b in blobs))
+batch.upload(blobs)
+t0 = time.time(); batch.decode(); batch.sync(); dt = time.time() - t0
+prof = batch.profile().astype(np.float64)
+nsym = plan.info.coef_elems
+names = ["vector phase", "property patch", "tree walk", "leaf switch", "symbol decode", "pixel rest", "row store", "-"]
+print("streams %d  kernel %.2f s  -> %.3f us/symbol/stream" % (n, dt, dt / nsym * 1e6))
+tot = prof[:, :7].sum(axis=1).mean()
+for k in range(7):
+    c = prof[:, k].mean()
+    print("  %-16s %8.1f cycles/symbol  %5.1f %%" % (names[k], c / nsym, 100 * c / tot))
+print("  %-16s %8.1f cycles/symbol (instrumented)" % ("total", tot / nsym))
