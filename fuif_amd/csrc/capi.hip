@@ -67,14 +67,15 @@ namespace fuifgpu {
 size_t maniac_scratch_bytes(int max_nodes, size_t *bfs_off, size_t *leaves_off, size_t *stack_off, size_t *queue_off) {
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     size_t nodes = up((size_t)(max_nodes + 1) * 8);
+    size_t snodes = up((size_t)((max_nodes + 1) / 2 + 1) * 512);  // one supernode per inner node at worst
     size_t leaves = up((size_t)((max_nodes + 1) / 2 + 1) * kLeafStride * 2);
     size_t stack = up((size_t)kTreeStackDepth * 24);
     size_t queue = up((size_t)(max_nodes + 1) * 4);
     *bfs_off = nodes;
-    *leaves_off = 2 * nodes;
-    *stack_off = 2 * nodes + leaves;
-    *queue_off = 2 * nodes + leaves + stack;
-    return 2 * nodes + leaves + stack + queue;
+    *leaves_off = nodes + snodes;
+    *stack_off = nodes + snodes + leaves;
+    *queue_off = nodes + snodes + leaves + stack;
+    return nodes + snodes + leaves + stack + queue;
 }
 }  // namespace fuifgpu
 

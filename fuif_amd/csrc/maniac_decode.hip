@@ -58,7 +58,8 @@ namespace {
 #endif
 
 constexpr int CH_ZERO = 0, CH_SIGN = 1, CH_EXP = 2, CH_MANT = 16, CH_N = 31;
-constexpr int kLdsNodes = 3712;   // 29 KB of breadth-first tree nodes in LDS
+constexpr int kLdsSuper = 58;     // 58 supernodes x 512 B = 29 KB of the context tree in LDS
+constexpr uint32_t kLeafFlag = 0x800000u;
 constexpr int kPropPitch = 33;    // odd pitch: conflict-free column writes / row reads
 
 DEV int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -283,7 +284,7 @@ struct RefChan {  // one reference channel of the current group (context_predict
 };
 
 struct Shared {
-    Node nodes[kLdsNodes];               // breadth-first top of the context tree
+    uint2 snodes[kLdsSuper * 64];        // breadth-first top of the supernode tree: lane i = {split_i, prop_i | exit_i << 8}
     int32_t cprops[64 * kPropPitch];     // [pixel of the chunk][property]
     uint16_t meta_ctx[3][32];            // three SimpleSymbolCoder contexts of the tree coder
     int32_t lo[kMaxProps], hi[kMaxProps];
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
     ChannelMeta *meta = P.meta + (int64_t)img * P.n_channels;
     uint8_t *scratch = P.scratch + (size_t)img * P.scratch_stride;
     Node *nodes = reinterpret_cast<Node *>(scratch);                          // parse-order nodes
-    Node *bfs_nodes = reinterpret_cast<Node *>(scratch + P.bfs_off);          // breadth-first nodes
+    uint2 *snodes_g = reinterpret_cast<uint2 *>(scratch + P.bfs_off);         // supernodes (64 x 8 B each)
     uint16_t *leaves = reinterpret_cast<uint16_t *>(scratch + P.leaves_off);
     Frame *stack = reinterpret_cast<Frame *>(scratch + P.stack_off);
     int32_t *queue = reinterpret_cast<int32_t *>(scratch + P.queue_off);      // breadth-first work list
@@ -328,7 +329,17 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
     const int nch = P.n_channels;
     int status = 0;
     PROF_DECL;
-    const uint32_t lds_nodes_addr = (uint32_t)(uintptr_t)(&sh.nodes[0]);  // LDS byte offset (low half of the flat address)
+    const uint32_t lds_nodes_addr = (uint32_t)(uintptr_t)(&sh.snodes[0]);  // LDS byte offset (low half of the flat address)
+    // geometry of a 6-level supernode in heap order (children of slot k: 2k+1 = "> split", 2k+2 = "<= split"):
+    // lane e owns exit e; exp/msk = the decisions its path needs and the slots they sit in
+    int exit_q = 0;
+    uint32_t exp_lo = 0, exp_hi = 0, msk_lo = 0, msk_hi = 0;
+    for (int d = 0; d < 6; d++) {
+        const int gt = (lane >> (5 - d)) & 1;
+        if (exit_q < 32) { msk_lo |= 1u << exit_q; if (gt) exp_lo |= 1u << exit_q; }
+        else { msk_hi |= 1u << (exit_q - 32); if (gt) exp_hi |= 1u << (exit_q - 32); }
+        exit_q = 2 * exit_q + (gt ? 1 : 2);
+    }
 
     // ---- fuif_decode channel loop: encoding.cpp:708-717 -------------------------------------
     for (int ci = 0; ci < nch; ci++) {
@@ -489,7 +500,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
         __syncthreads();
         if (lane == 0) for (int k = 0; k < 3; k++) symbol_chance_init(sh.meta_ctx[k], 1024);
         __syncthreads();
-        int tree_size = 1;
+        int tree_size = 1, leaf_count = 0;
         bool tree_ok = true;
         {
             int pos = 0, depth = 0;
@@ -514,7 +525,9 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                     __syncthreads();
                     continue;
                 }
-                if (lane == 0) { Node n; n.property = -1; n.child = 0; n.splitval = 0; nodes[pos] = n; }
+                // leaf ids only have to be a bijection (each leaf owns its chances, compound.h:213-225): parse order
+                if (lane == 0) { Node n; n.property = -1; n.child = (uint16_t)leaf_count; n.splitval = 0; nodes[pos] = n; }
+                leaf_count++;
                 // return to the nearest ancestor that still has its "<= splitval" branch to read
                 bool done = false;
                 while (true) {
@@ -545,38 +558,58 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
             break;
         }
 
-        // ---- breadth-first re-layout + leaf numbering -----------------------------------------
-        // Leaf ids only have to be a bijection (each leaf owns its chances, compound.h:213-225):
-        // number them in breadth-first order.  Children stay adjacent (child, child+1).
+        // ---- supernode layout ------------------------------------------------------------------
+        // The tree is cut into complete 6-level subtrees ("supernodes", 63 node slots in heap order
+        // + 64 exits).  Lane i of a supernode holds {splitval_i, property_i | exit_i << 8}; a walk
+        // evaluates all 63 nodes of a supernode at once (see find_leaf below).  Slots below an early
+        // leaf are "absent" (splitval INT_MAX = always the <= branch) and every exit under that
+        // leaf points to it.  Supernodes are numbered breadth first, so the ones nearest the root
+        // are the ones that stay in LDS.
         const int nleaves = (tree_size + 1) / 2;
+        int n_super = 1;
         {
+            int32_t *slot_node = sh.cprops;        // [127] tree node behind every heap slot (cprops is idle here)
+            int32_t *st_split = sh.cprops + 128;   // [64]
+            int32_t *st_prop = sh.cprops + 192;    // [64]
             if (lane == 0) queue[0] = 0;
             __syncthreads();
-            int head = 0, tail = 1, leaf_id = 0;
-            while (head < tail) {
-                const int o = rfl(queue[head]);
-                const Node n = nodes[o];
-                const int prop = rfl((int)n.property);
-                Node out;
-                out.property = (int16_t)prop;
-                out.splitval = rfl(n.splitval);
-                if (prop >= 0) {
-                    const int c = rfl((int)n.child);
-                    out.child = (uint16_t)tail;
-                    if (lane == 0) { queue[tail] = c; queue[tail + 1] = c + 1; }
-                    tail += 2;
-                } else {
-                    out.child = (uint16_t)leaf_id;
-                    leaf_id++;
+            for (int sn = 0; sn < n_super; sn++) {
+                if (lane == 0) slot_node[0] = queue[sn];
+                st_split[lane] = 0x7FFFFFFF;
+                st_prop[lane] = 0;
+                __syncthreads();
+                for (int d = 0; d < 6; d++) {
+                    if (lane < (1 << d)) {
+                        const int k = (1 << d) - 1 + lane;
+                        const int t = slot_node[k];
+                        const Node n = nodes[t];
+                        if (n.property >= 0) {
+                            st_split[k] = n.splitval; st_prop[k] = n.property;
+                            slot_node[2 * k + 1] = n.child; slot_node[2 * k + 2] = n.child + 1;
+                        } else {
+                            slot_node[2 * k + 1] = t; slot_node[2 * k + 2] = t;
+                        }
+                    }
+                    __syncthreads();
                 }
-                if (lane == 0) {
-                    bfs_nodes[head] = out;
-                    if (head < kLdsNodes) sh.nodes[head] = out;
-                }
-                head++;
+                const int t = slot_node[exit_q];
+                const Node n = nodes[t];
+                const bool inner = n.property >= 0;
+                const unsigned long long im = __ballot(inner);
+                const int rank = __popcll(im & ((1ull << lane) - 1ull));
+                uint32_t tgt;
+                if (inner) { tgt = (uint32_t)(n_super + rank); queue[n_super + rank] = t; }
+                else tgt = kLeafFlag | (uint32_t)n.child;
+                n_super += __popcll(im);
+                uint2 out;
+                out.x = (uint32_t)st_split[lane];
+                out.y = ((uint32_t)st_prop[lane] & 0xFFu) | (tgt << 8);
+                snodes_g[(size_t)sn * 64 + lane] = out;
+                if (sn < kLdsSuper) sh.snodes[sn * 64 + lane] = out;
                 __syncthreads();
             }
         }
+        const uint2 root_nd = snodes_g[lane];  // the root supernode lives in registers
         // FinalPropertySymbolCoder ctor: every leaf starts from SymbolChance(zero_chance) (compound.h:213-219)
         {
             if (lane == 0) { symbol_chance_init(leaves, predictability); leaves[31] = 0; }
@@ -700,24 +733,22 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                                 int diff = mn;  // compound.h:228: min == max needs no symbol
                                 PROF_LAP(1);
                                 if (mn != mx) {
-                                    // find_leaf: compound.h:142-153.  Breadth-first numbering: once the walk leaves
-                                    // the LDS-resident top of the tree it stays in the HBM part.
-                                    int pos = 0, leaf = -1;
-                                    while (pos < kLdsNodes) {
-                                        const uint2 raw = lds_load_node(lds_nodes_addr + (uint32_t)pos * 8u);
-                                        const int meta_w = rfl((int)raw.y);           // child | property << 16
-                                        const int child = meta_w & 0xFFFF;
-                                        const int prop = meta_w >> 16;
-                                        if (prop < 0) { leaf = child; break; }
-                                        pos = child + ((rdlane(pv, prop) > rfl((int)raw.x)) ? 0 : 1);
-                                    }
-                                    while (leaf < 0) {
-                                        const uint2 raw = global_load_node(&bfs_nodes[pos]);
-                                        const int meta_w = rfl((int)raw.y);
-                                        const int child = meta_w & 0xFFFF;
-                                        const int prop = meta_w >> 16;
-                                        if (prop < 0) { leaf = child; break; }
-                                        pos = child + ((rdlane(pv, prop) > rfl((int)raw.x)) ? 0 : 1);
+                                    // find_leaf: compound.h:142-153, six tree levels per step.  Lane i fetches the
+                                    // property its node tests (ds_bpermute from lane `prop` of pv) and compares;
+                                    // the 63 outcomes form a mask; lane e checks whether the mask agrees with the
+                                    // six decisions on the path to exit e -- exactly one exit matches.
+                                    int leaf;
+                                    uint2 nd = root_nd;
+                                    while (true) {
+                                        const int val = __builtin_amdgcn_ds_bpermute((int)((nd.y & 0xFFu) << 2), pv);
+                                        const unsigned long long m = __ballot(val > (int)nd.x);
+                                        const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
+                                        const bool hit = ((((mlo ^ exp_lo) & msk_lo) | ((mhi ^ exp_hi) & msk_hi)) == 0u);
+                                        const int e = __builtin_ctzll(__ballot(hit));
+                                        const uint32_t tgt = (uint32_t)rdlane((int)nd.y, e) >> 8;
+                                        if (tgt & kLeafFlag) { leaf = (int)(tgt & (kLeafFlag - 1u)); break; }
+                                        if (tgt < (uint32_t)kLdsSuper) nd = lds_load_node(lds_nodes_addr + tgt * 512u + (uint32_t)lane * 8u);
+                                        else nd = global_load_node(&snodes_g[(size_t)tgt * 64 + lane]);
                                     }
                                     PROF_LAP(2);
                                     switch_leaf(leaf);
