@@ -101,10 +101,13 @@ struct Stream {
     int blob_mode;  // BlobReader::isEOF(): pos >= size (fileio.h:100-102)
 };
 
+#define LIKELY(x) __builtin_expect(!!(x), 1)
+#define UNLIKELY(x) __builtin_expect(!!(x), 0)
+
 DEV int s_getc(Stream &s, int lane) {
-    if (s.pos >= s.size) { s.eof_flag = 1; return -1; }
+    if (UNLIKELY(s.pos >= s.size)) { s.eof_flag = 1; return -1; }
     uint32_t idx = s.pos - s.win_base;
-    if (idx >= 256u) {
+    if (UNLIKELY(idx >= 256u)) {
         s.win_base = s.pos & ~255u;
         s.win = reinterpret_cast<const uint32_t *>(s.p + s.win_base)[lane];
         idx = s.pos - s.win_base;
@@ -149,8 +152,12 @@ struct Rac {
     uint32_t range, low;
 };
 DEV void rac_input(Rac &r, Stream &s, int lane) {
-    if (r.range <= 0x10000u) { r.low <<= 8; r.range <<= 8; r.low |= (uint32_t)s_getc(s, lane); }
-    if (r.range <= 0x10000u) { r.low <<= 8; r.range <<= 8; r.low |= (uint32_t)s_getc(s, lane); }
+    // rac.h:70-81: at most two byte shifts; the second is only possible after the first.  Most
+    // decisions need none, so the whole renormalisation is kept off the fall-through path.
+    if (UNLIKELY(r.range <= 0x10000u)) {
+        r.low <<= 8; r.range <<= 8; r.low |= (uint32_t)s_getc(s, lane);
+        if (UNLIKELY(r.range <= 0x10000u)) { r.low <<= 8; r.range <<= 8; r.low |= (uint32_t)s_getc(s, lane); }
+    }
 }
 DEV int rac_get(Rac &r, Stream &s, int lane, uint32_t chance) {
     const uint32_t thr = r.range - chance;
@@ -249,10 +256,8 @@ DEV int leaf_symbol(Rac &r, Stream &s, int lane, LeafRegs &L, int min, int max) 
     return sign ? have : -have;
 }
 DEV void leaf_commit(LeafRegs &L, int lane, const uint16_t *table) {
-    if (L.touched) {
-        if ((L.touched >> lane) & 1u) L.leafv = table[L.leafv * 2 + ((L.bits >> lane) & 1u)];
-        L.touched = 0; L.bits = 0;
-    }
+    if ((L.touched >> lane) & 1u) L.leafv = table[L.leafv * 2 + ((L.bits >> lane) & 1u)];
+    L.touched = 0; L.bits = 0;
 }
 
 // maniac/symbol.h:115-138
@@ -625,7 +630,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
         L.touched = 0; L.bits = 0;
         int cur_leaf = 0;
         auto switch_leaf = [&](int id) {
-            if (id != cur_leaf) {
+            if (LIKELY(id != cur_leaf)) {
                 if (lane < 32) {
                     leaves[(int64_t)cur_leaf * kLeafStride + lane] = (uint16_t)L.leafv;
                     L.leafv = (int)leaves[(int64_t)id * kLeafStride + lane];
@@ -669,6 +674,18 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                         // left / leftleft start as `zero`, which is exactly what the edge rules
                         // give at x == 0 (context_predict.h:126,131)
                         int left = zero, leftleft = zero;
+                        // The 7 left-dependent local properties (context_predict.h:136-154) are all of the form
+                        // F(c*left + bias): the vector phase stores the bias, the scalar phase finishes them with
+                        // ~16 vector instructions for all lanes at once.  k = local property index of this lane.
+                        //   k:  1 |left|   3 slog(left)   6 left+top-topleft   7 topleft+topright-top
+                        //       8 slog(left-topleft)   9 slog(topleft-top)   12 slog(left-leftleft)
+                        // In row 0 topleft IS left (context_predict.h:128), which moves the left term from 6,8 to 7,9.
+                        const int kloc = lane - nrefprops;
+                        const bool f_abs = (kloc == 1);
+                        const bool f_slog = (kloc == 3) | (kloc == 8) | (kloc == 9) | (kloc == 12);
+                        const bool f_patch = f_abs | f_slog | (kloc == 6) | (kloc == 7);
+                        const bool f_l12 = (kloc == 12);
+                        const bool f_lcoef = (kloc == 1) | (kloc == 3) | (kloc == 12) | (y ? ((kloc == 6) | (kloc == 8)) : ((kloc == 7) | (kloc == 9)));
                         for (int x0 = 0; x0 < w; x0 += 64) {
                             const int nx = min(64, w - x0);
                             // ---- vector phase: lane j prepares pixel x0+j ------------------------
@@ -694,6 +711,9 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                                 int32_t *q = cp + nrefprops;
                                 q[0] = iabs(vtop); q[2] = slog(vtop); q[4] = y; q[5] = x0 + lane;
                                 q[10] = slog(vtop - vtr); q[11] = slog(vtop - vtt);
+                                q[1] = 0; q[3] = 0;
+                                if (y) { q[6] = vtop - vtl; q[7] = vtl + vtr - vtop; q[8] = -vtl; q[9] = vtl - vtop; }
+                                else { q[6] = zero; q[7] = 0; q[8] = 0; q[9] = -zero; }
                             }
                             __syncthreads();
                             PROF_LAP(0);
@@ -703,21 +723,17 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                                 PROF_START();
                                 int pv = sh.cprops[j * kPropPitch + (lane & 31)];
                                 const int l = left;
-                                const int top = rdlane(vtop, j);
-                                const int tlraw = rdlane(vtl, j);
-                                const int topleft = y ? tlraw : l;           // y == 0: topleft = left (context_predict.h:128)
-                                const int topright = rdlane(vtr, j);
-                                const int ll = leftleft;
-                                // the left-dependent properties (context_predict.h:136-154)
-                                pv = wrlane(iabs(l), nrefprops + 1, pv);
-                                pv = wrlane(slog(l), nrefprops + 3, pv);
-                                pv = wrlane(l + top - topleft, nrefprops + 6, pv);
-                                pv = wrlane(topleft + topright - top, nrefprops + 7, pv);
-                                pv = wrlane(slog(l - topleft), nrefprops + 8, pv);
-                                pv = wrlane(slog(topleft - top), nrefprops + 9, pv);
-                                pv = wrlane(slog(l - ll), nrefprops + 12, pv);
+                                {
+                                    int d = pv + (f_lcoef ? l : 0);
+                                    d = f_l12 ? (l - leftleft) : d;
+                                    const int r = f_abs ? iabs(d) : (f_slog ? slog(d) : d);
+                                    pv = f_patch ? r : pv;
+                                }
                                 int guess = zero;
                                 if (!PRED0) {
+                                    const int top = rdlane(vtop, j);
+                                    const int topleft = y ? rdlane(vtl, j) : l;   // y == 0: topleft = left (context_predict.h:128)
+                                    const int topright = rdlane(vtr, j);
                                     switch (predictor) {  // context_predict.h:157-166
                                         case 0: guess = zero; break;
                                         case 1: guess = (l + top) / 2; break;
@@ -732,7 +748,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                                 const int mn = minv - guess, mx = maxv - guess;
                                 int diff = mn;  // compound.h:228: min == max needs no symbol
                                 PROF_LAP(1);
-                                if (mn != mx) {
+                                if (LIKELY(mn != mx)) {
                                     // find_leaf: compound.h:142-153, six tree levels per step.  Lane i fetches the
                                     // property its node tests (ds_bpermute from lane `prop` of pv) and compares;
                                     // the 63 outcomes form a mask; lane e checks whether the mask agrees with the
