@@ -4,7 +4,7 @@
 Workload (config.workload = "C2"): a batch of 1024 3840x2160 8-bit photographic RGB images,
 YCoCg+Squeeze lossless .fuif, per GPU (weak scaling: every rank decodes its own 1024 streams; the
 path shards by independent images and has no data-path collective -- the only exchange is the
-final gather of per-image output checksums).
+final gather of per-image output checksums over RCCL).
 
 One "step" = one pass of the hot path over the batch with the compressed streams already resident
 in HBM: entropy kernel (k_maniac_decode) + inverse-transform schedule, ending with all int32
@@ -43,9 +43,10 @@ def make_inputs(k, w, h, channels, bits, seed0, cache_dir):
     """K distinct encoded streams (+ their seeds); cached on local disk inside one box session."""
     os.makedirs(cache_dir, exist_ok=True)
     jobs, blobs = [], {}
+    name = "synth_%dx%dx%d_%dbit_seed%d.fuif"
     for i in range(k):
         seed = seed0 + i
-        path = os.path.join(cache_dir, "synth_%dx%dx%d_%dbit_seed%d.fuif" % (w, h, channels, bits, seed))
+        path = os.path.join(cache_dir, name % (w, h, channels, bits, seed))
         if os.path.exists(path):
             blobs[seed] = open(path, "rb").read()
         else:
@@ -57,7 +58,7 @@ def make_inputs(k, w, h, channels, bits, seed0, cache_dir):
             for seed, blob in pool.imap_unordered(_encode_one, jobs):
                 blobs[seed] = blob
                 try:
-                    with open(os.path.join(cache_dir, "synth_%dx%dx%d_%dbit_seed%d.fuif" % (w, h, channels, bits, seed)), "wb") as f:
+                    with open(os.path.join(cache_dir, name % (w, h, channels, bits, seed)), "wb") as f:
                         f.write(blob)
                 except OSError:
                     pass
@@ -85,6 +86,22 @@ def cpu_baseline(blobs, w, h, budget_s=25.0):
             "sample": "%d of the bench's %dx%d streams, full decode (entropy + inverse transforms), 1 thread, %.1f s" % (n, w, h, t_total)}
 
 
+def pmc_traffic(batch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r*_pmc_traffic.json, collected with tools/collect_profiles.sh); None if no profile
+    of this batch size exists."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("kernel") == "k_maniac_decode" and d.get("batch") == batch:
+            best = d
+    return None if best is None else int(best["traffic_bytes_per_launch"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,17 +117,13 @@ def main():
 
     import torch
     import fuif_amd
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from fuif_amd import dist as fd
+    rank, local_rank, world = fd.env_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the FUIF decode path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
+    dist = fd.init(device=dev)
     fuif_amd.build()
 
     W, H, C, BITS = args.width, args.height, 3, 8
@@ -153,11 +166,7 @@ def main():
         dec_ms.append(d)
         tr_ms.append(t)
     fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = fd.max_over_ranks(time.perf_counter() - t0, dist, dev)
 
     # ---- correctness at full size: lossless round trip against the generator's pixels ----------
     from fuif_amd.synth import photographic
@@ -165,23 +174,21 @@ def main():
     ok = not st.any()
     outs = plan.output_channels
     view = out.view(args.batch, info.out_elems)
-    checks = torch.zeros(args.batch, dtype=torch.int64, device=dev)
     for k in range(K):
         src = torch.from_numpy(photographic(W, H, C, BITS, seed=inputs[k][0])).to(dev)
         for i in range(k, args.batch, K):
             for c, oc in enumerate(outs):
                 got = view[i, oc["offset"]: oc["offset"] + oc["w"] * oc["h"]].view(oc["h"], oc["w"])
                 ok = ok and bool(torch.equal(got, src[c]))
-    # the only cross-rank exchange: gather of per-image output checksums over RCCL
-    weights = (torch.arange(info.out_elems, device=dev, dtype=torch.int64) % 65521) + 1
-    for i0 in range(0, args.batch, 8):
-        checks[i0:i0 + 8] = (view[i0:i0 + 8].to(torch.int64) * weights).sum(dim=1)
-    if dist is not None:
-        gathered = [torch.zeros_like(checks) for _ in range(world)]
-        dist.all_gather(gathered, checks)
-        okt = torch.tensor([1 if ok else 0], device=dev)
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        ok = bool(okt.item())
+    # the only cross-rank exchange: gather of per-image output checksums (RCCL all_gather)
+    checks = fd.plane_checksums(view)
+    gathered = fd.gather_checksums(checks, dist)
+    # replicas of one source image must agree on every rank
+    for r in range(gathered.shape[0]):
+        for k in range(K):
+            col = gathered[r, k::K]
+            ok = ok and bool((col == col[0]).all().item())
+    ok = fd.all_ok(ok, dist, dev)
 
     total_px = world * args.batch * W * H * args.steps
     value = total_px / 1e6 / elapsed
@@ -194,13 +201,15 @@ def main():
         # dominant kernel: k_maniac_decode reads the stream once and writes every coefficient once
         alg_kernel = args.batch * (S + 4.0 * N)
         d_avg = float(np.mean(dec_ms)) / 1e3
+        t_avg = float(np.mean(tr_ms)) / 1e3
         achieved = alg_kernel / d_avg / 1e9
         roofline = {"bound": "hbm", "kernel": "k_maniac_decode", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(args.batch),
                     "kernel_ms": round(d_avg * 1e3, 3), "algorithmic_bytes_per_launch": int(alg_kernel),
-                    "note": "latency-bound serial range decoder, one wavefront per stream; see DESIGN.md",
-                    "transforms": {"ms": round(float(np.mean(tr_ms)), 3),
-                                   "achieved": round(args.batch * 4.0 * (N + P) / (float(np.mean(tr_ms)) / 1e3) / 1e9, 1),
+                    "ns_per_symbol_per_stream": round(d_avg * 1e9 / N, 1),
+                    "note": "serial range decoder, one wavefront per stream: bound by instruction issue on the per-symbol "
+                            "dependency chain, not by HBM (DESIGN.md 4.1)",
+                    "transforms": {"ms": round(t_avg * 1e3, 3), "achieved": round(args.batch * 4.0 * (N + P) / t_avg / 1e9, 1),
                                    "unit": "GB/s", "algorithmic_bytes": int(args.batch * 4.0 * (N + P))},
                     "path_bytes_per_image": int(S + 8.0 * N + 4.0 * P)}
         res = {"metric": "Mpixels/s decode (4K Squeeze+YCoCg)", "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world,
@@ -209,7 +218,7 @@ def main():
                "config": {"workload": "C2: batch of %d %dx%d 8-bit photographic YCoCg+Squeeze lossless per GPU" % (args.batch, W, H),
                           "images_per_gpu": args.batch, "distinct_images": K, "bytes_per_stream": int(S),
                           "writer": "fuif_amd/csrc/writer.cpp learned trees", "parity_roundtrip_ok": ok,
-                          "input_gen_s": round(t_gen, 1), "upload_s": round(t_upload, 3)},
+                          "gather": "all_gather of per-image output checksums", "input_gen_s": round(t_gen, 1), "upload_s": round(t_upload, 3)},
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline([b for _, b in inputs], W, H)

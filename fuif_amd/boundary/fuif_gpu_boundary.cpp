@@ -1,0 +1,185 @@
+// fuif_amd/boundary/fuif_gpu_boundary.cpp -- the reference-side binding of libfuifgpu.so.
+//
+// This is the ONE file a maintainer of cloudinary/fuif adds to route the decode hot path to the
+// MI355X.  It is compiled against the reference's OWN headers (Image, Channel,
+// Transform, fuif_options, FileIO, BlobReader -- included from the reference tree, nothing copied)
+// and defines the three entry points the CLI uses for decoding:
+//
+//     bool fuif_decode_file(const char*, Image&, fuif_options)      encoding/encoding.cpp:745-753
+//     template <IO> bool fuif_decode(IO&, Image&, fuif_options)     encoding/encoding.cpp:599-720
+//     void Image::undo_transforms(int keep)                         image/image.cpp:94-115
+//
+// The reference's own definitions of these three are kept in the link under the names
+// fuif_decode_file_cpu / fuif_decode_cpu / Image::undo_transforms_cpu (the Makefile compiles
+// encoding.cpp and image.cpp with -Dname=name_cpu) and are used for what is outside the GPU
+// scope: -i/--identify, animations (FUAF), streams with Palette/Match/Permute/Approximate
+// transforms, and undo_transforms(keep != 0).  Everything else (fuif.cpp, import/export code,
+// the encoder) is compiled and linked UNCHANGED.
+//
+// Ownership: fuif_decode() fills `image` exactly like the reference (channel vector = coded
+// channels with geometry, ranges, q and samples narrowed to pixel_type; transform list with
+// expanded parameters) and keeps the device batch alive in a registry keyed by &image so that the
+// following image.undo_transforms() can run the inverse-transform schedule on the coefficients
+// that are still resident in HBM.
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "encoding/encoding.h"
+#include "fileio.h"
+#include "image/image.h"
+#include "io.h"
+#include "transform/transform.h"
+
+#include "fuifgpu.h"
+
+// the reference's CPU implementations, renamed at compile time (see Makefile)
+bool fuif_decode_file_cpu(const char *filename, Image &image, fuif_options options);
+template <typename IO> bool fuif_decode_cpu(IO &io, Image &image, fuif_options options);
+
+namespace {
+
+struct Resident {
+    fuifgpu_plan *plan = nullptr;
+    fuifgpu_batch *batch = nullptr;
+    ~Resident() {
+        if (batch) fuifgpu_batch_destroy(batch);
+        if (plan) fuifgpu_plan_destroy(plan);
+    }
+};
+std::map<const Image *, std::unique_ptr<Resident>> &registry() {
+    static std::map<const Image *, std::unique_ptr<Resident>> r;
+    return r;
+}
+
+template <typename IO> std::vector<uint8_t> slurp(IO &io) {
+    std::vector<uint8_t> b;
+    for (int c = io.get_c(); c != io.EOS; c = io.get_c()) b.push_back((uint8_t)c);
+    return b;
+}
+
+bool gpu_decode_bytes(const std::vector<uint8_t> &bytes, Image &image, const fuif_options &options, bool *unsupported) {
+    *unsupported = false;
+    auto res = std::make_unique<Resident>();
+    int rc = fuifgpu_plan_create(bytes.data(), bytes.size(), &res->plan);
+    if (rc == FUIFGPU_E_UNSUPPORTED) { *unsupported = true; return false; }
+    if (rc == FUIFGPU_E_NOT_FUIF) { e_printf("%s is not a FUIF file\n", "input"); return false; }
+    if (rc != FUIFGPU_OK) { e_printf("Corrupt file. Aborting. (%s)\n", fuifgpu_last_error()); return false; }
+    fuifgpu_image_info info;
+    fuifgpu_plan_info(res->plan, &info);
+    if (info.nb_frames > 1) { *unsupported = true; return false; }
+    rc = fuifgpu_batch_create(res->plan, 1, bytes.size(), nullptr, nullptr, 1, &res->batch);
+    if (rc != FUIFGPU_OK) { e_printf("fuifgpu: %s (%s)\n", fuifgpu_strerror(rc), fuifgpu_last_error()); return false; }
+    const uint8_t *blobs[1] = {bytes.data()};
+    const size_t sizes[1] = {bytes.size()};
+    if ((rc = fuifgpu_batch_upload(res->batch, blobs, sizes, 1, options.preview, nullptr)) != FUIFGPU_OK ||
+        (rc = fuifgpu_batch_decode(res->batch, nullptr)) != FUIFGPU_OK || (rc = fuifgpu_batch_sync(res->batch, nullptr)) != FUIFGPU_OK) {
+        e_printf("fuifgpu: %s (%s)\n", fuifgpu_strerror(rc), fuifgpu_last_error());
+        return false;
+    }
+    int32_t status = 0;
+    uint32_t used = 0;
+    fuifgpu_batch_status(res->batch, &status, &used);
+    if (status & FUIFGPU_ST_CORRUPT) { e_printf("Corruption detected.\n"); return false; }
+
+    // Image(w,h,maxval,nb_channels,colormodel) + what meta_apply and the channel loop leave behind
+    image = Image(info.w, info.h, info.maxval, info.nb_channels, info.colormodel);
+    std::vector<int32_t> slab((size_t)(info.coef_elems > 0 ? info.coef_elems : 1));
+    fuifgpu_batch_download_coef(res->batch, 0, slab.data(), nullptr);
+    std::vector<int32_t> meta((size_t)info.nb_coded_channels * 4);
+    fuifgpu_batch_channel_meta(res->batch, 0, meta.data());
+    image.channel.clear();
+    for (int c = 0; c < info.nb_coded_channels; c++) {
+        fuifgpu_channel_desc d;
+        fuifgpu_plan_coded_channel(res->plan, c, &d);
+        Channel ch;
+        ch.w = d.w; ch.h = d.h; ch.hshift = d.hshift; ch.vshift = d.vshift; ch.hcshift = d.hcshift; ch.vcshift = d.vcshift;
+        ch.component = d.component;
+        const int32_t *m = &meta[(size_t)c * 4];
+        const bool parsed = (m[0] != 0 || m[1] != 0 || m[2] != 0);
+        ch.minval = (pixel_type)m[0]; ch.maxval = (pixel_type)m[1]; ch.q = parsed ? m[2] : 1;
+        if (!parsed && c < info.nb_channels) { ch.minval = 0; ch.maxval = (pixel_type)info.maxval; }  // Image ctor range of a never-reached base channel
+        ch.setzero();
+        if (m[3]) {  // plane was decoded (or constant / zero-filled by the truncation rules)
+            const size_t n = (size_t)d.w * d.h;
+            ch.data.resize(n);
+            for (size_t i = 0; i < n; i++) ch.data[i] = (pixel_type)slab[(size_t)d.offset + i];
+        }
+        image.channel.push_back(ch);
+    }
+    image.transform.clear();
+    for (int t = 0; t < info.nb_transforms; t++) {
+        int32_t id = 0, np = 0;
+        std::vector<int32_t> params(4096);
+        fuifgpu_plan_transform(res->plan, t, &id, params.data(), (int)params.size(), &np);
+        Transform tr(id);
+        for (int k = 0; k < np && k < (int)params.size(); k++) tr.parameters.push_back(params[k]);
+        image.transform.push_back(tr);
+    }
+    image.error = false;
+    registry()[&image] = std::move(res);
+    return true;
+}
+
+}  // namespace
+
+template <typename IO> bool fuif_decode(IO &io, Image &image, fuif_options options) {
+    if (options.identify) return fuif_decode_cpu(io, image, options);
+    std::vector<uint8_t> bytes = slurp(io);
+    bool unsupported = false;
+    if (gpu_decode_bytes(bytes, image, options, &unsupported)) return true;
+    if (!unsupported) return false;
+    BlobReader again(bytes.data(), bytes.size());  // outside the GPU scope: the reference's own decoder
+    return fuif_decode_cpu(again, image, options);
+}
+template bool fuif_decode(FileIO &io, Image &image, fuif_options options);
+template bool fuif_decode(BlobReader &io, Image &image, fuif_options options);
+
+bool fuif_decode_file(const char *filename, Image &image, fuif_options options) {
+    FILE *file = !strcmp(filename, "-") ? stdin : fopen(filename, "rb");
+    if (!file) return false;
+    FileIO fio(file, (file == stdin ? "from standard input" : filename));
+    return fuif_decode(fio, image, options);
+}
+
+// Image::undo_transforms(int) -- exported under the member's Itanium-ABI name.  This file is compiled
+// with -Dundo_transforms=undo_transforms_cpu (like image.cpp), so inside this translation unit the class
+// declares the reference's CPU implementation as Image::undo_transforms_cpu, and the GPU version is a
+// free function taking `this` explicitly (same calling convention) bound to the original symbol.
+void fuifgpu_boundary_undo_transforms(Image *self, int keep) __asm__("_ZN5Image15undo_transformsEi");
+void fuifgpu_boundary_undo_transforms(Image *self, int keep) {
+    auto it = registry().find(self);
+    if (it == registry().end() || keep != 0) {
+        if (it != registry().end()) registry().erase(it);
+        self->undo_transforms(keep);  // macro-renamed: the reference's own CPU implementation
+        return;
+    }
+    Resident &res = *it->second;
+    fuifgpu_image_info info;
+    fuifgpu_plan_info(res.plan, &info);
+    int rc = fuifgpu_batch_undo_transforms(res.batch, nullptr);
+    if (rc == FUIFGPU_OK) rc = fuifgpu_batch_sync(res.batch, nullptr);
+    if (rc != FUIFGPU_OK) {
+        e_printf("Error while undoing transforms on the GPU: %s\n", fuifgpu_last_error());
+        self->error = true;
+        registry().erase(it);
+        return;
+    }
+    std::vector<int32_t> slab((size_t)(info.out_elems > 0 ? info.out_elems : 1));
+    fuifgpu_batch_download_out(res.batch, 0, slab.data(), nullptr);
+    std::vector<Channel> outch;
+    for (int c = 0; c < info.nb_output_channels; c++) {
+        fuifgpu_channel_desc d;
+        fuifgpu_plan_output_channel(res.plan, c, &d);
+        Channel ch(d.w, d.h, (pixel_type)self->minval, (pixel_type)self->maxval, 1, d.hshift, d.vshift, d.hcshift, d.vcshift);
+        ch.component = d.component;
+        const size_t n = (size_t)d.w * d.h;
+        for (size_t i = 0; i < n; i++) ch.data[i] = (pixel_type)slab[(size_t)d.offset + i];
+        outch.push_back(ch);
+    }
+    self->channel = outch;
+    self->transform.clear();
+    registry().erase(self);
+}

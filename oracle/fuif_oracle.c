@@ -600,6 +600,26 @@ static int corrupt_or_truncated(fo_io *io, fo_channel *c, size_t btl) {
     return 0;
 }
 
+/* optional leaf-locality statistics (FO_LEAFSIM=1): hit rates of direct-mapped leaf caches, used to
+ * size the LDS leaf cache of the HIP kernel; not part of the decode semantics */
+static int g_leafsim = -1;
+static uint64_t g_ls_access, g_ls_same, g_ls_hit[4];
+static int g_ls_tags[4][1024];
+static const int g_ls_sizes[4] = {64, 128, 256, 512};
+static void leafsim_reset(void) { for (int k = 0; k < 4; k++) for (int i = 0; i < 1024; i++) g_ls_tags[k][i] = -1; }
+static void leafsim_access(int id, int *prev) {
+    g_ls_access++;
+    if (id == *prev) { g_ls_same++; return; }
+    *prev = id;
+    for (int k = 0; k < 4; k++) { int slot = id % g_ls_sizes[k]; if (g_ls_tags[k][slot] == id) g_ls_hit[k]++; else g_ls_tags[k][slot] = id; }
+}
+void fo_leafsim_report(uint64_t *out6) { out6[0] = g_ls_access; out6[1] = g_ls_same; for (int k = 0; k < 4; k++) out6[2 + k] = g_ls_hit[k]; }
+static void dfs_number(const fo_node *n, int pos, int *ids, int *next) {
+    if (n[pos].property == -1) { ids[n[pos].childID] = (*next)++; return; }
+    dfs_number(n, n[pos].childID, ids, next);
+    dfs_number(n, n[pos].childID + 1, ids, next);
+}
+
 static uint16_t g_table_tree[8192], g_table_pixel[8192];
 static int g_tables_ready = 0;
 static void ensure_tables(void) {
@@ -701,6 +721,9 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
 
     int32_t props[FO_MAX_PROPS];
     memset(props, 0, sizeof(props));
+    if (g_leafsim < 0) g_leafsim = getenv("FO_LEAFSIM") ? 1 : 0;
+    int *ls_ids = NULL, ls_prev = -1;
+    if (g_leafsim) { ls_ids = (int *)malloc(sizeof(int) * nleaves); int nx = 0; dfs_number(tree.n, 0, ls_ids, &nx); leafsim_reset(); }
     const int nref = nprops - FO_NB_NONREF;
 
     for (int i = beginc; i <= endc; i++) {
@@ -736,6 +759,7 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
                             if (props[tree.n[pos].property] > tree.n[pos].splitval) pos = tree.n[pos].childID;
                             else pos = tree.n[pos].childID + 1;
                         }
+                        if (g_leafsim) leafsim_access(ls_ids[tree.n[pos].childID], &ls_prev);
                         diff = read_symbol(&rac, leaves + (size_t)tree.n[pos].childID * CH_N, g_table_pixel, mn, mx);
                     }
                     c->data[(size_t)y * c->w + x] = diff + guess;
@@ -747,6 +771,7 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
         if (LIMIT_HIT(io, btl)) break;
     }
     img->stat_rac_decisions += rac.decisions;
+    free(ls_ids);
     free(leaves);
     free(tree.n);
     *beginc_io = endc;
