@@ -77,7 +77,7 @@ ABI_SYMBOLS = [
     "fuifgpu_batch_decode", "fuifgpu_batch_undo_transforms", "fuifgpu_batch_sync", "fuifgpu_batch_status",
     "fuifgpu_batch_channel_meta", "fuifgpu_batch_coef_ptr", "fuifgpu_batch_out_ptr", "fuifgpu_batch_download_coef",
     "fuifgpu_batch_download_out", "fuifgpu_batch_last_timing", "fuifgpu_batch_profile", "fuifgpu_inv_hsqueeze", "fuifgpu_inv_vsqueeze",
-    "fuifgpu_inv_ycocg", "fuifgpu_inv_ycbcr", "fuifgpu_idct8x8", "fuifgpu_upsample", "fuifgpu_encode_image", "fuifgpu_free_blob",
+    "fuifgpu_inv_ycocg", "fuifgpu_inv_ycbcr", "fuifgpu_idct8x8", "fuifgpu_upsample", "fuifgpu_encode_image", "fuifgpu_encode_channels", "fuifgpu_free_blob",
 ]
 
 

@@ -229,8 +229,17 @@ struct LeafRegs {
     uint32_t bits;      // scalar
 };
 DEV int leaf_bit(Rac &r, Stream &s, int lane, LeafRegs &L, int idx) {
-    const uint32_t c = (uint32_t)rdlane(L.leafv, idx);
-    const int bit = rac_get(r, s, lane, chance12(r.range, c));
+    // Every lane evaluates the decision for ITS chance with the current range (rac.h:43-52,82-95):
+    // chance = (range*b12+0x800)>>12 as one 64-bit mad, threshold = range-chance, low >= threshold.
+    // Four vector instructions replace ~12 dependent scalar ones; lane `idx` holds the answer.
+    const uint32_t ch_v = (uint32_t)(((unsigned long long)r.range * (uint32_t)L.leafv + 0x800ull) >> 12);
+    const uint32_t thr_v = r.range - ch_v;
+    const unsigned long long ge = __ballot(r.low >= thr_v);
+    const uint32_t thr = (uint32_t)rdlane((int)thr_v, idx);
+    const int bit = (int)((ge >> idx) & 1ull);
+    r.low = bit ? r.low - thr : r.low;
+    r.range = bit ? r.range - thr : thr;
+    rac_input(r, s, lane);
     L.touched |= 1u << idx;
     L.bits |= (uint32_t)bit << idx;
     return bit;

@@ -150,6 +150,16 @@ typedef struct {
 } fuifgpu_encode_options;
 int fuifgpu_encode_image(const int32_t *planes, int w, int h, int nch, int bit_depth, const fuifgpu_encode_options *opt,
                          uint8_t **blob_out, size_t *size_out);
+/* channels already in a transform domain (e.g. the quantised DCT coefficient planes import/read_jpeg.h:56-184
+ * builds): geometry + q + samples per channel, `transforms` = flat words {id, nparams, params...} of the
+ * transforms that produced them; opt->squeeze adds the default Squeeze of the first nb_channels channels */
+typedef struct {
+    int32_t w, h, hshift, vshift, hcshift, vcshift, component, q;
+    const int32_t *data;
+} fuifgpu_raw_channel;
+int fuifgpu_encode_channels(const fuifgpu_raw_channel *channels, int n_channels, int w, int h, int nb_channels, int bit_depth,
+                            const int32_t *transforms, int n_transform_words, const fuifgpu_encode_options *opt,
+                            uint8_t **blob_out, size_t *size_out);
 void fuifgpu_free_blob(uint8_t *blob);
 
 #ifdef __cplusplus

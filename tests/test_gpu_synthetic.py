@@ -65,3 +65,21 @@ def test_truncated_learned_tree_stream(gpulib, port):
         assert st[0] & 1
         for g, e in zip(post[0], d_post.channels):
             assert np.array_equal(g, e["data"])
+
+
+@pytest.mark.parametrize("w,h,c,sub", [(1280, 720, 3, True), (333, 257, 3, False), (640, 480, 1, False)])
+def test_jpeg_like_dct_path_matches_oracle(gpulib, port, w, h, c, sub):
+    """config C3 shape at size: YCbCr + 4:2:0 + 8x8 FP64 iDCT + dequantisation + Squeeze of DC, bit-exact"""
+    from fuif_amd.jpeglike import encode_jpeg_like
+    img = photographic(w, h, c, 8, seed=6000 + w, sigma=1.0)
+    blob = encode_jpeg_like(img, 90, sub)
+    pre, post, st, used = gpu_decode(gpulib, [blob, blob])
+    d_pre, d_post = port.decode_both(blob)
+    assert not st.any()
+    for planes in pre:
+        for g, e in zip(planes, d_pre.channels):
+            assert np.array_equal(g, e["data"])
+    for planes in post:
+        assert len(planes) == len(d_post.channels)
+        for g, e in zip(planes, d_post.channels):
+            assert np.array_equal(g, e["data"])

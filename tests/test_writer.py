@@ -50,3 +50,22 @@ def test_writer_accepted_by_real_reference(gpulib, ref, tmp_path, w, h, c, bits,
     mine = gpulib.encode_image(img, bits, tree_mode=0)
     # the reference appends one stray byte (BlobIO::bytes_used = seek_pos+1, fileio.h:252-254)
     assert mine == refblob[: len(mine)] and len(refblob) - len(mine) <= 1
+
+
+@pytest.mark.parametrize("w,h,c,sub", [(72, 56, 3, True), (97, 61, 3, False), (64, 40, 1, False), (130, 33, 3, True)])
+def test_jpeg_like_streams_port_and_reference_agree(gpulib, port, w, h, c, sub):
+    """JPEG-transcode-shaped streams (YCbCr + 4:2:0 + DCT + Quantize + Squeeze of DC) from the product's
+    writer: the oracle decodes them, the picture is the source within JPEG error, and (when built) the REAL
+    reference decodes them to exactly the same planes."""
+    from fuif_amd.jpeglike import encode_jpeg_like
+    from oracle_py import Ref
+    img = photographic(w, h, c, 8, seed=900 + w, sigma=1.0)
+    blob = encode_jpeg_like(img, 90, sub)
+    pre, post = port.decode_both(blob)
+    assert pre.ok and [t[0] for t in pre.transforms][-3:] == [4, 5, 7]
+    rec = np.stack([ch["data"][:h, :w] for ch in post.channels]).astype(np.float64)
+    assert ((rec - img) ** 2).mean() < 40.0
+    if Ref.available():
+        a0, a1 = Ref().decode_both(blob)
+        assert all(np.array_equal(x["data"], y["data"]) for x, y in zip(a0.channels, pre.channels))
+        assert all(np.array_equal(x["data"], y["data"]) for x, y in zip(a1.channels, post.channels))
