@@ -259,7 +259,7 @@ DEV int leaf_symbol(Rac &r, Stream &s, int lane, LeafRegs &L, int min, int max) 
     for (int pos = e; pos > 0;) {
         pos--;
         int minabs1 = have | (1 << pos);
-        if (minabs1 > amax) continue;
+        if (minabs1 > amax) continue;  // 1-bit is impossible (symbol.h:180)
         if (leaf_bit(r, s, lane, L, CH_MANT + pos)) have = minabs1;
     }
     return sign ? have : -have;
