@@ -9,17 +9,24 @@
 // vector unit:
 //   * compressed bytes: one coalesced 256-byte window per refill, lane i holds dword i,
 //     bytes are picked with v_readlane (no per-byte memory access);
-//   * context tree: nodes re-laid out breadth first after parsing, the first kLdsNodes of them
-//     live in LDS (one ds_read_b64 per level), deeper ones spill to the per-stream HBM scratch;
+//   * context tree: after parsing, the tree is cut into complete 6-level "supernodes" (63 node
+//     slots in heap order + 64 exits); one walk step evaluates a whole supernode: every lane
+//     fetches the property its node tests (ds_bpermute), compares (63 decisions -> one 64-bit
+//     mask), and lane e tests whether the mask agrees with the six decisions on the path to exit
+//     e.  The root supernode lives in registers, the next 57 in LDS, deeper ones in HBM scratch;
 //   * the properties of 64 consecutive pixels that do not depend on the pixel being decoded
 //     (reference channels, top row, position) are computed by 64 lanes at once and parked in LDS;
-//     per pixel one ds_read puts property p into lane p, the 7 left-dependent ones are patched
-//     with v_writelane, and the tree walk picks properties with v_readlane;
-//   * the 31 adaptive chances of the current leaf sit in lanes 0..30; a symbol's binary
-//     decisions only read them (v_readlane) and record (index,bit) in two scalar masks; all
-//     touched chances are advanced together by one vector table lookup after the symbol;
-//   * decoded pixels are collected in a VGPR (v_writelane) and stored 64 at a time.
-// LDS budget 39 KB per wave so that 4 streams share a CU (160 KB): 29 KB of tree nodes,
+//     per pixel one ds_read puts property p into lane p and the 7 left-dependent ones, all of
+//     the form F(c*left + bias), are finished by a handful of vector instructions;
+//   * the 31 adaptive chances of the current leaf sit in lanes 0..30; a binary decision is
+//     evaluated by all lanes at once for their own chance (64-bit mad, compare -> mask) and the
+//     lane of the context in use is picked; (index,bit) pairs are recorded in two scalar masks
+//     and all touched chances are advanced together by one vector table lookup after the symbol;
+//   * decoded pixels are collected in a VGPR and stored 64 at a time.
+// A single wave issues one instruction every ~4.6 cycles, a taken branch costs ~25 and a
+// VALU<->SALU hand-over ~14 (tools/ubench.hip), so the kernel is bound by the instruction count of
+// the per-symbol chain; every item above trades scalar instructions for vector ones.
+// LDS budget 39 KB per wave so that 4 streams share a CU (160 KB): 29 KB of supernodes,
 // 8.4 KB of chunk properties, the rest small state.  The 16 KB chance transition table is read
 // through L1/L2 instead: its lookups are off the dependency chain thanks to the batched update.
 //
@@ -246,23 +253,35 @@ DEV int leaf_bit(Rac &r, Stream &s, int lane, LeafRegs &L, int idx) {
 }
 // maniac/symbol.h:154-185
 DEV int leaf_symbol(Rac &r, Stream &s, int lane, LeafRegs &L, int min, int max) {
-    if (min == max) return min;
-    if (leaf_bit(r, s, lane, L, CH_ZERO)) return 0;
-    int sign;
-    if (min < 0) { if (max > 0) sign = leaf_bit(r, s, lane, L, CH_SIGN); else sign = 0; }
-    else sign = 1;
-    const int amax = sign ? max : -min;
-    const int emax = ilog2u((uint32_t)amax);
-    int e = 0;
-    for (; e < emax; e++) if (leaf_bit(r, s, lane, L, CH_EXP + e)) break;
-    int have = 1 << e;
-    for (int pos = e; pos > 0;) {
-        pos--;
-        int minabs1 = have | (1 << pos);
-        if (minabs1 > amax) continue;  // 1-bit is impossible (symbol.h:180)
-        if (leaf_bit(r, s, lane, L, CH_MANT + pos)) have = minabs1;
+    // single-exit formulation (no early returns / breaks): hipcc's control-flow structuriser turns
+    // every early exit of an inlined function into extra mask bookkeeping and branches
+    int result = min;
+    if (min != max) {
+        result = 0;
+        if (!leaf_bit(r, s, lane, L, CH_ZERO)) {
+            int sign = 1;
+            if (min < 0) { sign = 0; if (max > 0) sign = leaf_bit(r, s, lane, L, CH_SIGN); }
+            const int amax = sign ? max : -min;
+            const int emax = ilog2u((uint32_t)amax);
+            int e = 0;
+            bool more = emax > 0;
+            while (more) {  // unary exponent: stop at the first 1 bit or at emax
+                const int b = leaf_bit(r, s, lane, L, CH_EXP + e);
+                e += 1 - b;
+                more = (b == 0) & (e < emax);
+            }
+            int have = 1 << e;
+            for (int pos = e - 1; pos >= 0; pos--) {
+                const int minabs1 = have | (1 << pos);
+                if (minabs1 <= amax) {  // else the 1-bit is impossible (symbol.h:180)
+                    const int b = leaf_bit(r, s, lane, L, CH_MANT + pos);
+                    have = b ? minabs1 : have;
+                }
+            }
+            result = sign ? have : -have;
+        }
     }
-    return sign ? have : -have;
+    return result;
 }
 DEV void leaf_commit(LeafRegs &L, int lane, const uint16_t *table) {
     if ((L.touched >> lane) & 1u) L.leafv = table[L.leafv * 2 + ((L.bits >> lane) & 1u)];
@@ -762,19 +781,19 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                                     // property its node tests (ds_bpermute from lane `prop` of pv) and compares;
                                     // the 63 outcomes form a mask; lane e checks whether the mask agrees with the
                                     // six decisions on the path to exit e -- exactly one exit matches.
-                                    int leaf;
+                                    int leaf = -1;
                                     uint2 nd = root_nd;
-                                    while (true) {
+                                    do {
                                         const int val = __builtin_amdgcn_ds_bpermute((int)((nd.y & 0xFFu) << 2), pv);
                                         const unsigned long long m = __ballot(val > (int)nd.x);
                                         const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
                                         const bool hit = ((((mlo ^ exp_lo) & msk_lo) | ((mhi ^ exp_hi) & msk_hi)) == 0u);
                                         const int e = __builtin_ctzll(__ballot(hit));
                                         const uint32_t tgt = (uint32_t)rdlane((int)nd.y, e) >> 8;
-                                        if (tgt & kLeafFlag) { leaf = (int)(tgt & (kLeafFlag - 1u)); break; }
-                                        if (tgt < (uint32_t)kLdsSuper) nd = lds_load_node(lds_nodes_addr + tgt * 512u + (uint32_t)lane * 8u);
+                                        if (tgt & kLeafFlag) leaf = (int)(tgt & (kLeafFlag - 1u));
+                                        else if (tgt < (uint32_t)kLdsSuper) nd = lds_load_node(lds_nodes_addr + tgt * 512u + (uint32_t)lane * 8u);
                                         else nd = global_load_node(&snodes_g[(size_t)tgt * 64 + lane]);
-                                    }
+                                    } while (leaf < 0);
                                     PROF_LAP(2);
                                     switch_leaf(leaf);
 #ifdef FUIF_PROF
