@@ -282,3 +282,49 @@ def encode_image(planes, bit_depth=8, ycocg=True, squeeze=True, max_properties=1
     blob = C.string_at(out.value, n.value)
     lib().fuifgpu_free_blob(out)
     return blob
+
+
+def group_by_signature(blobs):
+    """host-side batch scheduler, step 1: streams that share geometry + transform chain (equal
+    fuifgpu_image_info::signature) can share a launch.  Returns {signature: (Plan, [indices])} in
+    first-seen order.  Pure host code (no GPU)."""
+    groups = {}
+    for i, b in enumerate(blobs):
+        p = Plan(b)
+        sig = int(p.info.signature)
+        if sig not in groups:
+            groups[sig] = (p, [])
+        groups[sig][1].append(i)
+    return groups
+
+
+def plan_bytes_per_image(plan, avg_blob_bytes=0):
+    """HBM bytes one in-flight image needs: coefficient + output slabs + decoder scratch + its stream"""
+    return 4 * (plan.info.coef_elems + plan.info.out_elems) + 19 * (1 << 20) + int(avg_blob_bytes)
+
+
+def decode_mixed(blobs, preview=-1, hbm_budget_bytes=200 << 30):
+    """Decode an arbitrary list of streams (mixed sizes / Squeeze and DCT chains, BASELINE config C5's
+    shape): group by signature, run one batch per group in chunks that fit `hbm_budget_bytes`, and
+    return the per-image output planes in the caller's order plus the status words."""
+    outs = [None] * len(blobs)
+    status = np.zeros(len(blobs), np.int32)
+    for sig, (plan, idx) in group_by_signature(blobs).items():
+        per = plan_bytes_per_image(plan, sum(len(blobs[i]) for i in idx) / len(idx))
+        chunk = max(1, min(len(idx), int(hbm_budget_bytes // per), 65535))
+        for c0 in range(0, len(idx), chunk):
+            part = idx[c0:c0 + chunk]
+            sub = [blobs[i] for i in part]
+            batch = Batch(plan, len(sub), sum(len(b) for b in sub))
+            try:
+                batch.upload(sub, preview)
+                batch.decode()
+                batch.undo_transforms()
+                batch.sync()
+                st, _ = batch.status()
+                for k, i in enumerate(part):
+                    outs[i] = batch.out_planes(k)
+                    status[i] = st[k]
+            finally:
+                batch.close()
+    return outs, status

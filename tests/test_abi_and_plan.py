@@ -75,3 +75,14 @@ def test_no_gpu_fails_loudly(gpulib, manifest):
     with pytest.raises(gpulib.FuifGpuError) as ei:
         gpulib.decode_batch([golden_blob(e, e["cases"][0])])
     assert ei.value.code == 5  # FUIFGPU_E_HIP: no CPU fallback
+
+
+def test_group_by_signature_is_host_only(gpulib, manifest):
+    """mixed-stream scheduling (config C5 shape): grouping needs no GPU and keeps caller order inside a group"""
+    names = ["rgb8_128x128_I0", "jpeg420_256x192_q90", "rgb8_97x61", "rgb8_128x128_I0", "jpeg420_256x192_q90", "gray8_64x48"]
+    by = {e["name"]: e for e in manifest["fixtures"]}
+    blobs = [golden_blob(by[n], by[n]["cases"][0]) for n in names]
+    groups = gpulib.group_by_signature(blobs)
+    assert sorted(idx for _, idx in groups.values()) == [[0, 3], [1, 4], [2], [5]]
+    for plan, idx in groups.values():
+        assert gpulib.plan_bytes_per_image(plan) > 4 * (plan.info.coef_elems + plan.info.out_elems)

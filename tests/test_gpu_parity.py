@@ -76,3 +76,15 @@ def test_batch_of_replicas_and_distinct_streams(gpulib, manifest):
     for b, planes, s in zip(blobs, outs, st):
         assert [plane_hash(p) for p in planes] == exp[id(b)]
         assert (s & 1) == (1 if b is b2 else 0)
+
+
+def test_mixed_streams_scheduler(gpulib, manifest):
+    """config C5 shape: Squeeze and DCT streams of different sizes in one call, results in caller order"""
+    names = ["rgb8_128x128_I0", "jpeg420_256x192_q90", "rgb8_97x61", "rgb8_128x128_E0", "jpeg444_136x120_q85", "gray8_64x48",
+             "rgb8_128x128_I0", "jpeg420_256x192_q90"]
+    by = {e["name"]: e for e in manifest["fixtures"]}
+    blobs = [golden_blob(by[n], by[n]["cases"][0]) for n in names]
+    outs, st = gpulib.decode_mixed(blobs, hbm_budget_bytes=64 << 20)   # tiny budget: exercises chunking
+    assert not (st & 2).any()
+    for n, planes in zip(names, outs):
+        assert [plane_hash(p) for p in planes] == [c["sha256"] for c in by[n]["cases"][0]["post"]], n
