@@ -422,6 +422,9 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                 early = true;
                 break;
             }
+            // an inverted range can only come from a corrupt varint; the reference's uniform coder would recurse
+            // without end on it (symbol.h:44-57 asserts len >= 0), so it is reported as corruption here
+            if (maxv < minv) { fatal = true; break; }
             if (compress && !check_bit_depth(minv, maxv, predictor)) { fatal = true; break; }
         }
         __syncthreads();  // meta[] written by lane 0 is read below by every lane

@@ -660,6 +660,7 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
         if (c->minval == 0 && c->maxval == 0) continue;
         c->q = read_varint(io);
         if (LIMIT_HIT(io, btl)) return corrupt_or_truncated(io, c, btl);
+        if (c->maxval < c->minval) return 0; /* corrupt varint; symbol.h:45 asserts len >= 0 */
         if (compress && !check_bit_depth(c->minval, c->maxval, predictor)) return 0;
     }
     if (firstrealc > endc) { *beginc_io = endc; return 1; }
