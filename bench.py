@@ -37,6 +37,10 @@ WORKLOADS = {
     # BASELINE.json configs[2] -- JPEG-transcode shape (YCbCr + 4:2:0 + 8x8 DCT + Quantize + Squeeze of DC), lossy q90
     "c3": dict(channels=3, bits=8, kind="dct420", lossless=False,
                desc="C3: batch of %d %dx%d JPEG-transcode-like (YCbCr+4:2:0+DCT+Quantize q90) lossy per GPU"),
+    # BASELINE.json configs[3] -- deep-bit raw-sensor shape: 4 channels, 14 bit, Squeeze only (pass --width 8192 --height 8192
+    # --batch <what fits>: one 8192x8192x4 image needs 2.2 GB of planes)
+    "c4": dict(channels=4, bits=14, kind="squeeze_raw", lossless=True,
+               desc="C4: batch of %d %dx%d 14-bit 4-channel Squeeze-only lossless per GPU"),
 }
 
 
@@ -49,7 +53,7 @@ def _encode_one(args):
         img = photographic(w, h, channels, bits, seed=seed, sigma=1.0)
         return seed, encode_jpeg_like(img, 90, True)
     img = photographic(w, h, channels, bits, seed=seed)
-    return seed, fuif_amd.encode_image(img, bits, tree_mode=1)
+    return seed, fuif_amd.encode_image(img, bits, ycocg=(kind != "squeeze_raw"), tree_mode=1)
 
 
 def make_inputs(k, w, h, channels, bits, seed0, cache_dir, kind="squeeze"):
