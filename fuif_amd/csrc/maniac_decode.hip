@@ -784,19 +784,26 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                                     // property its node tests (ds_bpermute from lane `prop` of pv) and compares;
                                     // the 63 outcomes form a mask; lane e checks whether the mask agrees with the
                                     // six decisions on the path to exit e -- exactly one exit matches.
-                                    int leaf = -1;
-                                    uint2 nd = root_nd;
-                                    do {
+                                    // Control flow is kept to one `while` with a single condition and if-without-else
+                                    // bodies: hipcc's structuriser turns every if/else into 2-3 branches (~25 cycles each).
+                                    auto walk_round = [&](const uint2 nd) -> uint32_t {
                                         const int val = __builtin_amdgcn_ds_bpermute((int)((nd.y & 0xFFu) << 2), pv);
                                         const unsigned long long m = __ballot(val > (int)nd.x);
                                         const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
                                         const bool hit = ((((mlo ^ exp_lo) & msk_lo) | ((mhi ^ exp_hi) & msk_hi)) == 0u);
                                         const int e = __builtin_ctzll(__ballot(hit));
-                                        const uint32_t tgt = (uint32_t)rdlane((int)nd.y, e) >> 8;
-                                        if (tgt & kLeafFlag) leaf = (int)(tgt & (kLeafFlag - 1u));
-                                        else if (tgt < (uint32_t)kLdsSuper) nd = lds_load_node(lds_nodes_addr + tgt * 512u + (uint32_t)lane * 8u);
-                                        else nd = global_load_node(&snodes_g[(size_t)tgt * 64 + lane]);
-                                    } while (leaf < 0);
+                                        return (uint32_t)rdlane((int)nd.y, e) >> 8;
+                                    };
+                                    uint32_t tgt = walk_round(root_nd);
+                                    while (!(tgt & kLeafFlag)) {
+                                        // LDS-resident supernodes are the common case; the load is issued unconditionally
+                                        // (index clamped) and replaced in the rare deep case
+                                        const uint32_t li = tgt < (uint32_t)kLdsSuper ? tgt : (uint32_t)(kLdsSuper - 1);
+                                        uint2 nd = lds_load_node(lds_nodes_addr + li * 512u + (uint32_t)lane * 8u);
+                                        if (UNLIKELY(tgt >= (uint32_t)kLdsSuper)) nd = global_load_node(&snodes_g[(size_t)tgt * 64 + lane]);
+                                        tgt = walk_round(nd);
+                                    }
+                                    const int leaf = (int)(tgt & (kLeafFlag - 1u));
                                     PROF_LAP(2);
                                     switch_leaf(leaf);
 #ifdef FUIF_PROF
