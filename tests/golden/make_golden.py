@@ -59,6 +59,10 @@ JPEG_SPECS = [
     ("jpeg444_136x120_q85", dict(w=136, h=120, channels=3, bits=8, seed=21), dict(quality=85, subsampling=0)),
     ("jpeggray_120x88_q80", dict(w=120, h=88, channels=1, bits=8, seed=22), dict(quality=80)),
 ]
+# animation (FUAF): frames are stacked vertically; -M 0 keeps the 2D-match transform (out of scope) off
+ANIM_SPECS = [
+    ("anim3_48x32", dict(w=48, h=32, channels=3, bits=8, seed=700), dict(frames=3)),
+]
 PREVIEWS = {"c1_rgb8_512x512": [0, 1, 2, 3, 4], "rgb8_97x61": [0, 2, 4], "jpeg420_256x192_q90": [0, 1, 2, 3, 4]}
 TRUNCATE = {"rgb8_97x61": [0.2, 0.55, 0.93], "rgb8_128x128_I0": [0.5], "jpeg420_256x192_q90": [0.4], "rgb8_64x64_U": [0.6]}
 
@@ -67,11 +71,17 @@ def main():
     ref = Ref()
     manifest = {"generator": "tests/golden/make_golden.py", "reference": "cloudinary/fuif @ /root/reference (unmodified)", "fixtures": []}
     tmp = tempfile.mkdtemp()
-    for name, gen, flags in SPECS + [(n, g, j) for n, g, j in JPEG_SPECS]:
+    for name, gen, flags in SPECS + [(n, g, j) for n, g, j in JPEG_SPECS] + ANIM_SPECS:
         img = photographic(**gen)
         maxval = (1 << gen["bits"]) - 1
         out = os.path.join(HERE, name + ".fuif")
-        if isinstance(flags, dict):
+        if isinstance(flags, dict) and "frames" in flags:
+            for i in range(flags["frames"]):
+                g2 = dict(gen); g2["seed"] = gen["seed"] + i
+                write_pnm(os.path.join(tmp, name + "-%02d.ppm" % i), photographic(**g2), maxval)
+            src = os.path.join(tmp, name + "-%02d.ppm")
+            cli_flags = ["-M", "0"]
+        elif isinstance(flags, dict):
             from PIL import Image
             arr = np.moveaxis(img, 0, -1).astype(np.uint8)
             pil = Image.fromarray(arr[..., 0] if gen["channels"] == 1 else arr)
@@ -87,7 +97,7 @@ def main():
             raise SystemExit("reference CLI failed for %s: %s %s" % (name, r.stdout[-400:], r.stderr[-400:]))
         blob = open(out, "rb").read()
         entry = {"name": name, "file": name + ".fuif", "bytes": len(blob), "file_sha256": hashlib.sha256(blob).hexdigest(),
-                 "source": gen, "cli_flags": cli_flags if not isinstance(flags, dict) else ["<jpeg>", json.dumps(flags)], "cases": []}
+                 "source": gen, "cli_flags": cli_flags if not isinstance(flags, dict) else ["<jpeg/anim>", json.dumps(flags)] + cli_flags, "cases": []}
         cases = [("full", -1, len(blob))]
         cases += [("preview%d" % k, k, len(blob)) for k in PREVIEWS.get(name, [])]
         cases += [("trunc%02d" % int(f * 100), -1, int(len(blob) * f)) for f in TRUNCATE.get(name, [])]
