@@ -133,8 +133,20 @@ def main():
     ap.add_argument("--cache", default=os.environ.get("FUIF_BENCH_CACHE", "/tmp/fuif_bench_cache"))
     args = ap.parse_args()
 
-    import torch
     import fuif_amd
+    fuif_amd.build()
+    rank = int(os.environ.get("RANK", "0"))
+    wl = WORKLOADS[args.workload]
+    W, H, C, BITS = args.width, args.height, wl["channels"], wl["bits"]
+    K = max(1, min(args.distinct, args.batch))
+    # Inputs first: the encoder pool forks, so it runs before HIP, torch.distributed or any helper thread
+    # exists in this process.  Rank r decodes its own images: distinct seeds per rank.
+    t0 = time.time()
+    inputs = make_inputs(K, W, H, C, BITS, 1000 + 100 * rank, args.cache, wl["kind"])
+    t_gen = time.time() - t0
+    blobs = [inputs[i % K][1] for i in range(args.batch)]
+
+    import torch
     from fuif_amd import dist as fd
     rank, local_rank, world = fd.env_world()
     if not torch.cuda.is_available():
@@ -142,16 +154,6 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = fd.init(device=dev)
-    fuif_amd.build()
-
-    wl = WORKLOADS[args.workload]
-    W, H, C, BITS = args.width, args.height, wl["channels"], wl["bits"]
-    K = max(1, min(args.distinct, args.batch))
-    # rank r decodes its own images: distinct seeds per rank
-    t0 = time.time()
-    inputs = make_inputs(K, W, H, C, BITS, 1000 + 100 * rank, args.cache, wl["kind"])
-    t_gen = time.time() - t0
-    blobs = [inputs[i % K][1] for i in range(args.batch)]
 
     plan = fuif_amd.Plan(blobs[0])
     info = plan.info
