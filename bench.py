@@ -134,8 +134,19 @@ def main():
     args = ap.parse_args()
 
     import fuif_amd
-    fuif_amd.build()
     rank = int(os.environ.get("RANK", "0"))
+    # the HIP library is built by __graft_entry__.build() and travels in-tree; only a missing library is
+    # built here, by local rank 0 alone (N ranks must not run hipcc on the same output file)
+    lib_path = os.path.join(ROOT, "fuif_amd", "libfuifgpu.so")
+    if not os.path.exists(lib_path):
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            fuif_amd.build()
+        else:
+            for _ in range(600):
+                if os.path.exists(lib_path):
+                    break
+                time.sleep(1.0)
+    fuif_amd.lib()
     wl = WORKLOADS[args.workload]
     W, H, C, BITS = args.width, args.height, wl["channels"], wl["bits"]
     K = max(1, min(args.distinct, args.batch))
