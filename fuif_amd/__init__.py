@@ -22,7 +22,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("FUIF_AMD_LIB") or os.path.join(_HERE, "libfuifgpu.so")  # FUIF_AMD_LIB: diagnostic (-DFUIF_PROF) build
-_SOURCES = ["plan.cpp", "writer.cpp", "maniac_decode.hip", "transforms.hip", "capi.hip"]
+_SOURCES = ["plan.cpp", "index.cpp", "writer.cpp", "maniac_decode.hip", "transforms.hip", "capi.hip"]
 _lib = None
 
 
@@ -66,7 +66,7 @@ class ChannelDesc(C.Structure):
 
 class EncodeOptions(C.Structure):
     _fields_ = [("ycocg", C.c_int32), ("squeeze", C.c_int32), ("max_properties", C.c_int32), ("tree_mode", C.c_int32),
-                ("max_tree_nodes", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("max_tree_nodes", C.c_int32), ("emit_index", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 # every symbol include/fuifgpu.h declares (tests check that the library exports all of them)
@@ -78,6 +78,7 @@ ABI_SYMBOLS = [
     "fuifgpu_batch_channel_meta", "fuifgpu_batch_coef_ptr", "fuifgpu_batch_out_ptr", "fuifgpu_batch_download_coef",
     "fuifgpu_batch_download_out", "fuifgpu_batch_last_timing", "fuifgpu_batch_profile", "fuifgpu_inv_hsqueeze", "fuifgpu_inv_vsqueeze",
     "fuifgpu_inv_ycocg", "fuifgpu_inv_ycbcr", "fuifgpu_idct8x8", "fuifgpu_upsample", "fuifgpu_encode_image", "fuifgpu_encode_channels", "fuifgpu_free_blob",
+    "fuifgpu_index_parse", "fuifgpu_index_append", "fuifgpu_batch_group_index", "fuifgpu_batch_set_group_parallel",
 ]
 
 
@@ -123,6 +124,10 @@ def lib():
     L.fuifgpu_upsample.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     L.fuifgpu_encode_image.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(EncodeOptions), C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.fuifgpu_free_blob.argtypes = [vp]; L.fuifgpu_free_blob.restype = None
+    L.fuifgpu_index_parse.argtypes = [C.c_char_p, C.c_size_t, vp, vp, C.c_int, C.POINTER(C.c_int)]
+    L.fuifgpu_index_append.argtypes = [C.c_char_p, C.c_size_t, vp, vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.fuifgpu_batch_group_index.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int)]
+    L.fuifgpu_batch_set_group_parallel.argtypes = [vp, C.c_int]
     _lib = L
     return L
 
@@ -219,6 +224,17 @@ class Batch:
         _check(lib().fuifgpu_batch_status(self._h, st.ctypes.data, used.ctypes.data))
         return st, used
 
+    def set_group_parallel(self, enable):
+        """False: ignore group indices (one wavefront per image, as for streams that carry none); applies to the next upload"""
+        _check(lib().fuifgpu_batch_set_group_parallel(self._h, int(bool(enable))))
+
+    def group_index(self, image):
+        """[(first_channel, byte_offset)] of every channel group the last decode of `image` went through"""
+        nch = self.plan.info.nb_coded_channels
+        fc, st, n = np.zeros(max(nch, 1), np.int32), np.zeros(max(nch, 1), np.uint32), C.c_int(0)
+        _check(lib().fuifgpu_batch_group_index(self._h, image, fc.ctypes.data, st.ctypes.data, nch, C.byref(n)))
+        return [(int(fc[i]), int(st[i])) for i in range(n.value)]
+
     def channel_meta(self, image):
         m = np.zeros((self.plan.info.nb_coded_channels, 4), np.int32)
         _check(lib().fuifgpu_batch_channel_meta(self._h, image, m.ctypes.data))
@@ -271,17 +287,36 @@ def decode_batch(blobs, preview=-1, undo=True):
         batch.close()
 
 
-def encode_image(planes, bit_depth=8, ycocg=True, squeeze=True, max_properties=12, tree_mode=1, max_tree_nodes=4095):
-    """(C,H,W) int32 planes -> lossless .fuif bytes (host C++ writer, csrc/writer.cpp)."""
+def encode_image(planes, bit_depth=8, ycocg=True, squeeze=True, max_properties=12, tree_mode=1, max_tree_nodes=4095, index=False):
+    """(C,H,W) int32 planes -> lossless .fuif bytes (host C++ writer, csrc/writer.cpp).
+    index=True appends the group index trailer (csrc/index.cpp) that unlocks one-wavefront-per-group decoding."""
     planes = np.ascontiguousarray(planes, dtype=np.int32)
     c, h, w = planes.shape
-    opt = EncodeOptions(int(ycocg), int(squeeze), max_properties, tree_mode, max_tree_nodes, (C.c_int32 * 3)(0, 0, 0))
+    opt = EncodeOptions(int(ycocg), int(squeeze), max_properties, tree_mode, max_tree_nodes, int(index), (C.c_int32 * 2)(0, 0))
     out = C.c_void_p()
     n = C.c_size_t(0)
     _check(lib().fuifgpu_encode_image(planes.ctypes.data, w, h, c, bit_depth, C.byref(opt), C.byref(out), C.byref(n)))
     blob = C.string_at(out.value, n.value)
     lib().fuifgpu_free_blob(out)
     return blob
+
+
+def index_parse(blob):
+    """[(first_channel, byte_offset)] from the stream's group index trailer (csrc/index.cpp); [] when it has none"""
+    fc, st, n = np.zeros(4096, np.int32), np.zeros(4096, np.uint32), C.c_int(0)
+    _check(lib().fuifgpu_index_parse(blob, len(blob), fc.ctypes.data, st.ctypes.data, 4096, C.byref(n)))
+    return [(int(fc[i]), int(st[i])) for i in range(min(n.value, 4096))]
+
+
+def index_append(blob, groups):
+    """the stream with a group index trailer built from [(first_channel, byte_offset)] (an existing trailer is replaced)"""
+    fc = np.array([g[0] for g in groups], np.int32)
+    st = np.array([g[1] for g in groups], np.uint32)
+    out, n = C.c_void_p(), C.c_size_t(0)
+    _check(lib().fuifgpu_index_append(blob, len(blob), fc.ctypes.data, st.ctypes.data, len(groups), C.byref(out), C.byref(n)))
+    res = C.string_at(out.value, n.value)
+    lib().fuifgpu_free_blob(out)
+    return res
 
 
 def group_by_signature(blobs):

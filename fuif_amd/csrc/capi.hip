@@ -38,6 +38,14 @@ struct fuifgpu_batch {
     uint16_t *d_tables = nullptr;
     uint8_t *d_scratch = nullptr;
     size_t scratch_stride = 0, bfs_off = 0, leaves_off = 0, stack_off = 0, queue_off = 0;
+    int scratch_waves = 0;            // wavefronts d_scratch is sized for
+    int max_waves = 0;                // resident wavefronts the device holds (occupancy x CUs)
+    int n_waves = 0;                  // persistent wavefronts of the next decode launch
+    bool group_parallel = true;       // use group indices (index.cpp) when streams carry them
+    Tile *d_tiles = nullptr;
+    int tiles_cap = 0, n_tiles = 0;
+    uint32_t *d_progress = nullptr, *d_group_start = nullptr, *d_queue_head = nullptr;
+    std::vector<Tile> tiles;
     int max_nodes = kMaxNodes;
     int32_t *d_coef = nullptr, *d_out = nullptr, *d_tmp = nullptr;
     bool own_coef = false, own_out = false;
@@ -64,10 +72,14 @@ static int hip_fail(hipError_t e, const char *what) {
     } while (0)
 
 namespace fuifgpu {
+// With M supernodes that have children (>= 6 inner nodes each, and >= k-1 for k children) and T
+// without (>= 1 each): inner >= 2T-1 and inner >= 6M+T, so M+T <= (7 inner + 5)/12 < 0.3 max_nodes.
+// The kernel checks the bound it is given.
+int maniac_max_supernodes(int max_nodes) { return (int)(((int64_t)max_nodes + 1) * 5 / 16 + 66); }
 size_t maniac_scratch_bytes(int max_nodes, size_t *bfs_off, size_t *leaves_off, size_t *stack_off, size_t *queue_off) {
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     size_t nodes = up((size_t)(max_nodes + 1) * 8);
-    size_t snodes = up((size_t)((max_nodes + 1) / 2 + 1) * 512);  // one supernode per inner node at worst
+    size_t snodes = up((size_t)maniac_max_supernodes(max_nodes) * 512);
     size_t leaves = up((size_t)((max_nodes + 1) / 2 + 1) * kLeafStride * 2);
     size_t stack = up((size_t)kTreeStackDepth * 24);
     size_t queue = up((size_t)(max_nodes + 1) * 4);
@@ -156,6 +168,7 @@ void fuifgpu_batch_destroy(fuifgpu_batch *b) {
     if (!b) return;
     hipFree(b->d_blobs); hipFree(b->d_jobs); hipFree(b->d_geom); hipFree(b->d_meta); hipFree(b->d_status); hipFree(b->d_consumed);
     hipFree(b->d_tables); hipFree(b->d_scratch); hipFree(b->d_tmp); hipFree(b->d_list); hipFree(b->d_prof);
+    hipFree(b->d_tiles); hipFree(b->d_progress); hipFree(b->d_group_start); hipFree(b->d_queue_head);
     if (b->own_coef) hipFree(b->d_coef);
     if (b->own_out) hipFree(b->d_out);
     if (b->h_blobs) hipHostFree(b->h_blobs);
@@ -198,7 +211,11 @@ int fuifgpu_batch_create(const fuifgpu_plan *plan, int n_images, size_t blob_cap
         CHK(hipMemcpy(b->d_tables, tables.data(), tables.size() * 2, hipMemcpyHostToDevice));
     }
     b->scratch_stride = maniac_scratch_bytes(b->max_nodes, &b->bfs_off, &b->leaves_off, &b->stack_off, &b->queue_off);
-    CHK(hipMalloc((void **)&b->d_scratch, b->scratch_stride * n_images));
+    b->max_waves = maniac_max_waves();
+    if (b->max_waves < 1) { g_last_error = "cannot query the device occupancy of the entropy kernel"; fuifgpu_batch_destroy(b); return FUIFGPU_E_HIP; }
+    CHK(hipMalloc((void **)&b->d_progress, sizeof(uint32_t) * (size_t)n_images * std::max(nch, 1)));
+    CHK(hipMalloc((void **)&b->d_group_start, sizeof(uint32_t) * (size_t)n_images * std::max(nch, 1)));
+    CHK(hipMalloc((void **)&b->d_queue_head, 256));
     if (coef_ext) b->d_coef = coef_ext;
     else { CHK(hipMalloc((void **)&b->d_coef, sizeof(int32_t) * (size_t)std::max<int64_t>(p.coef_elems, 1) * n_images)); b->own_coef = true; }
     if (out_ext) b->d_out = out_ext;
@@ -231,6 +248,9 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
     // Distinct host blobs are copied H2D once; replicas (same host pointer) are duplicated D2D so a
     // 1024-image batch built from K distinct streams moves K streams over PCIe, not 1024.
     std::vector<std::pair<const uint8_t *, int>> seen;
+    const int nch = (int)b->plan.coded.size();
+    std::vector<std::vector<GroupEntry>> groups;   // per distinct stream: its tiles' first bytes / channels
+    std::vector<int> group_of(n_images, -1);
     HIPCHK(hipStreamSynchronize(st));
     for (int i = 0; i < n_images; i++) {
         if (sizes[i] > 0xFFFFFFF0ull) return FUIFGPU_E_ARG;
@@ -243,6 +263,11 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
             int r = parse_and_plan(blobs[i], sizes[i], tmp);
             if (r != FUIFGPU_OK) { g_last_error = tmp.message; return r; }
             if (tmp.signature != b->plan.signature) { g_last_error = "image " + std::to_string(i) + " has a different geometry/transform chain"; return FUIFGPU_E_MISMATCH; }
+            std::vector<GroupEntry> idx;
+            if (b->group_parallel) parse_index_trailer(blobs[i], sizes[i], tmp.data_start, nch, idx, nullptr);
+            if (idx.empty()) idx.push_back(GroupEntry{(uint32_t)tmp.data_start, 0});
+            groups.push_back(std::move(idx));
+            group_of[i] = (int)groups.size() - 1;
             HIPCHK(hipMemsetAsync(b->d_blobs + off + (padded - 32), 0, 32, st));
             HIPCHK(hipMemcpyAsync(b->d_blobs + off, blobs[i], sizes[i], hipMemcpyHostToDevice, st));
             j.data_start = (uint32_t)tmp.data_start;
@@ -252,12 +277,45 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
             HIPCHK(hipMemcpyAsync(b->d_blobs + off, b->d_blobs + b->jobs[src].blob_off, padded, hipMemcpyDeviceToDevice, st));
             j.data_start = b->jobs[src].data_start;
             j.limit = b->jobs[src].limit;
+            group_of[i] = group_of[src];
         }
         j.blob_off = off; j.blob_size = (uint32_t)sizes[i];
         j.flags = 0;
         off += padded;
     }
     HIPCHK(hipMemcpyAsync(b->d_jobs, b->jobs.data(), sizeof(StreamJob) * n_images, hipMemcpyHostToDevice, st));
+    // Work list in dependency order: tile k of every image before tile k+1 of any image, so a tile's
+    // producers (earlier groups of the same image) are always ahead of it in the list, and the big
+    // final groups of all images sit together at the end, where they balance the machine.
+    b->tiles.clear();
+    size_t deepest = 0;
+    for (auto &g : groups) deepest = std::max(deepest, g.size());
+    for (size_t k = 0; k < deepest; k++)
+        for (int i = 0; i < n_images; i++) {
+            const std::vector<GroupEntry> &g = groups[group_of[i]];
+            if (k >= g.size()) continue;
+            Tile t;
+            t.image = (uint32_t)i;
+            t.start = g[k].start;
+            t.first_channel = k == 0 ? 0 : g[k].first_channel;
+            t.last_channel = k + 1 < g.size() ? g[k + 1].first_channel - 1 : nch - 1;
+            b->tiles.push_back(t);
+        }
+    b->n_tiles = (int)b->tiles.size();
+    if (b->n_tiles > b->tiles_cap) {
+        hipFree(b->d_tiles); b->d_tiles = nullptr; b->tiles_cap = 0;
+        HIPCHK(hipMalloc((void **)&b->d_tiles, sizeof(Tile) * (size_t)b->n_tiles));
+        b->tiles_cap = b->n_tiles;
+    }
+    if (b->n_tiles) HIPCHK(hipMemcpyAsync(b->d_tiles, b->tiles.data(), sizeof(Tile) * (size_t)b->n_tiles, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));  // b->tiles / b->jobs may be rebuilt by the next upload
+    // one persistent wavefront per tile up to what the device holds at once; each owns a scratch area
+    b->n_waves = std::max(1, std::min(b->n_tiles, b->max_waves));
+    if (b->n_waves > b->scratch_waves) {
+        hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_waves = 0;
+        HIPCHK(hipMalloc((void **)&b->d_scratch, b->scratch_stride * (size_t)b->n_waves));
+        b->scratch_waves = b->n_waves;
+    }
     b->n_loaded = n_images;
     return FUIFGPU_OK;
 }
@@ -267,13 +325,21 @@ int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const int nch = (int)b->plan.coded.size();
     HIPCHK(hipMemsetAsync(b->d_meta, 0, sizeof(ChannelMeta) * (size_t)b->n_loaded * std::max(nch, 1), st));
+    // every word the tiles poll or accumulate into is zeroed before every launch
+    HIPCHK(hipMemsetAsync(b->d_progress, 0, sizeof(uint32_t) * (size_t)b->n_loaded * std::max(nch, 1), st));
+    HIPCHK(hipMemsetAsync(b->d_group_start, 0, sizeof(uint32_t) * (size_t)b->n_loaded * std::max(nch, 1), st));
+    HIPCHK(hipMemsetAsync(b->d_queue_head, 0, 256, st));
+    HIPCHK(hipMemsetAsync(b->d_status, 0, sizeof(int32_t) * b->n_loaded, st));
+    HIPCHK(hipMemsetAsync(b->d_consumed, 0, sizeof(uint32_t) * b->n_loaded, st));
+    HIPCHK(hipMemsetAsync(b->d_prof, 0, sizeof(unsigned long long) * 8 * b->n_loaded, st));
     DecodeParams P{};
     P.blobs = b->d_blobs; P.jobs = b->d_jobs; P.n_images = b->n_loaded; P.n_channels = nch; P.geom = b->d_geom;
     P.coef = b->d_coef; P.coef_stride = b->plan.coef_elems; P.meta = b->d_meta; P.status = b->d_status; P.consumed = b->d_consumed;
     P.tables = b->d_tables; P.scratch = b->d_scratch; P.scratch_stride = b->scratch_stride; P.bfs_off = b->bfs_off; P.leaves_off = b->leaves_off;
-    P.stack_off = b->stack_off; P.queue_off = b->queue_off; P.max_properties = b->plan.max_properties; P.max_nodes = b->max_nodes; P.prof = b->d_prof;
+    P.stack_off = b->stack_off; P.queue_off = b->queue_off; P.max_properties = b->plan.max_properties; P.max_nodes = b->max_nodes; P.max_super = maniac_max_supernodes(b->max_nodes); P.prof = b->d_prof;
+    P.tiles = b->d_tiles; P.n_tiles = b->n_tiles; P.queue_head = b->d_queue_head; P.progress = b->d_progress; P.group_start = b->d_group_start;
     HIPCHK(hipEventRecord(b->ev[0], st));
-    launch_maniac_decode(P, st);
+    launch_maniac_decode(P, b->n_waves, st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->ev[1], st));
     b->decode_timed = true;
@@ -311,6 +377,31 @@ int fuifgpu_batch_status(fuifgpu_batch *b, int32_t *status, uint32_t *bytes_cons
     HIPCHK(hipDeviceSynchronize());
     if (status) HIPCHK(hipMemcpy(status, b->d_status, sizeof(int32_t) * b->n_loaded, hipMemcpyDeviceToHost));
     if (bytes_consumed) HIPCHK(hipMemcpy(bytes_consumed, b->d_consumed, sizeof(uint32_t) * b->n_loaded, hipMemcpyDeviceToHost));
+    return FUIFGPU_OK;
+}
+
+int fuifgpu_batch_set_group_parallel(fuifgpu_batch *b, int enable) {
+    if (!b) return FUIFGPU_E_ARG;
+    b->group_parallel = enable != 0;
+    return FUIFGPU_OK;
+}
+
+int fuifgpu_batch_group_index(fuifgpu_batch *b, int image, int32_t *first_channel, uint32_t *start, int cap, int *n_groups) {
+    if (!b || image < 0 || image >= b->n_loaded || !n_groups) return FUIFGPU_E_ARG;
+    const int nch = (int)b->plan.coded.size();
+    std::vector<uint32_t> gs(std::max(nch, 1));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(gs.data(), b->d_group_start + (size_t)image * nch, sizeof(uint32_t) * nch, hipMemcpyDeviceToHost));
+    int n = 0;
+    for (int c = 0; c < nch; c++) {
+        if (!gs[c]) continue;
+        if (n < cap) {
+            if (first_channel) first_channel[n] = c;
+            if (start) start[n] = gs[c] - 1u;
+        }
+        n++;
+    }
+    *n_groups = n;
     return FUIFGPU_OK;
 }
 

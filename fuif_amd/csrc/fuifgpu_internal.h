@@ -29,6 +29,7 @@ enum : int {
     ST_TRUNCATED = 1,       // ran into EOF / the preview byte limit (not an error: encoding.cpp:209-219)
     ST_CORRUPT = 2,         // the reference would return false
     ST_UNSUPPORTED = 4,     // needs a feature outside SURVEY.md §8 (bit depth, tree size, ...)
+    ST_STALLED = 8,         // internal: a tile gave up waiting for another tile's rows (never expected; reported with ST_CORRUPT)
 };
 
 // Geometry of one coded channel after all meta transforms (image/image.h:54-91 minus the data)
@@ -52,6 +53,15 @@ struct StreamJob {
     uint32_t data_start;  // first byte after the header = first channel group
     uint32_t limit;       // bytes_to_load for responsive decodes (0 = none), encoding.cpp:704-705
     uint32_t flags;       // bit 0: BlobReader EOF semantics (fileio.h:100-102) instead of FileIO/feof
+};
+
+// One unit of entropy-decoding work: a run of consecutive channel groups of one image whose first
+// byte is known.  Without a group index (index.cpp) that is the whole stream; with one, every
+// group is its own tile and gets its own wavefront.
+struct Tile {
+    uint32_t image;
+    uint32_t start;                       // byte offset of the first group header of the tile
+    int32_t first_channel, last_channel;  // coded channels [first,last] are decoded (or zero-filled) by this tile
 };
 
 // --- inverse-transform schedule ---------------------------------------------------------------
@@ -105,6 +115,14 @@ struct Plan {
     int error = 0;                              // FUIFGPU_E_* (0 = ok)
     std::string message;
 };
+
+// One channel group of a stream: where its header starts and the first channel it codes (index.cpp)
+struct GroupEntry {
+    uint32_t start;
+    int32_t first_channel;
+};
+void build_index_trailer(const std::vector<GroupEntry> &groups, std::vector<uint8_t> &out);
+bool parse_index_trailer(const uint8_t *blob, size_t n, size_t data_start, int nch, std::vector<GroupEntry> &groups, size_t *stream_end);
 
 // host planner (plan.cpp)
 int parse_and_plan(const uint8_t *blob, size_t n, Plan &plan);

@@ -18,14 +18,24 @@ struct DecodeParams {
     int32_t *status;             // [n_images]
     uint32_t *consumed;          // [n_images]
     const uint16_t *tables;      // [0,8192): tree coder table, [8192,16384): pixel coder table
-    uint8_t *scratch;            // per stream: parse-order nodes | breadth-first nodes | leaves | parse stack | BFS queue
+    // work list: tiles in dependency order (a tile only reads channels of tiles before it), handed
+    // out to persistent wavefronts through *queue_head
+    const Tile *tiles;
+    int32_t n_tiles;
+    uint32_t *queue_head;        // zeroed before the launch
+    uint32_t *progress;          // [n_images][n_channels] 0 = nothing yet, 1 + rows finished once the header is known; zeroed before the launch
+    uint32_t *group_start;       // [n_images][n_channels] 1 + byte offset of the group that starts at this channel (0 = none); zeroed before the launch
+    uint8_t *scratch;            // per wavefront: parse-order nodes | breadth-first nodes | leaves | parse stack | BFS queue
     size_t scratch_stride, bfs_off, leaves_off, stack_off, queue_off;
     int32_t max_properties;
     int32_t max_nodes;
+    int32_t max_super;           // supernodes the scratch area holds
     unsigned long long *prof;    // -DFUIF_PROF builds: 8 cycle counters per stream (else unused)
 };
 
+int maniac_max_supernodes(int max_nodes);
 size_t maniac_scratch_bytes(int max_nodes, size_t *bfs_off, size_t *leaves_off, size_t *stack_off, size_t *queue_off);
-void launch_maniac_decode(const DecodeParams &P, hipStream_t stream);
+int maniac_max_waves();   // persistent wavefronts the device can hold at once (occupancy x CUs)
+void launch_maniac_decode(const DecodeParams &P, int n_waves, hipStream_t stream);
 
 }  // namespace fuifgpu

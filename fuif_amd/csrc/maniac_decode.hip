@@ -65,7 +65,10 @@ namespace {
 #endif
 
 constexpr int CH_ZERO = 0, CH_SIGN = 1, CH_EXP = 2, CH_MANT = 16, CH_N = 31;
-constexpr int kLdsSuper = 58;     // 58 supernodes x 512 B = 29 KB of the context tree in LDS
+#ifndef FUIF_LDS_SUPER
+#define FUIF_LDS_SUPER 58
+#endif
+constexpr int kLdsSuper = FUIF_LDS_SUPER;  // 58 supernodes x 512 B = 29 KB of the context tree in LDS
 constexpr uint32_t kLeafFlag = 0x800000u;
 constexpr int kPropPitch = 33;    // odd pitch: conflict-free column writes / row reads
 
@@ -74,6 +77,21 @@ DEV uint32_t rflu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane(
 DEV int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 // clang for ROCm 7.2 has no writelane builtin: a uniform compare + v_cndmask does the same job
 DEV int wrlane(int val, int l, int old) { return ((int)threadIdx.x == l) ? val : old; }
+
+// ---- tile-to-tile hand-off (placement independent) ----------------------------------------------
+// Tiles of one image run on different wavefronts, possibly on different XCDs whose L2s are not
+// coherent.  Everything one tile writes and another reads (coefficient planes, ChannelMeta, the
+// progress words) is therefore stored write-through (sc1, agent-scope relaxed atomics) and read
+// with agent-scope loads that bypass the CU's L1; a progress word is stored only after
+// `s_waitcnt vmcnt(0)` has drained the payload stores of the (single) writing wave.
+typedef __attribute__((address_space(1))) int32_t gi32;
+typedef __attribute__((address_space(1))) uint32_t gu32;
+DEV void st_agent(int32_t *p, int v) { __hip_atomic_store((gi32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store((gu32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV int ld_agent(const int32_t *p) { return __hip_atomic_load((const gi32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load((const gu32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+constexpr uint32_t kSpinLimit = 1u << 25;   // x (sleep + one L2 round trip) ~ a minute: only a lost producer gets here
 
 struct Node {  // maniac/compound.h:41-51; property -1 = leaf, child = leaf id
     int32_t splitval;
@@ -314,6 +332,7 @@ DEV bool check_bit_depth(int minv, int maxv, int predictor) {
 struct RefChan {  // one reference channel of the current group (context_predict.h:233-289)
     int64_t off;  // element offset of the plane inside the image's coefficient slab
     int32_t w, h, hshift, vshift;
+    int32_t chan, pad;
 };
 
 struct Shared {
@@ -325,34 +344,19 @@ struct Shared {
 };
 
 DEV void fill_plane(int32_t *plane, int64_t first, int64_t count, int v, int lane) {
-    for (int64_t i = first + lane; i < first + count; i += 64) plane[i] = v;
+    for (int64_t i = first + lane; i < first + count; i += 64) st_agent(plane + i, v);
 }
 
 }  // namespace
 
 __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
     __shared__ Shared sh;
-    const int img = blockIdx.x;
     const int lane = threadIdx.x;
-    if (img >= P.n_images) return;
 
     const uint16_t *tree_table = P.tables;          // cut 2, alpha 0xFFFFFFFF/19 (compound.h:262)
     const uint16_t *pixel_table = P.tables + 8192;  // cut 6, alpha 0x0d000000 (encoding.h:54-55)
 
-    const StreamJob job = P.jobs[img];
-    Stream s;
-    s.p = P.blobs + job.blob_off;
-    s.size = rflu(job.blob_size);
-    s.pos = rflu(job.data_start);
-    s.limit = rflu(job.limit);
-    s.win_base = 0xFFFFFF00u;
-    s.win = 0;
-    s.eof_flag = 0;
-    s.blob_mode = rfl((int)(job.flags & 1u));
-
-    int32_t *coef = P.coef + (int64_t)img * P.coef_stride;
-    ChannelMeta *meta = P.meta + (int64_t)img * P.n_channels;
-    uint8_t *scratch = P.scratch + (size_t)img * P.scratch_stride;
+    uint8_t *scratch = P.scratch + (size_t)blockIdx.x * P.scratch_stride;  // per wavefront, reused from tile to tile
     Node *nodes = reinterpret_cast<Node *>(scratch);                          // parse-order nodes
     uint2 *snodes_g = reinterpret_cast<uint2 *>(scratch + P.bfs_off);         // supernodes (64 x 8 B each)
     uint16_t *leaves = reinterpret_cast<uint16_t *>(scratch + P.leaves_off);
@@ -360,8 +364,6 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
     int32_t *queue = reinterpret_cast<int32_t *>(scratch + P.queue_off);      // breadth-first work list
     const ChannelGeom *geom = P.geom;
     const int nch = P.n_channels;
-    int status = 0;
-    PROF_DECL;
     const uint32_t lds_nodes_addr = (uint32_t)(uintptr_t)(&sh.snodes[0]);  // LDS byte offset (low half of the flat address)
     // geometry of a 6-level supernode in heap order (children of slot k: 2k+1 = "> split", 2k+2 = "<= split"):
     // lane e owns exit e; exp/msk = the decisions its path needs and the slots they sit in
@@ -374,14 +376,55 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
         exit_q = 2 * exit_q + (gt ? 1 : 2);
     }
 
+    // ---- persistent wavefront: take tiles in list order until the list is empty ----------------
+    // A tile only waits for tiles EARLIER in the list, and a tile that has been taken is running on
+    // a resident wavefront, so the earliest unfinished tile can always make progress: no deadlock,
+    // whatever the dispatch order or placement of the wavefronts.
+    for (;;) {
+    uint32_t tix = 0;
+    if (lane == 0) tix = atomicAdd(P.queue_head, 1u);
+    tix = rflu(tix);
+    if (tix >= (uint32_t)P.n_tiles) break;
+    const Tile tile = P.tiles[tix];
+    const int img = rfl((int)tile.image);
+    const int first_c = rfl(tile.first_channel), last_c = rfl(tile.last_channel);
+
+    const StreamJob job = P.jobs[img];
+    Stream s;
+    s.p = P.blobs + job.blob_off;
+    s.size = rflu(job.blob_size);
+    s.pos = rflu(tile.start);
+    s.limit = rflu(job.limit);
+    s.win_base = 0xFFFFFF00u;
+    s.win = 0;
+    s.eof_flag = 0;
+    s.blob_mode = rfl((int)(job.flags & 1u));
+
+    int32_t *coef = P.coef + (int64_t)img * P.coef_stride;
+    ChannelMeta *meta = P.meta + (int64_t)img * P.n_channels;
+    uint32_t *progress = P.progress + (size_t)img * nch;
+    int status = 0;
+    bool stalled = false;
+    PROF_DECL;
+    // progress word of channel c: 1 = ChannelMeta valid, 1 + r = rows [0,r) final, 1 + h = plane final
+    auto publish = [&](int c, uint32_t v) { drain_stores(); if (lane == 0) st_agent(progress + c, v); };
+    auto wait_header = [&](int c) {
+        uint32_t spins = 0;
+        while (!stalled && rflu(ld_agent(progress + c)) == 0u) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > kSpinLimit) { stalled = true; status |= ST_STALLED | ST_CORRUPT; }
+        }
+    };
+
     // ---- fuif_decode channel loop: encoding.cpp:708-717 -------------------------------------
-    for (int ci = 0; ci < nch; ci++) {
+    for (int ci = first_c; ci <= last_c; ci++) {
         if (!((s.limit == 0 || s.pos < s.limit) && !s_eof(s))) break;
         if (!rfl(geom[ci].w) || !rfl(geom[ci].h)) continue;
 
         // ---- fuif_decode_channel: encoding.cpp:259-429 --------------------------------------
         const int beginc = ci;
         if (s_limit_hit(s)) continue;
+        const uint32_t group_pos = s.pos;
         int firstbyte = s_varint(s, lane);
         if (s_limit_hit(s)) continue;
         const int endc = beginc + (firstbyte >> 4);
@@ -393,14 +436,15 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
         if (s_limit_hit(s)) continue;
         const int global_maxv = global_minv + s_varint(s, lane);
         if (s_limit_hit(s)) continue;
-        if (endc >= nch || endc < beginc) { status |= ST_CORRUPT; break; }
+        if (endc > last_c || endc < beginc) { status |= ST_CORRUPT; break; }  // a group never crosses a tile (or the channel list)
+        if (lane == 0) P.group_start[(size_t)img * nch + beginc] = group_pos + 1u;
 
         int firstrealc = beginc;
         bool fatal = false, early = false;
         for (int i = beginc; i <= endc; i++) {
             const int gw = rfl(geom[i].w), gh = rfl(geom[i].h);
             const int64_t goff = geom[i].coef_off;
-            if ((int64_t)gw * gh <= 0) continue;
+            if ((int64_t)gw * gh <= 0) { publish(i, 1u); continue; }
             int minv = global_minv, maxv = global_maxv;
             if (endc > beginc && global_minv < global_maxv) {
                 minv += s_varint(s, lane);
@@ -413,11 +457,13 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
             }
             bool have_q = !(minv == 0 && maxv == 0);
             if (have_q) q = s_varint(s, lane);
-            if (lane == 0) { meta[i].minval = minv; meta[i].maxval = maxv; meta[i].q = q; meta[i].decoded = (minv == maxv) ? 1 : 0; }
+            if (lane == 0) { st_agent(&meta[i].minval, minv); st_agent(&meta[i].maxval, maxv); st_agent(&meta[i].q, q); st_agent(&meta[i].decoded, (minv == maxv) ? 1 : 0); }
+            publish(i, (minv == maxv) ? (uint32_t)gh + 1u : 1u);  // header known (constant planes are already final)
             if (!have_q) continue;
             if (s_limit_hit(s)) {  // corrupt_or_truncated: encoding.cpp:209-219 (isEOF or limit => zero-fill, true)
                 fill_plane(coef + goff, 0, (int64_t)gw * gh, 0, lane);
-                if (lane == 0) meta[i].decoded = 1;
+                if (lane == 0) st_agent(&meta[i].decoded, 1);
+                publish(i, (uint32_t)gh + 1u);
                 status |= ST_TRUNCATED;
                 early = true;
                 break;
@@ -438,7 +484,8 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
         {
             int offset = 0;
             for (int j = beginc - 1; j >= 0 && offset < P.max_properties; j--) {
-                const int jmin = rfl(meta[j].minval), jmax = rfl(meta[j].maxval);
+                if (j < first_c) wait_header(j);  // another tile's channel: its header may still be on its way
+                const int jmin = rfl(ld_agent(&meta[j].minval)), jmax = rfl(ld_agent(&meta[j].maxval));
                 if (jmin == jmax) continue;
                 if (rfl(geom[j].hshift) < 0) continue;
                 int mn = jmin; if (mn > 0) mn = 0;
@@ -449,6 +496,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                     RefChan rc;
                     rc.off = geom[j].coef_off;
                     rc.w = geom[j].w; rc.h = geom[j].h; rc.hshift = geom[j].hshift; rc.vshift = geom[j].vshift;
+                    rc.chan = j; rc.pad = 0;
                     sh.refs[nrefs] = rc;
                 }
                 nprops += 2; offset += 2;
@@ -458,7 +506,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
             for (int j = beginc; j <= endc; j++) {
                 // zero-pixel channels keep their constructor range (0,0 for inserted residual
                 // channels) in the reference; meta[] is zero-initialised likewise
-                const int jmin = rfl(meta[j].minval), jmax = rfl(meta[j].maxval);
+                const int jmin = rfl(ld_agent(&meta[j].minval)), jmax = rfl(ld_agent(&meta[j].maxval));
                 if (jmin < mn) mn = jmin;
                 if (jmax > mx) mx = jmax;
                 const int jh = rfl(geom[j].h), jw = rfl(geom[j].w);
@@ -490,7 +538,8 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
             if (rounded < 1 || rounded > 127) {
                 if (s_limit_hit(s)) {
                     fill_plane(coef + geom[firstrealc].coef_off, 0, (int64_t)geom[firstrealc].w * geom[firstrealc].h, 0, lane);
-                    if (lane == 0) meta[firstrealc].decoded = 1;
+                    if (lane == 0) st_agent(&meta[firstrealc].decoded, 1);
+                    publish(firstrealc, (uint32_t)rfl(geom[firstrealc].h) + 1u);
                     status |= ST_TRUNCATED;
                     continue;
                 }
@@ -507,7 +556,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
             // uncompressed group: encoding.cpp:334-354
             for (int i = beginc; i <= endc; i++) {
                 const int gw = rfl(geom[i].w), gh = rfl(geom[i].h);
-                const int minv = rfl(meta[i].minval), maxv = rfl(meta[i].maxval);
+                const int minv = rfl(ld_agent(&meta[i].minval)), maxv = rfl(ld_agent(&meta[i].maxval));
                 if (minv == maxv) continue;
                 int32_t *plane = coef + geom[i].coef_off;
                 const int zero = minv > 0 ? minv : (maxv < 0 ? maxv : 0);
@@ -518,11 +567,13 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                         const int nx = min(64, gw - x0);
                         int rowv = 0;
                         for (int j = 0; j < nx; j++) rowv = wrlane(uniform_read(rac, s, lane, minv, maxv - minv), j, rowv);
-                        if (lane < nx) plane[(int64_t)y * gw + x0 + lane] = rowv;
+                        if (lane < nx) st_agent(plane + (int64_t)y * gw + x0 + lane, rowv);
                     }
+                    publish(i, (uint32_t)y + 2u);
                 }
                 if (y < gh) { fill_plane(plane, (int64_t)y * gw, (int64_t)(gh - y) * gw, zero, lane); status |= ST_TRUNCATED; }
-                if (lane == 0) meta[i].decoded = 1;
+                if (lane == 0) st_agent(&meta[i].decoded, 1);
+                publish(i, (uint32_t)gh + 1u);
                 if (s_limit_hit(s)) break;
             }
             __syncthreads();
@@ -586,7 +637,8 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
             // corrupt_or_truncated(io, image.channel[beginc], ...): encoding.cpp:358
             if (s_limit_hit(s)) {
                 fill_plane(coef + geom[beginc].coef_off, 0, (int64_t)geom[beginc].w * geom[beginc].h, 0, lane);
-                if (lane == 0) meta[beginc].decoded = 1;
+                if (lane == 0) st_agent(&meta[beginc].decoded, 1);
+                publish(beginc, (uint32_t)rfl(geom[beginc].h) + 1u);
                 status |= ST_TRUNCATED;
                 continue;
             }
@@ -603,6 +655,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
         // are the ones that stay in LDS.
         const int nleaves = (tree_size + 1) / 2;
         int n_super = 1;
+        bool super_ok = true;
         {
             int32_t *slot_node = sh.cprops;        // [127] tree node behind every heap slot (cprops is idle here)
             int32_t *st_split = sh.cprops + 128;   // [64]
@@ -610,6 +663,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
             if (lane == 0) queue[0] = 0;
             __syncthreads();
             for (int sn = 0; sn < n_super; sn++) {
+                if (sn + 64 >= P.max_super) { super_ok = false; break; }
                 if (lane == 0) slot_node[0] = queue[sn];
                 st_split[lane] = 0x7FFFFFFF;
                 st_prop[lane] = 0;
@@ -645,6 +699,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                 __syncthreads();
             }
         }
+        if (!super_ok) { status |= ST_UNSUPPORTED | ST_CORRUPT; break; }
         const uint2 root_nd = snodes_g[lane];  // the root supernode lives in registers
         // FinalPropertySymbolCoder ctor: every leaf starts from SymbolChance(zero_chance) (compound.h:213-219)
         {
@@ -674,11 +729,12 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
         for (int i = beginc; i <= endc; i++) {
             const int w = rfl(geom[i].w), h = rfl(geom[i].h);
             const int ghs = rfl(geom[i].hshift), gvs = rfl(geom[i].vshift);
-            const int minv = rfl(meta[i].minval), maxv = rfl(meta[i].maxval);
+            const int minv = rfl(ld_agent(&meta[i].minval)), maxv = rfl(ld_agent(&meta[i].maxval));
             if (minv == maxv) continue;
             int32_t *plane = coef + geom[i].coef_off;
             const int zero = minv > 0 ? minv : (maxv < 0 ? maxv : 0);
             int y = 0;
+            uint32_t ref_seen = 0;  // lane k: last progress word seen for reference channel k
             if (tree_size == 1 && predictor == 0 && zero == 0) {
                 // fast track: encoding.cpp:371-383 (single leaf, no properties)
                 for (; y < h; y++) {
@@ -690,8 +746,9 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                             rowv = wrlane(leaf_symbol(rac, s, lane, L, minv, maxv), j, rowv);
                             leaf_commit(L, lane, pixel_table);
                         }
-                        if (lane < nx) plane[(int64_t)y * w + x0 + lane] = rowv;
+                        if (lane < nx) st_agent(plane + (int64_t)y * w + x0 + lane, rowv);
                     }
+                    publish(i, (uint32_t)y + 2u);
                 }
             } else {
                 // PRED0 = predictor 0 (all Squeeze residual / DCT coefficient channels): guess is a constant
@@ -700,6 +757,26 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                     for (; y < h; y++) {
                         if (s_limit_hit(s)) break;
                         __syncthreads();  // the previous row's stores are complete before it is re-read as `top`
+                        if (nrefs) {
+                            // the rows of the reference channels this row looks at must be final; they may be the
+                            // work of other tiles that are still running (lane k watches reference k)
+                            uint32_t need = 0;
+                            const uint32_t *fp = progress;
+                            if (lane < nrefs) {
+                                const RefChan rc = sh.refs[lane];
+                                int ry = (y << gvs) >> rc.vshift; if (ry >= rc.h) ry = rc.h - 1;
+                                need = (uint32_t)ry + 2u;
+                                fp = progress + rc.chan;
+                            }
+                            uint32_t spins = 0;
+                            while (__any(ref_seen < need) && !stalled) {
+                                if (ref_seen < need) ref_seen = ld_agent(fp);
+                                if (__any(ref_seen < need)) {
+                                    __builtin_amdgcn_s_sleep(8);
+                                    if (++spins > kSpinLimit) { stalled = true; status |= ST_STALLED | ST_CORRUPT; }
+                                }
+                            }
+                        }
                         const int32_t *row1 = plane + (int64_t)(y - 1) * w;
                         const int32_t *row2 = plane + (int64_t)(y - 2) * w;
                         // left / leftleft start as `zero`, which is exactly what the edge rules
@@ -735,7 +812,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                                         const RefChan rc = sh.refs[k];
                                         int ry = (y << gvs) >> rc.vshift; if (ry >= rc.h) ry = rc.h - 1;
                                         int rx = (x << ghs) >> rc.hshift; if (rx >= rc.w) rx = rc.w - 1;
-                                        const int v = coef[rc.off + (int64_t)ry * rc.w + rx];
+                                        const int v = ld_agent(coef + rc.off + (int64_t)ry * rc.w + rx);
                                         cp[2 * k] = iabs(v); cp[2 * k + 1] = slog(v);
                                     }
                                 }
@@ -823,37 +900,54 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                                 PROF_LAP(5);
                             }
                             PROF_START();
-                            if (lane < nx) plane[(int64_t)y * w + x0 + lane] = rowv;
+                            if (lane < nx) st_agent(plane + (int64_t)y * w + x0 + lane, rowv);
                             __syncthreads();  // cprops is rewritten by the next chunk
                             PROF_LAP(6);
                         }
+                        publish(i, (uint32_t)y + 2u);
                     }
                 };
                 if (predictor == 0) rows(std::true_type{}); else rows(std::false_type{});
             }
             if (y < h) { __syncthreads(); fill_plane(plane, (int64_t)y * w, (int64_t)(h - y) * w, zero, lane); status |= ST_TRUNCATED; }
-            if (lane == 0) meta[i].decoded = 1;
+            if (lane == 0) st_agent(&meta[i].decoded, 1);
+            publish(i, (uint32_t)h + 1u);
             if (s_limit_hit(s)) break;
         }
         __syncthreads();
         ci = endc;
     }
     if (s_limit_hit(s)) status |= ST_TRUNCATED;
-    // planes the stream never reached read as zeros in the reference (empty Channel::data,
-    // image/image.h:82-85; zero-filled residuals, transform/squeeze.h:379-383)
+    // planes the tile never reached read as zeros in the reference (empty Channel::data,
+    // image/image.h:82-85; zero-filled residuals, transform/squeeze.h:379-383).  Every channel of
+    // the tile ends up published as final, whatever path led here: nobody waits for ever.
     __syncthreads();
-    for (int c = 0; c < nch; c++) {
+    for (int c = first_c; c <= last_c; c++) {
         const int gw = rfl(geom[c].w), gh = rfl(geom[c].h);
-        if ((int64_t)gw * gh > 0 && rfl(meta[c].decoded) == 0) fill_plane(coef + geom[c].coef_off, 0, (int64_t)gw * gh, 0, lane);
+        const uint32_t done = (uint32_t)gh + 1u;
+        if (rflu(ld_agent(progress + c)) != done) {
+            if ((int64_t)gw * gh > 0 && rfl(ld_agent(&meta[c].decoded)) == 0) fill_plane(coef + geom[c].coef_off, 0, (int64_t)gw * gh, 0, lane);
+            publish(c, done);
+        }
     }
-    if (lane == 0) { P.status[img] = status; P.consumed[img] = s.pos; }
+    if (lane == 0) { atomicOr(&P.status[img], status); atomicMax(&P.consumed[img], s.pos); }
 #ifdef FUIF_PROF
-    if (lane == 0 && P.prof) for (int k = 0; k < 8; k++) P.prof[(size_t)img * 8 + k] = prof_acc[k];
+    if (lane == 0 && P.prof) for (int k = 0; k < 8; k++) atomicAdd(&P.prof[(size_t)img * 8 + k], prof_acc[k]);
 #endif
+    __syncthreads();
+    }  // tile loop
 }
 
-void launch_maniac_decode(const DecodeParams &P, hipStream_t stream) {
-    hipLaunchKernelGGL(k_maniac_decode, dim3(P.n_images), dim3(64), 0, stream, P);
+int maniac_max_waves() {
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_maniac_decode, 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    return per_cu * prop.multiProcessorCount;
+}
+
+void launch_maniac_decode(const DecodeParams &P, int n_waves, hipStream_t stream) {
+    hipLaunchKernelGGL(k_maniac_decode, dim3(n_waves), dim3(64), 0, stream, P);
 }
 
 }  // namespace fuifgpu

@@ -35,6 +35,7 @@ extern "C" {
                                      (not an error, encoding/encoding.cpp:209-219) */
 #define FUIFGPU_ST_CORRUPT 2      /* the reference would return false */
 #define FUIFGPU_ST_UNSUPPORTED 4
+#define FUIFGPU_ST_STALLED 8 /* internal error: a group gave up waiting for rows of another group (always with CORRUPT) */
 
 typedef struct fuifgpu_plan fuifgpu_plan;    /* host: parsed header + channel table + inverse schedule */
 typedef struct fuifgpu_batch fuifgpu_batch;  /* device: buffers and state for N same-geometry images */
@@ -116,6 +117,27 @@ int fuifgpu_batch_last_timing(fuifgpu_batch *batch, float *decode_ms, float *tra
  * all zero in release builds */
 int fuifgpu_batch_profile(fuifgpu_batch *batch, uint64_t *out8_per_image);
 
+/* ---- group index (csrc/index.cpp) --------------------------------------
+ * A FUIF stream is a chain of channel groups (fuif_decode_channel, encoding/encoding.cpp:259-429),
+ * each with its own range coder, whose byte boundaries the encoder knows (encoding.cpp:525-527,542)
+ * but does not store.  The index stores them in a trailer BEHIND the stream
+ *     <stream> <payload> <u32 LE payload length> "FGIX"
+ *     payload = varint 1 ; varint n ; n x { varint channel delta ; varint byte-offset delta }
+ * which the reference decoder never reads (it stops after the last group, encoding.cpp:708-717):
+ * indexed files still decode with the unmodified reference.  fuifgpu_batch_upload() finds the
+ * trailer by itself and then decodes every group of every image on its own wavefront; streams
+ * without one are decoded one wavefront per image.  Ways to get an index: the writer below
+ * (emit_index), or decode once and keep fuifgpu_batch_group_index()'s result with the asset. */
+/* groups of the trailer of `blob` (n_groups = 0: none / not valid for this stream) */
+int fuifgpu_index_parse(const uint8_t *blob, size_t size, int32_t *first_channel, uint32_t *start, int cap, int *n_groups);
+/* copy of the stream with a trailer for the given groups (replaces an existing one); free with fuifgpu_free_blob */
+int fuifgpu_index_append(const uint8_t *blob, size_t size, const int32_t *first_channel, const uint32_t *start, int n_groups,
+                         uint8_t **blob_out, size_t *size_out);
+/* after a decode: the groups the entropy kernel went through for one image (any stream, indexed or not) */
+int fuifgpu_batch_group_index(fuifgpu_batch *batch, int image, int32_t *first_channel, uint32_t *start, int cap, int *n_groups);
+/* enable = 0: ignore trailers from the next upload on (A/B measurements; default 1) */
+int fuifgpu_batch_set_group_parallel(fuifgpu_batch *batch, int enable);
+
 /* ---- single-transform entry points on raw device planes (row-major int32) ------------------
  * These are what Transform::apply(image, true) (transform/transform.cpp:48-63) dispatches to;
  * the C++ boundary layer (fuif_amd/csrc/boundary) and the unit parity tests call them. */
@@ -146,7 +168,8 @@ typedef struct {
     int32_t max_properties; /* CLI default 12 (-E) */
     int32_t tree_mode;      /* 0 none, 1 learned */
     int32_t max_tree_nodes; /* cap for learned trees (<= 65535) */
-    int32_t reserved[3];
+    int32_t emit_index;     /* 1: append the group index trailer (see fuifgpu_index_*) */
+    int32_t reserved[2];
 } fuifgpu_encode_options;
 int fuifgpu_encode_image(const int32_t *planes, int w, int h, int nch, int bit_depth, const fuifgpu_encode_options *opt,
                          uint8_t **blob_out, size_t *size_out);

@@ -319,6 +319,7 @@ void fo_free(fo_image *img) {
     free(img->ch);
     for (int i = 0; i < img->ntr; i++) free(img->tr[i].params);
     free(img->tr);
+    free(img->group_start); free(img->group_channel);
     free(img);
 }
 
@@ -854,6 +855,12 @@ fo_image *fo_decode(const uint8_t *blob, size_t n, int preview, int io_kind, int
     for (int i = 0; i < img->nch; i++) {
         if ((preview < 0 || io_tell(&io) < btl) && !io_eof(&io)) {
             if (!img->ch[i].w || !img->ch[i].h) continue;
+            if (img->ngroups == img->groups_cap) {
+                img->groups_cap = img->groups_cap ? img->groups_cap * 2 : 64;
+                img->group_start = (uint32_t *)realloc(img->group_start, sizeof(uint32_t) * img->groups_cap);
+                img->group_channel = (int32_t *)realloc(img->group_channel, sizeof(int32_t) * img->groups_cap);
+            }
+            img->group_start[img->ngroups] = (uint32_t)io_tell(&io); img->group_channel[img->ngroups] = i; img->ngroups++;
             if (!decode_channel_group(&io, img, &i, btl)) { img->bytes_consumed = io_tell(&io); return img; }
         } else break;
     }
@@ -1224,6 +1231,10 @@ void fo_transform_info(fo_image *img, int t, int32_t *out, int cap) {
     const fo_transform *tr = &img->tr[t];
     out[0] = tr->id; out[1] = tr->nparams;
     for (int i = 0; i < tr->nparams && i + 2 < cap; i++) out[i + 2] = tr->params[i];
+}
+int fo_groups(fo_image *img, int32_t *first_channel, uint32_t *start, int cap) {
+    for (int g = 0; g < img->ngroups && g < cap; g++) { first_channel[g] = img->group_channel[g]; start[g] = img->group_start[g]; }
+    return img->ngroups;
 }
 void fo_stats(fo_image *img, uint64_t *out) {
     out[0] = img->stat_symbols; out[1] = img->stat_rac_decisions; out[2] = img->stat_tree_steps; out[3] = img->bytes_consumed;

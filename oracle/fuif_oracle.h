@@ -45,6 +45,8 @@ typedef struct {
     /* statistics (not in the reference): */
     uint64_t stat_symbols, stat_rac_decisions, stat_tree_steps;
     size_t bytes_consumed;
+    /* byte offset / first channel of every channel group, in stream order (test aid for the group index) */
+    uint32_t *group_start; int32_t *group_channel; int ngroups, groups_cap;
 } fo_image;
 
 /* io_kind 0: FileIO semantics (feof only after a failed read; what the CLI uses, fileio.h:55-63)
@@ -58,6 +60,7 @@ void fo_channel_info(fo_image *img, int c, int32_t *out12);
 void fo_channel_data(fo_image *img, int c, int32_t *out);
 void fo_transform_info(fo_image *img, int t, int32_t *out, int cap);
 void fo_stats(fo_image *img, uint64_t *out4);
+int fo_groups(fo_image *img, int32_t *first_channel, uint32_t *start, int cap);
 
 /* known-answer helpers for unit tests */
 void fo_build_table(uint16_t *table8192, uint32_t alpha, int cut);

@@ -93,6 +93,9 @@ class _Lib:
                 st = np.zeros(4, np.uint64)
                 self.lib.fo_stats(C.c_void_p(h), st.ctypes.data)
                 d.stats = dict(symbols=int(st[0]), rac_decisions=int(st[1]), tree_steps=int(st[2]), bytes=int(st[3]))
+                gc, gs = np.zeros(4096, np.int32), np.zeros(4096, np.uint32)
+                ng = self.lib.fo_groups(C.c_void_p(h), gc.ctypes.data, gs.ctypes.data, 4096)
+                d.groups = [(int(gc[i]), int(gs[i])) for i in range(min(ng, 4096))]
             return d
         finally:
             self._fn("free")(h)
@@ -132,6 +135,8 @@ class Port(_Lib):
         super().__init__(path)
         self.lib.fo_stats.restype = None
         self.lib.fo_stats.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.fo_groups.restype = C.c_int
+        self.lib.fo_groups.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
 
 
 class Ref(_Lib):

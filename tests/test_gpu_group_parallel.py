@@ -1,0 +1,139 @@
+"""GPU parity (-m gpu) of the one-wavefront-per-group path (group index, csrc/index.cpp).
+
+The same stream is decoded (a) one wavefront per image and (b) one wavefront per channel group with
+the tiles of an image chasing each other row by row; (b) must be bit-identical to (a), to the
+golden vectors of the real reference and to the oracle -- planes, channel ranges, status and bytes
+consumed -- for reference-written files indexed after the fact, for files the product's writer
+indexed itself, for previews, for mixed batches and when there are far more tiles than resident
+wavefronts."""
+import numpy as np
+import pytest
+
+from conftest import all_cases, golden_blob, plane_hash
+from fuif_amd.synth import photographic
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(gpulib, blobs, preview=-1, parallel=True):
+    plan = gpulib.Plan(blobs[0])
+    batch = gpulib.Batch(plan, len(blobs), sum(len(b) for b in blobs))
+    try:
+        batch.set_group_parallel(parallel)
+        batch.upload(blobs, preview)
+        batch.decode()
+        batch.sync()
+        st, used = batch.status()
+        pre = [batch.coef_planes(i) for i in range(len(blobs))]
+        meta = [batch.channel_meta(i) for i in range(len(blobs))]
+        groups = [batch.group_index(i) for i in range(len(blobs))]
+        batch.undo_transforms()
+        batch.sync()
+        post = [batch.out_planes(i) for i in range(len(blobs))]
+        return dict(pre=pre, meta=meta, post=post, st=[int(x) for x in st], used=[int(x) for x in used], groups=groups)
+    finally:
+        batch.close()
+
+
+def _same(a, b, i=0, j=0):
+    return (all(np.array_equal(x, y) for x, y in zip(a["pre"][i], b["pre"][j])) and
+            all(np.array_equal(x, y) for x, y in zip(a["post"][i], b["post"][j])) and
+            np.array_equal(a["meta"][i], b["meta"][j]) and a["st"][i] == b["st"][j])
+
+
+def test_reference_written_files_indexed_after_the_fact(gpulib, manifest, port):
+    """decode once sequentially, keep the group starts the kernel reports, append them as a trailer,
+    decode again group-parallel: identical to the first decode and to the golden hashes"""
+    failures = []
+    for e in manifest["fixtures"]:
+        c = e["cases"][0]
+        blob = golden_blob(e, c)
+        seq = _run(gpulib, [blob], parallel=False)
+        d = port.decode(blob, undo=False)
+        assert seq["groups"][0] == d.groups, e["name"]
+        indexed = gpulib.index_append(blob, seq["groups"][0])
+        par = _run(gpulib, [indexed])
+        if not _same(seq, par) or par["st"][0] != 0 or par["used"][0] != seq["used"][0]:
+            failures.append(e["name"])
+            continue
+        if [plane_hash(p) for p in par["post"][0]] != [x["sha256"] for x in c["post"]]:
+            failures.append(e["name"] + " (golden)")
+        if par["groups"][0] != seq["groups"][0]:
+            failures.append(e["name"] + " (groups)")
+    assert not failures, failures
+
+
+def test_previews_of_indexed_streams(gpulib, manifest):
+    for e, c in all_cases(manifest):
+        if not c["case"].startswith("preview"):
+            continue
+        full = golden_blob(e, e["cases"][0])
+        seq_full = _run(gpulib, [full], parallel=False)
+        indexed = gpulib.index_append(full, seq_full["groups"][0])
+        par = _run(gpulib, [indexed], preview=c["preview"])
+        assert [plane_hash(p) for p in par["post"][0]] == [x["sha256"] for x in c["post"]], (e["name"], c["case"])
+        seq = _run(gpulib, [full], preview=c["preview"], parallel=False)
+        assert _same(seq, par), (e["name"], c["case"])
+
+
+@pytest.mark.parametrize("w,h,c,bits,seed", [(512, 384, 3, 8, 40), (97, 61, 3, 8, 2), (160, 200, 4, 14, 41), (301, 47, 1, 8, 42)])
+def test_writer_indexed_streams_vs_oracle(gpulib, port, w, h, c, bits, seed):
+    img = photographic(w, h, c, bits, seed=seed)
+    blob = gpulib.encode_image(img, bits, tree_mode=1, index=True)
+    par = _run(gpulib, [blob])
+    assert par["st"][0] == 0
+    pre, post = port.decode_both(blob)
+    assert all(np.array_equal(g, ch["data"]) for g, ch in zip(par["pre"][0], pre.channels) if ch["size"])
+    assert all(np.array_equal(par["post"][0][i], img[i]) for i in range(c))
+    assert par["groups"][0] == gpulib.index_parse(blob)
+    assert par["used"][0] == port.decode(blob, undo=False).stats["bytes"]
+
+
+def test_mixed_batch_with_more_tiles_than_wavefronts(gpulib, port):
+    """indexed and plain streams of one geometry share a launch; 96 images x ~30 groups is several
+    times the number of resident wavefronts, so the persistent wavefronts walk the whole work list"""
+    imgs = [photographic(160, 120, 3, 8, seed=500 + k) for k in range(6)]
+    indexed = [gpulib.encode_image(im, 8, tree_mode=1, index=True) for im in imgs]
+    plain = [gpulib.encode_image(im, 8, tree_mode=1) for im in imgs]
+    blobs, want = [], []
+    for k in range(96):
+        src = (indexed if (k % 3) else plain)[k % 6]
+        blobs.append(src)
+        want.append(imgs[k % 6])
+    par = _run(gpulib, blobs)
+    assert par["st"] == [0] * len(blobs)
+    for k in range(len(blobs)):
+        assert all(np.array_equal(par["post"][k][i], want[k][i]) for i in range(3)), k
+    ngroups = {len(g) for g in par["groups"]}
+    assert len(ngroups) == 1 and ngroups.pop() > 20      # plain streams report their groups too
+
+
+def test_jpeg_like_indexed(gpulib, port):
+    from fuif_amd.jpeglike import encode_jpeg_like
+    img = photographic(136, 120, 3, 8, seed=77, sigma=1.0)
+    blob = encode_jpeg_like(img, 90, True, index=True)
+    seq = _run(gpulib, [blob], parallel=False)
+    par = _run(gpulib, [blob, blob, blob])
+    assert par["st"] == [0, 0, 0] and all(_same(seq, par, 0, k) for k in range(3))
+    pre, post = port.decode_both(blob)
+    assert all(np.array_equal(g, ch["data"]) for g, ch in zip(par["post"][0], post.channels))
+
+
+def test_truncated_indexed_stream_falls_back_and_side_index_on_truncated_blob(gpulib, port):
+    """cutting an indexed file removes the trailer: the stream decodes sequentially, as the reference
+    would; an index that points past the cut still gives the sequential result"""
+    img = photographic(128, 96, 3, 8, seed=9)
+    blob = gpulib.encode_image(img, 8, tree_mode=1, index=True)
+    groups = gpulib.index_parse(blob)
+    cut = blob[: groups[len(groups) // 2][1] + 7]
+    seq = _run(gpulib, [cut], parallel=False)
+    assert seq["st"][0] & 1
+    pre, post = port.decode_both(cut)
+    assert all(np.array_equal(g, ch["data"]) for g, ch in zip(seq["post"][0], post.channels))
+    part = [g for g in groups if g[1] < len(cut)]
+    par = _run(gpulib, [gpulib.index_append(cut, part)])
+    # the appended trailer makes the file longer: what the group that hits the cut reads next differs,
+    # so only the planes before it are comparable
+    k = len(part) - 1
+    first_cut_channel = part[k][0]
+    assert all(np.array_equal(a, b) for a, b in list(zip(seq["pre"][0], par["pre"][0]))[:first_cut_channel])
