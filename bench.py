@@ -51,16 +51,16 @@ def _encode_one(args):
     if kind == "dct420":
         from fuif_amd.jpeglike import encode_jpeg_like
         img = photographic(w, h, channels, bits, seed=seed, sigma=1.0)
-        return seed, encode_jpeg_like(img, 90, True)
+        return seed, encode_jpeg_like(img, 90, True, index=True)
     img = photographic(w, h, channels, bits, seed=seed)
-    return seed, fuif_amd.encode_image(img, bits, ycocg=(kind != "squeeze_raw"), tree_mode=1)
+    return seed, fuif_amd.encode_image(img, bits, ycocg=(kind != "squeeze_raw"), tree_mode=1, index=True)
 
 
 def make_inputs(k, w, h, channels, bits, seed0, cache_dir, kind="squeeze"):
     """K distinct encoded streams (+ their seeds); cached on local disk inside one box session."""
     os.makedirs(cache_dir, exist_ok=True)
     jobs, blobs = [], {}
-    name = "synth_" + kind + "_%dx%dx%d_%dbit_seed%d.fuif"
+    name = "synth_idx_" + kind + "_%dx%dx%d_%dbit_seed%d.fuif"   # streams carry the group index trailer (csrc/index.cpp)
     for i in range(k):
         seed = seed0 + i
         path = os.path.join(cache_dir, name % (w, h, channels, bits, seed))
@@ -103,7 +103,7 @@ def cpu_baseline(blobs, w, h, budget_s=25.0):
             "sample": "%d of the bench's %dx%d streams, full decode (entropy + inverse transforms), 1 thread, %.1f s" % (n, w, h, t_total)}
 
 
-def pmc_traffic(batch):
+def pmc_traffic(batch, mode):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r*_pmc_traffic.json, collected with tools/collect_profiles.sh); None if no profile
     of this batch size exists."""
@@ -114,7 +114,7 @@ def pmc_traffic(batch):
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if d.get("kernel") == "k_maniac_decode" and d.get("batch") == batch:
+        if d.get("kernel") == "k_maniac_decode" and d.get("batch") == batch and d.get("mode", "images") == mode:
             best = d
     return None if best is None else int(best["traffic_bytes_per_launch"])
 
@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--distinct", type=int, default=8, help="K distinct images replicated to the batch")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2", help="c2 = BASELINE headline config (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-index", action="store_true", help="ignore the streams' group index: one wavefront per image for the timed steps")
+    ap.add_argument("--no-seq-compare", action="store_true", help="skip the extra one-wavefront-per-image step reported next to the headline")
     ap.add_argument("--cache", default=os.environ.get("FUIF_BENCH_CACHE", "/tmp/fuif_bench_cache"))
     args = ap.parse_args()
 
@@ -171,9 +173,11 @@ def main():
     out = torch.empty(args.batch * info.out_elems, dtype=torch.int32, device=dev)
     batch = fuif_amd.Batch(plan, args.batch, sum(len(b) for b in blobs), out_ptr=out.data_ptr())
     t0 = time.time()
+    batch.set_group_parallel(not args.no_index)
     batch.upload(blobs)
     batch.sync()
     t_upload = time.time() - t0
+    n_tiles = args.batch if args.no_index else sum(max(1, len(fuif_amd.index_parse(inputs[i % K][1]))) for i in range(args.batch))
 
     def step():
         batch.decode()
@@ -235,6 +239,24 @@ def main():
     value = total_px / 1e6 / elapsed
     ms_per_step = elapsed / args.steps * 1e3
 
+    # the same batch once more with the group index ignored (one wavefront per image, what a stream
+    # without the trailer gets): reported next to the headline, outside the timed region
+    seq = None
+    if world == 1 and not args.no_index and not args.no_seq_compare:
+        batch.set_group_parallel(False)
+        batch.upload(blobs)
+        batch.sync()
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        t_seq = time.perf_counter() - t0
+        d, t = batch.timing()
+        st2, _ = batch.status()
+        same = fd.plane_checksums(view)
+        seq = {"value": round(args.batch * W * H / 1e6 / t_seq, 3), "unit": "Mpixels/s", "ms_per_step": round(t_seq * 1e3, 3),
+               "entropy_kernel_ms": round(d, 3), "identical_output": bool(torch.equal(same, checks)) and not st2.any()}
+        ok = ok and seq["identical_output"]
+
     if rank == 0:
         S = sum(len(b) for b in blobs) / args.batch
         N = info.coef_elems
@@ -245,11 +267,11 @@ def main():
         t_avg = float(np.mean(tr_ms)) / 1e3
         achieved = alg_kernel / d_avg / 1e9
         roofline = {"bound": "hbm", "kernel": "k_maniac_decode", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(args.batch),
+                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(args.batch, "images" if args.no_index else "groups") if args.workload == "c2" else None,
                     "kernel_ms": round(d_avg * 1e3, 3), "algorithmic_bytes_per_launch": int(alg_kernel),
-                    "ns_per_symbol_per_stream": round(d_avg * 1e9 / N, 1),
-                    "note": "serial range decoder, one wavefront per stream: bound by instruction issue on the per-symbol "
-                            "dependency chain, not by HBM (DESIGN.md 4.1)",
+                    "tiles_per_launch": n_tiles,
+                    "note": "serial range decoders, one wavefront per channel group (4 per SIMD): bound by instruction issue on the "
+                            "per-symbol dependency chain and by the length of the largest group, not by HBM (DESIGN.md 4.1)",
                     "transforms": {"ms": round(t_avg * 1e3, 3), "achieved": round(args.batch * 4.0 * (N + P) / t_avg / 1e9, 1),
                                    "unit": "GB/s", "algorithmic_bytes": int(args.batch * 4.0 * (N + P))},
                     "path_bytes_per_image": int(S + 8.0 * N + 4.0 * P)}
@@ -259,9 +281,13 @@ def main():
                "config": {"workload": wl["desc"] % (args.batch, W, H),
                           "images_per_gpu": args.batch, "distinct_images": K, "bytes_per_stream": int(S),
                           "writer": "fuif_amd/csrc/writer.cpp learned trees", "parity_roundtrip_ok": ok,
+                          "group_index": "ignored (--no-index): one wavefront per image" if args.no_index else
+                                         "FGIX trailer behind each stream (csrc/index.cpp): one wavefront per channel group; the unmodified reference decodes the same files",
                           "parity_check": "decoded == source pixels for all images" if wl["lossless"] else "MSE vs source < 40 and all replicas identical (bit-exactness: tests -m gpu)",
                           "gather": "all_gather of per-image output checksums", "input_gen_s": round(t_gen, 1), "upload_s": round(t_upload, 3)},
                "roofline": roofline}
+        if seq is not None:
+            res["one_wavefront_per_image"] = seq
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline([b for _, b in inputs], W, H)
             res["speedup_vs_cpu_1thread"] = round(value / res["cpu_baseline"]["value"], 2)

@@ -82,6 +82,26 @@ ABI_SYMBOLS = [
 ]
 
 
+def _preload_hip_runtime():
+    """A process must hold ONE HIP runtime.  PyTorch-ROCm ships its own libamdhip64 with the SONAME of
+    /opt/rocm's; whichever is loaded first serves both, and with /opt/rocm's first torch's other bundled
+    libraries no longer match it (device discovery then fails in this library).  So when torch is
+    installed its copy is loaded first -- without importing torch."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load libfuifgpu.so; raises if the HIP extension was not built (no fallback)."""
     global _lib
@@ -90,6 +110,7 @@ def lib():
     if not os.path.exists(_LIB_PATH):
         raise ImportError("fuif_amd/libfuifgpu.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    _preload_hip_runtime()
     L = C.CDLL(_LIB_PATH)
     vp, i32p, u8p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
     L.fuifgpu_strerror.restype = C.c_char_p; L.fuifgpu_strerror.argtypes = [C.c_int]

@@ -39,8 +39,8 @@ struct fuifgpu_batch {
     uint8_t *d_scratch = nullptr;
     size_t scratch_stride = 0, bfs_off = 0, leaves_off = 0, stack_off = 0, queue_off = 0;
     int scratch_waves = 0;            // wavefronts d_scratch is sized for
-    int max_waves = 0;                // resident wavefronts the device holds (occupancy x CUs)
-    int n_waves = 0;                  // persistent wavefronts of the next decode launch
+    int max_waves[2] = {0, 0};        // resident wavefronts the device holds in the wide / dense kernel configuration
+    int n_waves = 0, dense = 0;       // persistent wavefronts and configuration of the next decode launch
     bool group_parallel = true;       // use group indices (index.cpp) when streams carry them
     Tile *d_tiles = nullptr;
     int tiles_cap = 0, n_tiles = 0;
@@ -72,17 +72,21 @@ static int hip_fail(hipError_t e, const char *what) {
     } while (0)
 
 namespace fuifgpu {
-// With M supernodes that have children (>= 6 inner nodes each, and >= k-1 for k children) and T
-// without (>= 1 each): inner >= 2T-1 and inner >= 6M+T, so M+T <= (7 inner + 5)/12 < 0.3 max_nodes.
-// The kernel checks the bound it is given.
-int maniac_max_supernodes(int max_nodes) { return (int)(((int64_t)max_nodes + 1) * 5 / 16 + 66); }
+// Supernodes a wavefront's scratch area holds.  A tree of n inner nodes needs at most (7n+5)/12 of them
+// (M supernodes with children hold >= 6 inner nodes each, T without hold >= 1: inner >= 2T-1 and
+// >= 6M+T); beyond kMaxSuper the kernel walks the remaining subtrees node by node, which keeps the
+// area at ~5 MB per wavefront instead of 13 MB for a case no encoder in sight produces.
+#ifndef FUIF_MAX_SUPER
+#define FUIF_MAX_SUPER 4096
+#endif
+int maniac_max_supernodes(int max_nodes) { return (int)std::min<int64_t>(FUIF_MAX_SUPER, ((int64_t)max_nodes + 1) * 5 / 16 + 66); }
 size_t maniac_scratch_bytes(int max_nodes, size_t *bfs_off, size_t *leaves_off, size_t *stack_off, size_t *queue_off) {
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     size_t nodes = up((size_t)(max_nodes + 1) * 8);
     size_t snodes = up((size_t)maniac_max_supernodes(max_nodes) * 512);
     size_t leaves = up((size_t)((max_nodes + 1) / 2 + 1) * kLeafStride * 2);
     size_t stack = up((size_t)kTreeStackDepth * 24);
-    size_t queue = up((size_t)(max_nodes + 1) * 4);
+    size_t queue = up((size_t)(maniac_max_supernodes(max_nodes) + 64) * 4);
     *bfs_off = nodes;
     *leaves_off = nodes + snodes;
     *stack_off = nodes + snodes + leaves;
@@ -211,8 +215,9 @@ int fuifgpu_batch_create(const fuifgpu_plan *plan, int n_images, size_t blob_cap
         CHK(hipMemcpy(b->d_tables, tables.data(), tables.size() * 2, hipMemcpyHostToDevice));
     }
     b->scratch_stride = maniac_scratch_bytes(b->max_nodes, &b->bfs_off, &b->leaves_off, &b->stack_off, &b->queue_off);
-    b->max_waves = maniac_max_waves();
-    if (b->max_waves < 1) { g_last_error = "cannot query the device occupancy of the entropy kernel"; fuifgpu_batch_destroy(b); return FUIFGPU_E_HIP; }
+    b->max_waves[0] = maniac_max_waves(0);
+    b->max_waves[1] = maniac_max_waves(1);
+    if (b->max_waves[0] < 1 || b->max_waves[1] < 1) { g_last_error = "cannot query the device occupancy of the entropy kernel"; fuifgpu_batch_destroy(b); return FUIFGPU_E_HIP; }
     CHK(hipMalloc((void **)&b->d_progress, sizeof(uint32_t) * (size_t)n_images * std::max(nch, 1)));
     CHK(hipMalloc((void **)&b->d_group_start, sizeof(uint32_t) * (size_t)n_images * std::max(nch, 1)));
     CHK(hipMalloc((void **)&b->d_queue_head, 256));
@@ -310,7 +315,9 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
     if (b->n_tiles) HIPCHK(hipMemcpyAsync(b->d_tiles, b->tiles.data(), sizeof(Tile) * (size_t)b->n_tiles, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));  // b->tiles / b->jobs may be rebuilt by the next upload
     // one persistent wavefront per tile up to what the device holds at once; each owns a scratch area
-    b->n_waves = std::max(1, std::min(b->n_tiles, b->max_waves));
+    // more tiles than the wide configuration has wavefronts: go dense (4 per SIMD)
+    b->dense = b->n_tiles > b->max_waves[0] ? 1 : 0;
+    b->n_waves = std::max(1, std::min(b->n_tiles, b->max_waves[b->dense]));
     if (b->n_waves > b->scratch_waves) {
         hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_waves = 0;
         HIPCHK(hipMalloc((void **)&b->d_scratch, b->scratch_stride * (size_t)b->n_waves));
@@ -339,7 +346,7 @@ int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
     P.stack_off = b->stack_off; P.queue_off = b->queue_off; P.max_properties = b->plan.max_properties; P.max_nodes = b->max_nodes; P.max_super = maniac_max_supernodes(b->max_nodes); P.prof = b->d_prof;
     P.tiles = b->d_tiles; P.n_tiles = b->n_tiles; P.queue_head = b->d_queue_head; P.progress = b->d_progress; P.group_start = b->d_group_start;
     HIPCHK(hipEventRecord(b->ev[0], st));
-    launch_maniac_decode(P, b->n_waves, st);
+    launch_maniac_decode(P, b->n_waves, b->dense, b->n_tiles > b->n_loaded ? 1 : 0, st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->ev[1], st));
     b->decode_timed = true;

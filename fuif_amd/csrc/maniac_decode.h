@@ -35,7 +35,9 @@ struct DecodeParams {
 
 int maniac_max_supernodes(int max_nodes);
 size_t maniac_scratch_bytes(int max_nodes, size_t *bfs_off, size_t *leaves_off, size_t *stack_off, size_t *queue_off);
-int maniac_max_waves();   // persistent wavefronts the device can hold at once (occupancy x CUs)
-void launch_maniac_decode(const DecodeParams &P, int n_waves, hipStream_t stream);
+// The kernel exists in two LDS configurations: wide (1 wavefront per SIMD, most of the context tree in
+// LDS) and dense (4 per SIMD).  maniac_max_waves = wavefronts the device holds at once in that configuration.
+int maniac_max_waves(int dense);
+void launch_maniac_decode(const DecodeParams &P, int n_waves, int dense, int hand_off, hipStream_t stream);
 
 }  // namespace fuifgpu

@@ -65,12 +65,34 @@ namespace {
 #endif
 
 constexpr int CH_ZERO = 0, CH_SIGN = 1, CH_EXP = 2, CH_MANT = 16, CH_N = 31;
-#ifndef FUIF_LDS_SUPER
-#define FUIF_LDS_SUPER 58
+// Supernodes (512 B each) of the context tree kept in LDS: the kernel is built twice.
+//   kLdsWide  : 29 KB of tree per wavefront, 1 wavefront per SIMD -- best when there are no more
+//               tiles than SIMDs (streams without a group index: one tile per image)
+//   kLdsDense : 1 KB of tree, 4 wavefronts per SIMD -- best when tiles abound (group index): the
+//               kernel is issue bound, co-resident wavefronts fill each other's stalls (measured
+//               1024 x 4K: 305 -> 470 Mpx/s) and hide the extra L2 trips of the deeper levels
+#ifndef FUIF_LDS_WIDE
+#define FUIF_LDS_WIDE 58
 #endif
-constexpr int kLdsSuper = FUIF_LDS_SUPER;  // 58 supernodes x 512 B = 29 KB of the context tree in LDS
+#ifndef FUIF_LDS_DENSE
+#define FUIF_LDS_DENSE 2
+#endif
+constexpr int kLdsWide = FUIF_LDS_WIDE, kLdsDense = FUIF_LDS_DENSE;
 constexpr uint32_t kLeafFlag = 0x800000u;
+constexpr uint32_t kSlowFlag = 0x400000u;   // exit leads to a plain tree node (index in the low 16 bits), not to a supernode
 constexpr int kPropPitch = 33;    // odd pitch: conflict-free column writes / row reads
+// Pixels whose properties are prepared at once (lane = pixel).  The property rows are the largest LDS
+// item; a shorter chunk buys resident wavefronts (the real lever of this kernel: it is issue bound).
+#ifndef FUIF_CHUNK
+#define FUIF_CHUNK 64
+#endif
+constexpr int kChunk = FUIF_CHUNK;
+static_assert(kChunk == 64 || kChunk == 32 || kChunk == 16, "chunk must divide the wavefront");
+#ifdef FUIF_WAVES
+#define FUIF_OCCUPANCY __attribute__((amdgpu_waves_per_eu(FUIF_WAVES, FUIF_WAVES)))
+#else
+#define FUIF_OCCUPANCY
+#endif
 
 DEV int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 DEV uint32_t rflu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -335,22 +357,35 @@ struct RefChan {  // one reference channel of the current group (context_predict
     int32_t chan, pad;
 };
 
+template <int kLdsSuper>
 struct Shared {
     uint2 snodes[kLdsSuper * 64];        // breadth-first top of the supernode tree: lane i = {split_i, prop_i | exit_i << 8}
-    int32_t cprops[64 * kPropPitch];     // [pixel of the chunk][property]
+    int32_t cprops[kChunk * kPropPitch]; // [pixel of the chunk][property]
     uint16_t meta_ctx[3][32];            // three SimpleSymbolCoder contexts of the tree coder
     int32_t lo[kMaxProps], hi[kMaxProps];
     RefChan refs[kMaxRefs];
 };
 
+// kHandOff = false: every image is one tile, nothing a tile writes is read by another one before the
+// kernel ends -- plain cached stores and loads (write-through stores drop the line from L2, and the
+// decoder re-reads its own previous rows: ~4 % on a whole-stream decode)
+template <bool kHandOff>
+DEV void st_plane(int32_t *p, int v) {
+    if (kHandOff) st_agent(p, v);
+    else *p = v;
+}
+template <bool kHandOff>
+DEV int ld_plane(const int32_t *p) { return kHandOff ? ld_agent(p) : *p; }
+template <bool kHandOff>
 DEV void fill_plane(int32_t *plane, int64_t first, int64_t count, int v, int lane) {
-    for (int64_t i = first + lane; i < first + count; i += 64) st_agent(plane + i, v);
+    for (int64_t i = first + lane; i < first + count; i += 64) st_plane<kHandOff>(plane + i, v);
 }
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
-    __shared__ Shared sh;
+template <int kLdsSuper, bool kHandOff>
+__global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParams P) {
+    __shared__ Shared<kLdsSuper> sh;
     const int lane = threadIdx.x;
 
     const uint16_t *tree_table = P.tables;          // cut 2, alpha 0xFFFFFFFF/19 (compound.h:262)
@@ -407,7 +442,9 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
     bool stalled = false;
     PROF_DECL;
     // progress word of channel c: 1 = ChannelMeta valid, 1 + r = rows [0,r) final, 1 + h = plane final
-    auto publish = [&](int c, uint32_t v) { drain_stores(); if (lane == 0) st_agent(progress + c, v); };
+    auto publish = [&](int c, uint32_t v) {
+        if (kHandOff) { drain_stores(); if (lane == 0) st_agent(progress + c, v); }
+    };
     auto wait_header = [&](int c) {
         uint32_t spins = 0;
         while (!stalled && rflu(ld_agent(progress + c)) == 0u) {
@@ -452,7 +489,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
             }
             int q = 1;
             if (minv == maxv) {
-                fill_plane(coef + goff, 0, (int64_t)gw * gh, minv, lane);
+                fill_plane<kHandOff>(coef + goff, 0, (int64_t)gw * gh, minv, lane);
                 firstrealc++;
             }
             bool have_q = !(minv == 0 && maxv == 0);
@@ -461,7 +498,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
             publish(i, (minv == maxv) ? (uint32_t)gh + 1u : 1u);  // header known (constant planes are already final)
             if (!have_q) continue;
             if (s_limit_hit(s)) {  // corrupt_or_truncated: encoding.cpp:209-219 (isEOF or limit => zero-fill, true)
-                fill_plane(coef + goff, 0, (int64_t)gw * gh, 0, lane);
+                fill_plane<kHandOff>(coef + goff, 0, (int64_t)gw * gh, 0, lane);
                 if (lane == 0) st_agent(&meta[i].decoded, 1);
                 publish(i, (uint32_t)gh + 1u);
                 status |= ST_TRUNCATED;
@@ -537,7 +574,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
             int rounded = s_varint(s, lane);
             if (rounded < 1 || rounded > 127) {
                 if (s_limit_hit(s)) {
-                    fill_plane(coef + geom[firstrealc].coef_off, 0, (int64_t)geom[firstrealc].w * geom[firstrealc].h, 0, lane);
+                    fill_plane<kHandOff>(coef + geom[firstrealc].coef_off, 0, (int64_t)geom[firstrealc].w * geom[firstrealc].h, 0, lane);
                     if (lane == 0) st_agent(&meta[firstrealc].decoded, 1);
                     publish(firstrealc, (uint32_t)rfl(geom[firstrealc].h) + 1u);
                     status |= ST_TRUNCATED;
@@ -567,11 +604,11 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                         const int nx = min(64, gw - x0);
                         int rowv = 0;
                         for (int j = 0; j < nx; j++) rowv = wrlane(uniform_read(rac, s, lane, minv, maxv - minv), j, rowv);
-                        if (lane < nx) st_agent(plane + (int64_t)y * gw + x0 + lane, rowv);
+                        if (lane < nx) st_plane<kHandOff>(plane + (int64_t)y * gw + x0 + lane, rowv);
                     }
                     publish(i, (uint32_t)y + 2u);
                 }
-                if (y < gh) { fill_plane(plane, (int64_t)y * gw, (int64_t)(gh - y) * gw, zero, lane); status |= ST_TRUNCATED; }
+                if (y < gh) { fill_plane<kHandOff>(plane, (int64_t)y * gw, (int64_t)(gh - y) * gw, zero, lane); status |= ST_TRUNCATED; }
                 if (lane == 0) st_agent(&meta[i].decoded, 1);
                 publish(i, (uint32_t)gh + 1u);
                 if (s_limit_hit(s)) break;
@@ -636,7 +673,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
         if (!tree_ok) {
             // corrupt_or_truncated(io, image.channel[beginc], ...): encoding.cpp:358
             if (s_limit_hit(s)) {
-                fill_plane(coef + geom[beginc].coef_off, 0, (int64_t)geom[beginc].w * geom[beginc].h, 0, lane);
+                fill_plane<kHandOff>(coef + geom[beginc].coef_off, 0, (int64_t)geom[beginc].w * geom[beginc].h, 0, lane);
                 if (lane == 0) st_agent(&meta[beginc].decoded, 1);
                 publish(beginc, (uint32_t)rfl(geom[beginc].h) + 1u);
                 status |= ST_TRUNCATED;
@@ -655,7 +692,6 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
         // are the ones that stay in LDS.
         const int nleaves = (tree_size + 1) / 2;
         int n_super = 1;
-        bool super_ok = true;
         {
             int32_t *slot_node = sh.cprops;        // [127] tree node behind every heap slot (cprops is idle here)
             int32_t *st_split = sh.cprops + 128;   // [64]
@@ -663,7 +699,6 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
             if (lane == 0) queue[0] = 0;
             __syncthreads();
             for (int sn = 0; sn < n_super; sn++) {
-                if (sn + 64 >= P.max_super) { super_ok = false; break; }
                 if (lane == 0) slot_node[0] = queue[sn];
                 st_split[lane] = 0x7FFFFFFF;
                 st_prop[lane] = 0;
@@ -688,9 +723,13 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                 const unsigned long long im = __ballot(inner);
                 const int rank = __popcll(im & ((1ull << lane) - 1ull));
                 uint32_t tgt;
-                if (inner) { tgt = (uint32_t)(n_super + rank); queue[n_super + rank] = t; }
+                // The scratch area holds P.max_super supernodes.  Subtrees beyond that (only trees with tens of
+                // thousands of nodes get there) are walked node by node from the parse-order array instead.
+                const bool admit = inner && (n_super + rank < P.max_super);
+                if (admit) { tgt = (uint32_t)(n_super + rank); queue[n_super + rank] = t; }
+                else if (inner) tgt = kSlowFlag | (uint32_t)t;
                 else tgt = kLeafFlag | (uint32_t)n.child;
-                n_super += __popcll(im);
+                n_super += __popcll(__ballot(admit));
                 uint2 out;
                 out.x = (uint32_t)st_split[lane];
                 out.y = ((uint32_t)st_prop[lane] & 0xFFu) | (tgt << 8);
@@ -699,7 +738,6 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                 __syncthreads();
             }
         }
-        if (!super_ok) { status |= ST_UNSUPPORTED | ST_CORRUPT; break; }
         const uint2 root_nd = snodes_g[lane];  // the root supernode lives in registers
         // FinalPropertySymbolCoder ctor: every leaf starts from SymbolChance(zero_chance) (compound.h:213-219)
         {
@@ -746,7 +784,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                             rowv = wrlane(leaf_symbol(rac, s, lane, L, minv, maxv), j, rowv);
                             leaf_commit(L, lane, pixel_table);
                         }
-                        if (lane < nx) st_agent(plane + (int64_t)y * w + x0 + lane, rowv);
+                        if (lane < nx) st_plane<kHandOff>(plane + (int64_t)y * w + x0 + lane, rowv);
                     }
                     publish(i, (uint32_t)y + 2u);
                 }
@@ -757,7 +795,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                     for (; y < h; y++) {
                         if (s_limit_hit(s)) break;
                         __syncthreads();  // the previous row's stores are complete before it is re-read as `top`
-                        if (nrefs) {
+                        if (kHandOff && nrefs) {
                             // the rows of the reference channels this row looks at must be final; they may be the
                             // work of other tiles that are still running (lane k watches reference k)
                             uint32_t need = 0;
@@ -794,8 +832,8 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                         const bool f_patch = f_abs | f_slog | (kloc == 6) | (kloc == 7);
                         const bool f_l12 = (kloc == 12);
                         const bool f_lcoef = (kloc == 1) | (kloc == 3) | (kloc == 12) | (y ? ((kloc == 6) | (kloc == 8)) : ((kloc == 7) | (kloc == 9)));
-                        for (int x0 = 0; x0 < w; x0 += 64) {
-                            const int nx = min(64, w - x0);
+                        for (int x0 = 0; x0 < w; x0 += kChunk) {
+                            const int nx = min(kChunk, w - x0);
                             // ---- vector phase: lane j prepares pixel x0+j ------------------------
                             PROF_START();
                             const int x = min(x0 + lane, w - 1);
@@ -803,7 +841,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                             const int vtl = (y && x) ? row1[x - 1] : zero;                 // x == 0: topleft = left = zero
                             const int vtr = (x + 1 < w && y) ? row1[x + 1] : vtop;         // context_predict.h:129
                             const int vtt = y > 1 ? row2[x] : vtop;                        // :133
-                            {
+                            if (kChunk == 64 || lane < kChunk) {
                                 int32_t *cp = sh.cprops + lane * kPropPitch;
 #pragma unroll
                                 for (int k = 0; k < kMaxRefs; k++) {
@@ -812,7 +850,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                                         const RefChan rc = sh.refs[k];
                                         int ry = (y << gvs) >> rc.vshift; if (ry >= rc.h) ry = rc.h - 1;
                                         int rx = (x << ghs) >> rc.hshift; if (rx >= rc.w) rx = rc.w - 1;
-                                        const int v = ld_agent(coef + rc.off + (int64_t)ry * rc.w + rx);
+                                        const int v = ld_plane<kHandOff>(coef + rc.off + (int64_t)ry * rc.w + rx);
                                         cp[2 * k] = iabs(v); cp[2 * k + 1] = slog(v);
                                     }
                                 }
@@ -877,7 +915,21 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                                         // (index clamped) and replaced in the rare deep case
                                         const uint32_t li = tgt < (uint32_t)kLdsSuper ? tgt : (uint32_t)(kLdsSuper - 1);
                                         uint2 nd = lds_load_node(lds_nodes_addr + li * 512u + (uint32_t)lane * 8u);
-                                        if (UNLIKELY(tgt >= (uint32_t)kLdsSuper)) nd = global_load_node(&snodes_g[(size_t)tgt * 64 + lane]);
+                                        if (UNLIKELY(tgt >= (uint32_t)kLdsSuper)) {
+                                            if (UNLIKELY(tgt & kSlowFlag)) {
+                                                // compound.h:142-153 as written: one node per step (lane p of pv holds property p)
+                                                int t = (int)(tgt & 0xFFFFu);
+                                                Node n = nodes[t];
+                                                while (n.property >= 0) {
+                                                    t = rdlane(pv, rfl((int)n.property)) > rfl(n.splitval) ? (int)n.child : (int)n.child + 1;
+                                                    t = rfl(t);
+                                                    n = nodes[t];
+                                                }
+                                                tgt = kLeafFlag | (uint32_t)rfl((int)n.child);
+                                                break;
+                                            }
+                                            nd = global_load_node(&snodes_g[(size_t)tgt * 64 + lane]);
+                                        }
                                         tgt = walk_round(nd);
                                     }
                                     const int leaf = (int)(tgt & (kLeafFlag - 1u));
@@ -900,7 +952,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                                 PROF_LAP(5);
                             }
                             PROF_START();
-                            if (lane < nx) st_agent(plane + (int64_t)y * w + x0 + lane, rowv);
+                            if (lane < nx) st_plane<kHandOff>(plane + (int64_t)y * w + x0 + lane, rowv);
                             __syncthreads();  // cprops is rewritten by the next chunk
                             PROF_LAP(6);
                         }
@@ -909,7 +961,7 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
                 };
                 if (predictor == 0) rows(std::true_type{}); else rows(std::false_type{});
             }
-            if (y < h) { __syncthreads(); fill_plane(plane, (int64_t)y * w, (int64_t)(h - y) * w, zero, lane); status |= ST_TRUNCATED; }
+            if (y < h) { __syncthreads(); fill_plane<kHandOff>(plane, (int64_t)y * w, (int64_t)(h - y) * w, zero, lane); status |= ST_TRUNCATED; }
             if (lane == 0) st_agent(&meta[i].decoded, 1);
             publish(i, (uint32_t)h + 1u);
             if (s_limit_hit(s)) break;
@@ -925,8 +977,8 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
     for (int c = first_c; c <= last_c; c++) {
         const int gw = rfl(geom[c].w), gh = rfl(geom[c].h);
         const uint32_t done = (uint32_t)gh + 1u;
-        if (rflu(ld_agent(progress + c)) != done) {
-            if ((int64_t)gw * gh > 0 && rfl(ld_agent(&meta[c].decoded)) == 0) fill_plane(coef + geom[c].coef_off, 0, (int64_t)gw * gh, 0, lane);
+        if (!kHandOff || rflu(ld_agent(progress + c)) != done) {
+            if ((int64_t)gw * gh > 0 && rfl(ld_agent(&meta[c].decoded)) == 0) fill_plane<kHandOff>(coef + geom[c].coef_off, 0, (int64_t)gw * gh, 0, lane);
             publish(c, done);
         }
     }
@@ -938,16 +990,21 @@ __global__ __launch_bounds__(64) void k_maniac_decode(DecodeParams P) {
     }  // tile loop
 }
 
-int maniac_max_waves() {
+int maniac_max_waves(int dense) {
     int dev = 0, per_cu = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_maniac_decode, 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    hipError_t e = dense ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_maniac_decode<kLdsDense, true>, 64, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_maniac_decode<kLdsWide, true>, 64, 0);
+    if (e != hipSuccess || per_cu < 1) per_cu = 1;
     return per_cu * prop.multiProcessorCount;
 }
 
-void launch_maniac_decode(const DecodeParams &P, int n_waves, hipStream_t stream) {
-    hipLaunchKernelGGL(k_maniac_decode, dim3(n_waves), dim3(64), 0, stream, P);
+// hand_off = 0 promises that no tile reads what another tile of the launch writes (one tile per image)
+void launch_maniac_decode(const DecodeParams &P, int n_waves, int dense, int hand_off, hipStream_t stream) {
+    if (dense) hipLaunchKernelGGL((k_maniac_decode<kLdsDense, true>), dim3(n_waves), dim3(64), 0, stream, P);
+    else if (hand_off) hipLaunchKernelGGL((k_maniac_decode<kLdsWide, true>), dim3(n_waves), dim3(64), 0, stream, P);
+    else hipLaunchKernelGGL((k_maniac_decode<kLdsWide, false>), dim3(n_waves), dim3(64), 0, stream, P);
 }
 
 }  // namespace fuifgpu

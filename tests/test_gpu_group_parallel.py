@@ -90,13 +90,13 @@ def test_writer_indexed_streams_vs_oracle(gpulib, port, w, h, c, bits, seed):
 
 
 def test_mixed_batch_with_more_tiles_than_wavefronts(gpulib, port):
-    """indexed and plain streams of one geometry share a launch; 96 images x ~30 groups is several
-    times the number of resident wavefronts, so the persistent wavefronts walk the whole work list"""
+    """indexed and plain streams of one geometry share a launch; 192 images x ~30 groups is more tiles
+    than the device holds wavefronts (4 per SIMD), so the persistent wavefronts walk the work list"""
     imgs = [photographic(160, 120, 3, 8, seed=500 + k) for k in range(6)]
     indexed = [gpulib.encode_image(im, 8, tree_mode=1, index=True) for im in imgs]
     plain = [gpulib.encode_image(im, 8, tree_mode=1) for im in imgs]
     blobs, want = [], []
-    for k in range(96):
+    for k in range(192):
         src = (indexed if (k % 3) else plain)[k % 6]
         blobs.append(src)
         want.append(imgs[k % 6])

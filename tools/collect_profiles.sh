@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-seq-compare"
 # 1) per-kernel time (same command shape as the default bench run)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH --steps 2 --warmup 1 > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 # 2) HBM traffic counters, one PMC pass each (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass)
