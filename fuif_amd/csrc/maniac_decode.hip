@@ -910,27 +910,26 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                         return (uint32_t)rdlane((int)nd.y, e) >> 8;
                                     };
                                     uint32_t tgt = walk_round(root_nd);
-                                    while (!(tgt & kLeafFlag)) {
+                                    while (!(tgt & (kLeafFlag | kSlowFlag))) {
                                         // LDS-resident supernodes are the common case; the load is issued unconditionally
                                         // (index clamped) and replaced in the rare deep case
                                         const uint32_t li = tgt < (uint32_t)kLdsSuper ? tgt : (uint32_t)(kLdsSuper - 1);
                                         uint2 nd = lds_load_node(lds_nodes_addr + li * 512u + (uint32_t)lane * 8u);
-                                        if (UNLIKELY(tgt >= (uint32_t)kLdsSuper)) {
-                                            if (UNLIKELY(tgt & kSlowFlag)) {
-                                                // compound.h:142-153 as written: one node per step (lane p of pv holds property p)
-                                                int t = (int)(tgt & 0xFFFFu);
-                                                Node n = nodes[t];
-                                                while (n.property >= 0) {
-                                                    t = rdlane(pv, rfl((int)n.property)) > rfl(n.splitval) ? (int)n.child : (int)n.child + 1;
-                                                    t = rfl(t);
-                                                    n = nodes[t];
-                                                }
-                                                tgt = kLeafFlag | (uint32_t)rfl((int)n.child);
-                                                break;
-                                            }
-                                            nd = global_load_node(&snodes_g[(size_t)tgt * 64 + lane]);
-                                        }
+                                        if (UNLIKELY(tgt >= (uint32_t)kLdsSuper)) nd = global_load_node(&snodes_g[(size_t)tgt * 64 + lane]);
                                         tgt = walk_round(nd);
+                                    }
+                                    if (UNLIKELY(tgt & kSlowFlag)) {
+                                        // beyond the supernode cap: compound.h:142-153 as written, one node per step
+                                        // (lane p of pv holds property p).  Kept OUT of the loop above: a second exit
+                                        // would make the structuriser add ~4 branches to every round.
+                                        int t = (int)(tgt & 0xFFFFu);
+                                        Node n = nodes[t];
+                                        while (n.property >= 0) {
+                                            t = rdlane(pv, rfl((int)n.property)) > rfl(n.splitval) ? (int)n.child : (int)n.child + 1;
+                                            t = rfl(t);
+                                            n = nodes[t];
+                                        }
+                                        tgt = kLeafFlag | (uint32_t)rfl((int)n.child);
                                     }
                                     const int leaf = (int)(tgt & (kLeafFlag - 1u));
                                     PROF_LAP(2);
