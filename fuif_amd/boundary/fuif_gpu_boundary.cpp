@@ -118,6 +118,12 @@ bool gpu_decode_bytes(const std::vector<uint8_t> &bytes, Image &image, const fui
         for (int k = 0; k < np && k < (int)params.size(); k++) tr.parameters.push_back(params[k]);
         image.transform.push_back(tr);
     }
+    // Image::nb_meta_channels / nb_channels as the Palette meta steps leave them (transform/palette.h:87-88)
+    for (const Transform &tr : image.transform)
+        if (tr.ID == TRANSFORM_PALETTE && tr.parameters.size() == 3) {
+            image.nb_meta_channels++;
+            image.nb_channels -= tr.parameters[1] - tr.parameters[0];
+        }
     image.error = false;
     registry()[&image] = std::move(res);
     return true;
@@ -180,6 +186,8 @@ void fuifgpu_boundary_undo_transforms(Image *self, int keep) {
         outch.push_back(ch);
     }
     self->channel = outch;
+    self->nb_meta_channels = 0;               // every Palette has been expanded again (palette.h:65-67)
+    self->nb_channels = (int)outch.size();
     self->transform.clear();
     registry().erase(self);
 }

@@ -58,6 +58,7 @@ struct PlaneInfo {
 struct LiveChannel {
     int plane;
     int w, h, hshift, vshift, hcshift, vcshift, component;
+    bool ctor_data;   // the reference's Channel owns w*h samples before any decoding (constructor planes: image.h:64-65)
 };
 
 struct ProtoOp {
@@ -155,9 +156,10 @@ struct Builder {
     std::vector<LiveChannel> live;
     std::vector<PlaneInfo> planes;
     std::vector<ProtoOp> ops;
-    int nb_meta = 0;  // no transform in scope creates meta channels
+    int nb_meta = 0;  // Image::nb_meta_channels (palettes live in front of the channel list)
+    int nbc = 0;      // Image::nb_channels: shrinks/grows with Palette (palette.h:88,66)
 
-    explicit Builder(Plan &p) : plan(p) {}
+    explicit Builder(Plan &p) : plan(p), nbc(p.nb_channels) {}
 
     bool fail(int code, const std::string &msg) {
         plan.error = code;
@@ -169,7 +171,7 @@ struct Builder {
     // transform/squeeze.h:266-321
     void default_squeeze(std::vector<int> &params) {
         params.clear();
-        int nb = plan.nb_channels;
+        int nb = nbc;
         int w = live[nb_meta].w, h = live[nb_meta].h;
         bool wide = w > h;
         if (nb > 2 && live[nb_meta + 1].w == w && live[nb_meta + 1].h == h) {
@@ -193,7 +195,7 @@ struct Builder {
             bool horizontal = params[i] & 1;
             bool in_place = !(params[i] & 2);
             int beginc = params[i + 1], endc = params[i + 2];
-            int offset = in_place ? endc + 1 : nb_meta + plan.nb_channels;
+            int offset = in_place ? endc + 1 : nb_meta + nbc;
             if (beginc < 0 || endc < beginc || endc >= (int)live.size() || offset > (int)live.size())
                 return fail(FUIFGPU_E_CORRUPT, "squeeze parameters address a missing channel");
             for (int c = beginc; c <= endc; c++) {
@@ -220,7 +222,7 @@ struct Builder {
 
     // transform/dct.h:209-246 (scan script dct.h:173-207: position p -> component p%nb, coefficient p/nb)
     bool meta_dct(std::vector<int> &params) {
-        if (params.empty()) params = {0, plan.nb_channels - 1};
+        if (params.empty()) params = {0, nbc - 1};
         if (params.size() < 2) return fail(FUIFGPU_E_CORRUPT, "DCT needs two parameters");
         int beginc = nb_meta + params[0], endc = nb_meta + params[1];
         int nb = endc - beginc + 1;
@@ -259,6 +261,36 @@ struct Builder {
         return true;
     }
 
+    // transform/palette.h:76-96
+    bool meta_palette(const std::vector<int> &params) {
+        if (params.size() != 3) return fail(FUIFGPU_E_CORRUPT, "Palette needs three parameters");
+        int begin_c = nb_meta + params[0], end_c = nb_meta + params[1];
+        if (begin_c < 0 || begin_c > end_c || end_c >= (int)live.size()) return fail(FUIFGPU_E_CORRUPT, "Palette channel range invalid");
+        int nb = end_c - begin_c + 1, nb_colors = params[2];
+        if (nb_colors < 0 || (int64_t)nb_colors * nb > (1LL << 28)) return fail(FUIFGPU_E_CORRUPT, "implausible palette size");
+        nb_meta++;
+        nbc -= nb - 1;
+        live.erase(live.begin() + begin_c + 1, live.begin() + end_c + 1);
+        LiveChannel pch{};
+        pch.plane = -1; pch.w = nb_colors; pch.h = nb; pch.hshift = -1; pch.component = -1; pch.ctor_data = true;
+        live.insert(live.begin(), pch);
+        return true;
+    }
+
+    // transform/approximate.h:62-78
+    static int approx_q(const std::vector<int> &params, int c) {
+        size_t k = (size_t)(c + 2 - params[0]);
+        return k < params.size() ? params[k] : params.back();
+    }
+    bool meta_approximate(const std::vector<int> &params) {
+        if (params.size() < 3) return fail(FUIFGPU_E_CORRUPT, "Approximate needs at least three parameters");
+        int nb = params[1] - params[0] + 1;
+        if (nb < 1 || params[0] < 0 || params[1] >= (int)live.size()) return fail(FUIFGPU_E_CORRUPT, "Approximate channel range invalid");
+        for (int c = params[0]; c <= params[1]; c++)
+            if (approx_q(params, c)) { LiveChannel copy = live[c]; copy.plane = -1; live.push_back(copy); }
+        return true;
+    }
+
     // ---- inverse schedule -------------------------------------------------------------------
     int new_plane(int w, int h, int qsrc, int birth) {
         PlaneInfo pi;
@@ -274,7 +306,7 @@ struct Builder {
             bool horizontal = params[i] & 1;
             bool in_place = !(params[i] & 2);
             int beginc = params[i + 1], endc = params[i + 2];
-            int offset = in_place ? endc + 1 : nb_meta + plan.nb_channels;
+            int offset = in_place ? endc + 1 : nb_meta + nbc;
             if (beginc < 0 || endc < beginc || offset + (endc - beginc) >= (int)live.size())
                 return fail(FUIFGPU_E_CORRUPT, "inverse squeeze: residual channels missing");
             for (int c = beginc; c <= endc; c++) {
@@ -321,7 +353,7 @@ struct Builder {
 
     // transform/dct.h:249-296
     bool inv_dct(std::vector<int> &params) {
-        if (params.empty()) params = {0, plan.nb_channels - 1};
+        if (params.empty()) params = {0, nbc - 1};
         int beginc = nb_meta + params[0], endc = nb_meta + params[1];
         int nb = endc - beginc + 1;
         int offset = (int)live.size() - 63 * nb;
@@ -387,7 +419,7 @@ struct Builder {
     bool inv_color(int kind) {
         // transform/ycocg.h:33-48 / ycbcr.h:33-47 preconditions
         int m = (kind == OP_YCOCG) ? nb_meta : 0;
-        int have = (kind == OP_YCOCG) ? plan.nb_channels : (int)live.size();
+        int have = (kind == OP_YCOCG) ? nbc : (int)live.size();
         if (have < 3 || (int)live.size() < m + 3) return fail(FUIFGPU_E_CORRUPT, "colour transform needs three channels");
         int w = live[m].w, h = live[m].h;
         if (live[m + 1].w < w || live[m + 1].h < h || live[m + 2].w < w || live[m + 2].h < h)
@@ -398,6 +430,69 @@ struct Builder {
         for (int k = 0; k < 3; k++) { op.src[k] = op.dst[k] = live[m + k].plane; touch(live[m + k].plane, idx); }
         op.p0 = w; op.p1 = h;
         ops.push_back(op);
+        return true;
+    }
+
+    // transform/palette.h:32-68: one gather per component; the index plane is replaced by component 0
+    bool inv_palette(const std::vector<int> &params) {
+        if (nb_meta < 1 || params.size() != 3) return fail(FUIFGPU_E_CORRUPT, "Palette transform without palette");
+        const LiveChannel pal = live[0];
+        int nb = pal.h;
+        int c0 = nb_meta + params[0];
+        if (c0 >= (int)live.size() || nb < 1) return fail(FUIFGPU_E_CORRUPT, "Palette transform with incorrect parameters");
+        const LiveChannel index = live[c0];
+        std::vector<int> outp(nb);
+        for (int c = 0; c < nb; c++) {
+            ProtoOp op;
+            op.kind = OP_PALETTE;
+            int idx = (int)ops.size();
+            op.src[0] = index.plane; op.src[1] = pal.plane;
+            op.p0 = c; op.p1 = pal.w;
+            op.dst[0] = new_plane(index.w, index.h, c == 0 ? planes[index.plane].qsrc : -1, idx);
+            touch(index.plane, idx); touch(pal.plane, idx);
+            ops.push_back(op);
+            outp[c] = op.dst[0];
+        }
+        live[c0].plane = outp[0];
+        for (int i = 1; i < nb; i++) {
+            // Channel(w,h,0,1) inserted at c0+1, then channel[c0+i] is labelled (palette.h:52-55): only the
+            // channel that ends up last carries a component
+            LiveChannel n{};
+            n.w = index.w; n.h = index.h; n.component = -1; n.ctor_data = true; n.plane = -1;
+            live.insert(live.begin() + c0 + 1, n);
+            live[c0 + i].component = params[0] + i;
+        }
+        for (int i = 1; i < nb; i++) live[c0 + i].plane = outp[i];
+        nbc += nb - 1;
+        nb_meta--;
+        live.erase(live.begin());
+        return true;
+    }
+
+    // transform/approximate.h:32-60
+    bool inv_approximate(const std::vector<int> &params) {
+        int beginc = params[0], endc = params[1];
+        int offset = (int)live.size() - (endc - beginc + 1);
+        for (int c = beginc; c <= endc; c++) if (!approx_q(params, c)) offset++;
+        if (beginc < 0 || endc < beginc || offset <= endc || offset > (int)live.size()) return fail(FUIFGPU_E_CORRUPT, "Approximate: remainder channels missing");
+        int i = 0;
+        for (int c = beginc; c <= endc; c++) {
+            int q = approx_q(params, c) + 1;
+            if (q == 1) continue;
+            LiveChannel &ch = live[c];
+            const LiveChannel &chr = live[offset + i];
+            i++;
+            if ((int64_t)ch.w * ch.h == 0) continue;
+            if (chr.w != ch.w || chr.h != ch.h) return fail(FUIFGPU_E_UNSUPPORTED, "Approximate: remainder geometry differs");
+            ProtoOp op;
+            op.kind = OP_APPROX;
+            int idx = (int)ops.size();
+            op.src[0] = op.dst[0] = ch.plane; op.src[1] = chr.plane;
+            op.p0 = q; op.p1 = chr.ctor_data ? 1 : 0;
+            touch(ch.plane, idx); touch(chr.plane, idx);
+            ops.push_back(op);
+        }
+        live.erase(live.begin() + offset, live.end());
         return true;
     }
 
@@ -463,7 +558,7 @@ struct Builder {
             bool range_ok = (lk == OP_YCBCR) || (lk == OP_YCOCG && plan.minval == 0);
             if (range_ok) continue;
             if (lw >= 0 && planes[pl].birth == lw &&
-                (lk == OP_HSQUEEZE || lk == OP_VSQUEEZE || lk == OP_IDCT || lk == OP_UPSAMPLE || lk == OP_COPY_CLAMP)) {
+                (lk == OP_HSQUEEZE || lk == OP_VSQUEEZE || lk == OP_IDCT || lk == OP_UPSAMPLE || lk == OP_COPY_CLAMP || lk == OP_PALETTE)) {
                 clamp_fused[lw] = 1;
             } else {
                 ProtoOp op;
@@ -587,7 +682,7 @@ int parse_and_plan(const uint8_t *blob, size_t n, Plan &plan) {
     Builder b(plan);
     for (int c = 0; c < plan.nb_channels; c++) {  // Image(w,h,maxval,nb_channels): image/image.h:117-122
         LiveChannel ch{};
-        ch.plane = -1; ch.w = plan.w; ch.h = plan.h; ch.component = c;
+        ch.plane = -1; ch.w = plan.w; ch.h = plan.h; ch.component = c; ch.ctor_data = true;
         b.live.push_back(ch);
     }
     int nb_transforms = io.varint();
@@ -607,6 +702,8 @@ int parse_and_plan(const uint8_t *blob, size_t n, Plan &plan) {
             case TR_SUBSAMPLE: ok = b.meta_subsample(t.params); break;
             case TR_DCT: ok = b.meta_dct(t.params); break;
             case TR_SQUEEZE: ok = b.meta_squeeze(t.params); break;
+            case TR_PALETTE: ok = b.meta_palette(t.params); break;
+            case TR_APPROXIMATE: ok = b.meta_approximate(t.params); break;
             default:
                 plan.error = FUIFGPU_E_UNSUPPORTED;
                 plan.message = "transform id " + std::to_string(t.id) + " is outside the MI355X hot-path scope";
@@ -650,6 +747,8 @@ int parse_and_plan(const uint8_t *blob, size_t n, Plan &plan) {
             case TR_SUBSAMPLE: ok = b.inv_subsample(t.params); break;
             case TR_YCOCG: ok = b.inv_color(OP_YCOCG); break;
             case TR_YCBCR: ok = b.inv_color(OP_YCBCR); break;
+            case TR_PALETTE: ok = b.inv_palette(t.params); break;
+            case TR_APPROXIMATE: ok = b.inv_approximate(t.params); break;
             default: ok = false; break;
         }
         if (!ok) return plan.error ? plan.error : (plan.error = FUIFGPU_E_CORRUPT);

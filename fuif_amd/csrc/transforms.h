@@ -12,7 +12,7 @@ struct Bases {
     int64_t stride[3];
 };
 
-void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, const ChannelMeta *meta, int n_channels, int img_first,
+void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMeta *meta, int n_channels, int img_first,
                int n_images, hipStream_t stream);
 
 }  // namespace fuifgpu

@@ -13,6 +13,8 @@
 //   k_idct8x8        transform/dct.h:88-107,282-291 FP64, reference summation order, no FMA
 //   k_upsample       transform/subsample.h:90-115  "fancy" 2x chroma upsampling
 //   k_clamp / k_copy_clamp   image/image.cpp:107-113
+//   k_inv_palette    transform/palette.h:57-64     gather through the decoded palette meta-channel
+//   k_inv_approx     transform/approximate.h:44-57 quotient * q + remainder, in place
 #include <hip/hip_runtime.h>
 
 #include "fuifgpu_internal.h"
@@ -202,6 +204,37 @@ __global__ __launch_bounds__(256) void k_clamp(Bases b, PlaneRef src, PlaneRef d
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = clampi(s[i], lo, hi);
 }
 
+// transform/palette.h:57-64: out(y,x) = palette(component, CLAMP(index(y,x), 0, colours-1)).  The palette is a
+// decoded meta-channel (colours x components samples); rows of it stay in L1/L2.
+__global__ __launch_bounds__(256) void k_inv_palette(Bases b, PlaneRef pidx, PlaneRef ppal, PlaneRef po, int component, int colours,
+                                                     int clamp, int lo, int hi) {
+    const int64_t n = (int64_t)po.w * po.h;
+    const int32_t *idx = plane_ptr(b, pidx, blockIdx.z);
+    const int32_t *pal = plane_ptr(b, ppal, blockIdx.z) + (int64_t)component * ppal.w;
+    int32_t *d = plane_ptr(b, po, blockIdx.z);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int v = colours > 0 ? pal[clampi(idx[i], 0, colours - 1)] : 0;   // an empty palette reads Channel::zero (image.h:82)
+        d[i] = clamp ? clampi(v, lo, hi) : v;
+    }
+}
+
+// transform/approximate.h:44-57: ch = ch*q + remainder.  A remainder channel the stream never reached has no
+// samples in the reference (`chr.data.size() == 0`, :49,54): then nothing is added and Channel::q keeps its
+// value; otherwise Channel::q is taken from the remainder (:50).  `decoded` is per image, so the q hand-over is
+// done here on the ChannelMeta the later k_dequant reads.
+__global__ __launch_bounds__(256) void k_inv_approx(Bases b, PlaneRef pc, PlaneRef pr, int q, int ctor_data, ChannelMeta *meta, int n_channels,
+                                                    int img_first) {
+    ChannelMeta *m = meta + (int64_t)(img_first + blockIdx.z) * n_channels;
+    const bool reached = pr.qsrc >= 0 && m[pr.qsrc].decoded != 0;
+    const bool have = reached || ctor_data;
+    const int64_t n = (int64_t)pc.w * pc.h;
+    int32_t *d = plane_ptr(b, pc, blockIdx.z);
+    const int32_t *r = plane_ptr(b, pr, blockIdx.z);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        d[i] = d[i] * q + (have ? r[i] : 0);
+    if (have && blockIdx.x == 0 && threadIdx.x == 0 && pc.qsrc >= 0 && pr.qsrc >= 0) m[pc.qsrc].q = reached ? m[pr.qsrc].q : 1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // transform/dct.h:60-77 -- the constants exactly as the reference prints them
 __constant__ double kDCT[64] = {
@@ -298,7 +331,7 @@ static inline dim3 grid1d(int64_t n, int block, int z, int y = 1) {
     return dim3((unsigned)g, (unsigned)y, (unsigned)z);
 }
 
-void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, const ChannelMeta *meta, int n_channels, int img_first,
+void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMeta *meta, int n_channels, int img_first,
                int n_images, hipStream_t stream) {
     switch (op.kind) {
         case OP_VSQUEEZE: {
@@ -341,6 +374,16 @@ void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, const Cha
         case OP_CLAMP:
             hipLaunchKernelGGL(k_clamp, grid1d((int64_t)op.dst[0].w * op.dst[0].h, 256, n_images), dim3(256), 0, stream, b, op.src[0], op.dst[0],
                                op.lo, op.hi);
+            break;
+        case OP_PALETTE:
+            if ((int64_t)op.dst[0].w * op.dst[0].h <= 0) break;
+            hipLaunchKernelGGL(k_inv_palette, grid1d((int64_t)op.dst[0].w * op.dst[0].h, 256, n_images), dim3(256), 0, stream, b, op.src[0],
+                               op.src[1], op.dst[0], op.p0, op.p1, op.clamp_out, op.lo, op.hi);
+            break;
+        case OP_APPROX:
+            if (!meta || (int64_t)op.dst[0].w * op.dst[0].h <= 0) break;
+            hipLaunchKernelGGL(k_inv_approx, grid1d((int64_t)op.dst[0].w * op.dst[0].h, 256, n_images), dim3(256), 0, stream, b, op.src[0],
+                               op.src[1], op.p0, op.p1, meta, n_channels, img_first);
             break;
         default:
             break;

@@ -34,6 +34,28 @@ def photographic(w, h, channels=3, bits=8, seed=1, sigma=None):
     return out
 
 
+def graphic(w, h, channels=3, bits=8, seed=1, colors=32, step=1):
+    """Seeded "screen content": a few dozen flat colours in overlapping rectangles and diagonal bands
+    (what makes the reference CLI choose its Palette transform, transform/palette.h).  colors = size of the
+    colour set; step > 1 additionally restricts every sample to multiples of `step` (sparse channel histograms:
+    the per-channel palette heuristic of fuif.cpp:413-427)."""
+    rng = np.random.default_rng(seed)
+    maxval = (1 << bits) - 1
+    table = rng.integers(0, maxval // step + 1, size=(colors, channels)) * step
+    idx = np.zeros((h, w), dtype=np.int64)
+    for _ in range(3 * colors):
+        x0, y0 = int(rng.integers(0, w)), int(rng.integers(0, h))
+        x1, y1 = min(w, x0 + int(rng.integers(2, max(3, w // 2)))), min(h, y0 + int(rng.integers(2, max(3, h // 2))))
+        idx[y0:y1, x0:x1] = int(rng.integers(0, colors))
+    yy, xx = np.mgrid[0:h, 0:w]
+    band = ((xx + 2 * yy) // 7) % 11 == 0
+    idx[band] = (idx[band] + 1) % colors
+    out = np.empty((channels, h, w), dtype=np.int32)
+    for c in range(channels):
+        out[c] = table[idx, c]
+    return out
+
+
 def write_pnm(path, planes, maxval=255):
     """planes: (C,H,W) int32 -> P5/P6/P7 file readable by the reference's import/read_pam.h."""
     c, h, w = planes.shape

@@ -28,7 +28,9 @@
 #define TR_SUBSAMPLE 3
 #define TR_DCT 4
 #define TR_QUANTIZE 5
+#define TR_PALETTE 6
 #define TR_SQUEEZE 7
+#define TR_APPROXIMATE 10
 
 #define CLAMPI(x, l, u) ((x) < (l) ? (l) : ((x) > (u) ? (u) : (x)))
 
@@ -456,6 +458,50 @@ static int meta_subsample(fo_image *img, const fo_transform *t) {
     return ok;
 }
 
+/* Channel(w,h,min,max): image/image.h:64-65 -- data(w*h,0) is kept virtual (data==NULL, size=w*h) */
+static void ch_ctor(fo_channel *c, int w, int h, int minval, int maxval) {
+    ch_init(c);
+    c->w = w; c->h = h; c->minval = minval; c->maxval = maxval; ch_setzero(c);
+    c->size = (size_t)w * (size_t)h; c->data = NULL;
+}
+/* transform/palette.h:76-96 */
+static int meta_palette(fo_image *img, const fo_transform *t) {
+    if (t->nparams != 3) return 0;
+    int begin_c = img->nb_meta_channels + t->params[0];
+    int end_c = img->nb_meta_channels + t->params[1];
+    if (begin_c > end_c || end_c >= img->nch || begin_c < 0) return 0;
+    int nb = end_c - begin_c + 1;
+    int nb_colors = t->params[2];
+    if (nb_colors < 0 || (int64_t)nb_colors * nb > ((int64_t)1 << 28)) return 0; /* the reference would try to allocate this */
+    img->nb_meta_channels++;
+    img->nb_channels -= nb - 1;
+    img_erase_channels(img, begin_c + 1, nb - 1);
+    fo_channel pch; ch_ctor(&pch, nb_colors, nb, 0, 1);
+    pch.hshift = -1;
+    img_insert_channel(img, 0, &pch);
+    return 1;
+}
+/* transform/approximate.h:62-78 */
+static int approx_q(const fo_transform *t, int c) {
+    int k = c + 2 - t->params[0];
+    return k < t->nparams ? t->params[k] : t->params[t->nparams - 1];
+}
+static int meta_approximate(fo_image *img, const fo_transform *t) {
+    if (t->nparams < 3) return 0;
+    int nb = t->params[1] - t->params[0] + 1;
+    if (nb < 1 || t->params[0] < 0 || t->params[1] >= img->nch) return 0;
+    for (int c = t->params[0]; c <= t->params[1]; c++) {
+        if (!approx_q(t, c)) continue;
+        fo_channel copy = img->ch[c];   /* image.channel.push_back(image.channel[c]) */
+        if (copy.data) {
+            copy.data = (int32_t *)malloc(sizeof(int32_t) * (copy.size ? copy.size : 1));
+            memcpy(copy.data, img->ch[c].data, sizeof(int32_t) * copy.size);
+        }
+        img_insert_channel(img, img->nch, &copy);
+    }
+    return 1;
+}
+
 /* transform/transform.h:85-102 */
 static int tr_has_parameters(int id) {
     switch (id) { case 3: case 6: case 7: case 4: case 8: case 9: case 10: return 1; default: return 0; }
@@ -467,7 +513,9 @@ static int meta_apply(fo_image *img, fo_transform *t) {
         case TR_SUBSAMPLE: return meta_subsample(img, t);
         case TR_DCT: return meta_dct(img, t);
         case TR_SQUEEZE: return meta_squeeze(img, t);
-        default: return -1;
+        case TR_PALETTE: return meta_palette(img, t);
+        case TR_APPROXIMATE: return meta_approximate(img, t);
+        default: return -1;   /* 2D match (8), permute (9): not on the path this oracle restates */
     }
 }
 
@@ -1180,6 +1228,66 @@ static int inv_subsample(fo_image *img, const fo_transform *t) {
 }
 
 /* transform/transform.cpp:48-63 (inverse) */
+/* transform/palette.h:32-68 */
+static int inv_palette(fo_image *img, const fo_transform *t) {
+    if (img->nb_meta_channels < 1 || t->nparams != 3) return 0;
+    int nb = img->ch[0].h;
+    int c0 = img->nb_meta_channels + t->params[0];
+    if (c0 >= img->nch) return 0;
+    int w = img->ch[c0].w, h = img->ch[c0].h;
+    for (int i = 1; i < nb; i++) {
+        /* palette.h:52-55: every new channel is inserted at c0+1 and THEN channel[c0+i] is labelled, so the
+         * label lands on the channel inserted first each time: only position c0+nb-1 ends up with a component */
+        fo_channel n; ch_ctor(&n, w, h, 0, 1);
+        ch_materialize(&n);
+        img_insert_channel(img, c0 + 1, &n);
+        img->ch[c0 + i].component = t->params[0] + i;
+    }
+    const fo_channel *pal = &img->ch[0];
+    fo_channel *idx = &img->ch[c0];
+    ch_materialize(idx);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int index = ch_value(idx, y, x);
+            index = CLAMPI(index, 0, pal->w - 1);
+            for (int c = 0; c < nb; c++) {
+                fo_channel *o = &img->ch[c0 + c];
+                size_t at = (size_t)y * o->w + x;
+                if (at < o->size) o->data[at] = ch_value(pal, c, index);   /* value(r,c) = ...: out-of-range stores hit `zero` */
+            }
+        }
+    img->nb_channels += nb - 1;
+    img->nb_meta_channels--;
+    img_erase_channels(img, 0, 1);
+    return 1;
+}
+/* transform/approximate.h:32-60 */
+static int inv_approximate(fo_image *img, const fo_transform *t) {
+    int beginc = t->params[0], endc = t->params[1];
+    int offset = img->nch - (endc - beginc + 1);
+    for (int c = beginc; c <= endc; c++) if (!approx_q(t, c)) offset++;
+    if (beginc < 0 || endc < beginc || offset <= endc || offset > img->nch) return 0;
+    int i = 0;
+    for (int c = beginc; c <= endc; c++) {
+        int q = approx_q(t, c) + 1;
+        if (q == 1) continue;
+        fo_channel *ch = &img->ch[c];
+        const fo_channel *chr = &img->ch[offset + i];
+        i++;
+        int have = chr->size != 0;
+        if (have) ch->q = chr->q;
+        ch_materialize(ch);
+        for (int y = 0; y < ch->h; y++)
+            for (int x = 0; x < ch->w; x++) {
+                size_t at = (size_t)y * ch->w + x;
+                if (at >= ch->size) continue;
+                ch->data[at] = ch->data[at] * q + (have ? ch_value(chr, y, x) : 0);
+            }
+    }
+    img_erase_channels(img, offset, img->nch - offset);
+    return 1;
+}
+
 static int tr_apply_inverse(fo_image *img, fo_transform *t) {
     switch (t->id) {
         case TR_YCBCR: return inv_ycbcr(img);
@@ -1188,6 +1296,8 @@ static int tr_apply_inverse(fo_image *img, fo_transform *t) {
         case TR_QUANTIZE: return inv_quantize(img);
         case TR_YCOCG: return inv_ycocg(img);
         case TR_SQUEEZE: return inv_squeeze(img, t);
+        case TR_PALETTE: return inv_palette(img, t);
+        case TR_APPROXIMATE: return inv_approximate(img, t);
         default: return 0;
     }
 }

@@ -22,7 +22,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
-from fuif_amd.synth import photographic, write_pnm  # noqa: E402
+from fuif_amd.synth import graphic, photographic, write_pnm  # noqa: E402
 from oracle_py import Ref, run_ref_cli  # noqa: E402
 
 
@@ -54,6 +54,17 @@ SPECS = [
     ("rgb8_tall_40x200", dict(w=40, h=200, channels=3, bits=8, seed=10), []),
     ("rgb8_smooth_256x256", dict(w=256, h=256, channels=3, bits=8, seed=11, sigma=0.0), []),
 ]
+# screen content / sparse histograms with DEFAULT CLI flags: the reference picks Palette (transform/palette.h)
+# by itself (fuif.cpp:399-427); -A k,q adds Approximate (transform/approximate.h) on the last k channels
+GRAPHIC_SPECS = [
+    ("pal_rgb_graphic_120x90", dict(w=120, h=90, channels=3, bits=8, seed=31, colors=40), []),
+    ("pal_rgba_graphic_72x64", dict(w=72, h=64, channels=4, bits=8, seed=32, colors=20), []),
+    ("pal_gray_sparse_100x70", dict(w=100, h=70, channels=1, bits=8, seed=33, colors=24, step=5), []),
+    ("pal_rgb_sparse_128x96", dict(w=128, h=96, channels=3, bits=8, seed=34, colors=700, step=8), []),
+    ("pal_rgb_graphic_nosqueeze_64x48", dict(w=64, h=48, channels=3, bits=8, seed=35, colors=12), ["-R", "0"]),
+    ("pal_rgb_channelwise_96x72", dict(w=96, h=72, channels=3, bits=8, seed=37, poster=8), []),
+    ("approx_rgb8_96x80_A3", dict(w=96, h=80, channels=3, bits=8, seed=36, photographic=True), ["-A", "3,3"]),
+]
 JPEG_SPECS = [
     ("jpeg420_256x192_q90", dict(w=256, h=192, channels=3, bits=8, seed=20), dict(quality=90, subsampling=2)),
     ("jpeg444_136x120_q85", dict(w=136, h=120, channels=3, bits=8, seed=21), dict(quality=85, subsampling=0)),
@@ -63,16 +74,26 @@ JPEG_SPECS = [
 ANIM_SPECS = [
     ("anim3_48x32", dict(w=48, h=32, channels=3, bits=8, seed=700), dict(frames=3)),
 ]
-PREVIEWS = {"c1_rgb8_512x512": [0, 1, 2, 3, 4], "rgb8_97x61": [0, 2, 4], "jpeg420_256x192_q90": [0, 1, 2, 3, 4]}
-TRUNCATE = {"rgb8_97x61": [0.2, 0.55, 0.93], "rgb8_128x128_I0": [0.5], "jpeg420_256x192_q90": [0.4], "rgb8_64x64_U": [0.6]}
+PREVIEWS = {"c1_rgb8_512x512": [0, 1, 2, 3, 4], "rgb8_97x61": [0, 2, 4], "jpeg420_256x192_q90": [0, 1, 2, 3, 4],
+            "pal_rgb_graphic_120x90": [1, 3], "approx_rgb8_96x80_A3": [2]}
+TRUNCATE = {"rgb8_97x61": [0.2, 0.55, 0.93], "rgb8_128x128_I0": [0.5], "jpeg420_256x192_q90": [0.4], "rgb8_64x64_U": [0.6],
+            "pal_rgba_graphic_72x64": [0.5], "pal_rgb_sparse_128x96": [0.7]}
 
 
 def main():
     ref = Ref()
     manifest = {"generator": "tests/golden/make_golden.py", "reference": "cloudinary/fuif @ /root/reference (unmodified)", "fixtures": []}
     tmp = tempfile.mkdtemp()
-    for name, gen, flags in SPECS + [(n, g, j) for n, g, j in JPEG_SPECS] + ANIM_SPECS:
-        img = photographic(**gen)
+    for name, gen, flags in SPECS + GRAPHIC_SPECS + [(n, g, j) for n, g, j in JPEG_SPECS] + ANIM_SPECS:
+        gen = dict(gen)
+        if "colors" in gen:
+            img = graphic(**gen)
+        else:
+            gen.pop("photographic", None)
+            poster = gen.pop("poster", 0)
+            img = photographic(**gen)
+            if poster:
+                img = img // poster * poster   # more than 256 colours, sparse per-channel histograms
         maxval = (1 << gen["bits"]) - 1
         out = os.path.join(HERE, name + ".fuif")
         if isinstance(flags, dict) and "frames" in flags:

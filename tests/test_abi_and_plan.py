@@ -35,7 +35,7 @@ def test_plan_matches_reference_geometry(gpulib, manifest):
         outs = p.output_channels
         assert len(outs) == len(c["post"]), e["name"]
         for a, b in zip(outs, c["post"]):
-            assert (a["w"], a["h"]) == (b["w"], b["h"]), e["name"]
+            assert (a["w"], a["h"], a["component"]) == (b["w"], b["h"], b["component"]), e["name"]
         # slabs: planes do not overlap and stay inside the slab
         spans = sorted((ch["offset"], ch["offset"] + ch["w"] * ch["h"]) for ch in coded if ch["w"] * ch["h"])
         assert all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))

@@ -45,7 +45,8 @@ def expected_pnm_payload(planes, maxval):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["rgb8_97x61", "c1_rgb8_512x512", "gray8_64x48", "rgba14_80x72", "rgb8_160x120_Q80", "jpeg444_136x120_q85"])
+@pytest.mark.parametrize("name", ["rgb8_97x61", "c1_rgb8_512x512", "gray8_64x48", "rgba14_80x72", "rgb8_160x120_Q80", "jpeg444_136x120_q85",
+                                  "pal_rgb_graphic_120x90", "pal_rgb_channelwise_96x72", "approx_rgb8_96x80_A3"])
 def test_reference_cli_decodes_through_gpu(name, port, tmp_path):
     need_cli()
     src = os.path.join(GOLDEN, name + ".fuif")
