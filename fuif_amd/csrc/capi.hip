@@ -365,7 +365,7 @@ int fuifgpu_batch_undo_transforms(fuifgpu_batch *b, void *stream) {
         bases.base[BUF_COEF] = b->d_coef + (int64_t)i0 * p.coef_elems; bases.stride[BUF_COEF] = p.coef_elems;
         bases.base[BUF_OUT] = b->d_out + (int64_t)i0 * p.out_elems; bases.stride[BUF_OUT] = p.out_elems;
         bases.base[BUF_TMP] = b->d_tmp; bases.stride[BUF_TMP] = p.tmp_elems;
-        for (const Op &op : p.ops) launch_op(op, bases, b->d_list, b->d_meta, nch, i0, cnt, st);
+        for (const Op &op : p.ops) launch_op(op, bases, b->d_list, b->d_meta, nch, i0, cnt, st, b->d_status);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->ev[3], st));

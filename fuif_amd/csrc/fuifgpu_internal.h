@@ -76,7 +76,8 @@ enum : int {
     OP_HSQUEEZE = 1, OP_VSQUEEZE = 2, OP_YCOCG = 3, OP_YCBCR = 4, OP_QUANT = 5, OP_IDCT = 6,
     OP_UPSAMPLE = 7, OP_COPY_CLAMP = 8, OP_CLAMP = 9,
     OP_PALETTE = 10,   // dst = palette[p0][clamp(index)]: src[0] index plane, src[1] palette plane (p1 colours wide)
-    OP_APPROX = 11     // src[0] = src[0]*p0 + src[1] in place when the remainder src[1] was decoded (p1: it has constructor data)
+    OP_APPROX = 11,    // src[0] = src[0]*p0 + src[1] in place when the remainder src[1] was decoded (p1: it has constructor data)
+    OP_MATCH = 12      // 2D match against previous frames, in place on the listed planes: src[0] match plane, p0 softmatch, p1 frame height
 };
 struct Op {
     int32_t kind;

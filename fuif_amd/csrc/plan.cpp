@@ -291,6 +291,19 @@ struct Builder {
         return true;
     }
 
+    // transform/2dmatch.h:115-121,179-194
+    bool meta_match(std::vector<int> &params) {
+        if (params.empty()) params = {0, nbc - 1, 0, 1000000};
+        if (params.size() < 3) return fail(FUIFGPU_E_CORRUPT, "match transform with incorrect parameters");
+        int begin_c = nb_meta + params[0], end_c = nb_meta + params[1];
+        if (begin_c < 0 || begin_c > end_c || end_c >= (int)live.size()) return fail(FUIFGPU_E_CORRUPT, "match channel range invalid");
+        nb_meta++;
+        LiveChannel mch{};
+        mch.plane = -1; mch.w = live[begin_c].w; mch.h = live[begin_c].h; mch.component = -1; mch.ctor_data = true;
+        live.insert(live.begin(), mch);
+        return true;
+    }
+
     // ---- inverse schedule -------------------------------------------------------------------
     int new_plane(int w, int h, int qsrc, int birth) {
         PlaneInfo pi;
@@ -496,6 +509,34 @@ struct Builder {
         return true;
     }
 
+    // transform/2dmatch.h:123-177.  Which of the two modes a stream uses is DATA (the match channel's q,
+    // :147-149), so the op carries both pieces of geometry and the kernel decides per image; only the
+    // previous-frame mode (what the CLI picks for animations, fuif.cpp:440) runs on the GPU.
+    bool inv_match(const std::vector<int> &params) {
+        if (nb_meta < 1 || params.size() < 3) return fail(FUIFGPU_E_CORRUPT, "match transform without match channel");
+        int c0 = nb_meta + params[0], cn = nb_meta + params[1];
+        if (c0 < 1 || cn < c0 || cn >= (int)live.size()) return fail(FUIFGPU_E_CORRUPT, "match transform with incorrect parameters");
+        const LiveChannel &m = live[0];
+        int w = live[c0].w, h = live[c0].h;
+        ProtoOp op;
+        op.kind = OP_MATCH;
+        int idx = (int)ops.size();
+        op.src[0] = m.plane;
+        touch(m.plane, idx);
+        for (int c = c0; c <= cn; c++) {
+            if (live[c].w != w || live[c].h != h) return fail(FUIFGPU_E_UNSUPPORTED, "match over channels of different sizes");
+            op.list.push_back(live[c].plane);
+            touch(live[c].plane, idx);
+        }
+        if (m.w != w || m.h != h) return fail(FUIFGPU_E_UNSUPPORTED, "match channel geometry differs from the matched channels");
+        op.p0 = params[2] ? 1 : 0;
+        op.p1 = h / std::max(1, plan.nb_frames);
+        if ((int64_t)w * h > 0) ops.push_back(op);
+        nb_meta--;
+        live.erase(live.begin());
+        return true;
+    }
+
     bool finalize() {
         // every plane still referenced by a live channel is a final plane
         int nops_before = (int)ops.size();
@@ -503,7 +544,7 @@ struct Builder {
         for (int k = 0; k < nops_before; k++) {
             const ProtoOp &op = ops[k];
             for (int d = 0; d < 3; d++) if (op.dst[d] >= 0) { last_writer[op.dst[d]] = k; last_kind[op.dst[d]] = op.kind; }
-            if (op.kind == OP_QUANT) for (int pl : op.list) { last_writer[pl] = k; last_kind[pl] = op.kind; }
+            if (op.kind == OP_QUANT || op.kind == OP_MATCH) for (int pl : op.list) { last_writer[pl] = k; last_kind[pl] = op.kind; }
         }
         // final planes that are still coded planes need a copy into OUT
         for (auto &ch : live) {
@@ -704,6 +745,7 @@ int parse_and_plan(const uint8_t *blob, size_t n, Plan &plan) {
             case TR_SQUEEZE: ok = b.meta_squeeze(t.params); break;
             case TR_PALETTE: ok = b.meta_palette(t.params); break;
             case TR_APPROXIMATE: ok = b.meta_approximate(t.params); break;
+            case TR_2DMATCH: ok = b.meta_match(t.params); break;
             default:
                 plan.error = FUIFGPU_E_UNSUPPORTED;
                 plan.message = "transform id " + std::to_string(t.id) + " is outside the MI355X hot-path scope";
@@ -749,6 +791,7 @@ int parse_and_plan(const uint8_t *blob, size_t n, Plan &plan) {
             case TR_YCBCR: ok = b.inv_color(OP_YCBCR); break;
             case TR_PALETTE: ok = b.inv_palette(t.params); break;
             case TR_APPROXIMATE: ok = b.inv_approximate(t.params); break;
+            case TR_2DMATCH: ok = b.inv_match(t.params); break;
             default: ok = false; break;
         }
         if (!ok) return plan.error ? plan.error : (plan.error = FUIFGPU_E_CORRUPT);

@@ -13,6 +13,6 @@ struct Bases {
 };
 
 void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMeta *meta, int n_channels, int img_first,
-               int n_images, hipStream_t stream);
+               int n_images, hipStream_t stream, int32_t *status = nullptr);   // status: per-image FUIFGPU_ST_* words (optional)
 
 }  // namespace fuifgpu

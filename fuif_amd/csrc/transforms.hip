@@ -15,6 +15,7 @@
 //   k_clamp / k_copy_clamp   image/image.cpp:107-113
 //   k_inv_palette    transform/palette.h:57-64     gather through the decoded palette meta-channel
 //   k_inv_approx     transform/approximate.h:44-57 quotient * q + remainder, in place
+//   k_inv_match_frames  transform/2dmatch.h:147-171  copy / add the co-located sample of an earlier frame
 #include <hip/hip_runtime.h>
 
 #include "fuifgpu_internal.h"
@@ -235,6 +236,37 @@ __global__ __launch_bounds__(256) void k_inv_approx(Bases b, PlaneRef pc, PlaneR
     if (have && blockIdx.x == 0 && threadIdx.x == 0 && pc.qsrc >= 0 && pr.qsrc >= 0) m[pc.qsrc].q = reached ? m[pr.qsrc].q : 1;
 }
 
+// transform/2dmatch.h:147-171, the previous-frame mode (match channel q == 2*fh*fh + (fh&1), :147-149): frames are
+// stacked vertically, z = m(y,x) != 0 means "equal to (soft: add) the sample z frames up".  One lane per column,
+// serial down the rows (a source may itself be a matched sample of an earlier frame).  Channel::value() only
+// checks the linear index (image.h:82-85): a source before the first sample reads Channel::zero.
+// The general mode (q == 1: offsets into the causal neighbourhood, :136-146) is not built; such an image is
+// flagged FUIFGPU_ST_UNSUPPORTED and left unmatched.
+__global__ __launch_bounds__(256) void k_inv_match_frames(Bases b, PlaneRef pm, const PlaneRef *list, int n_list, int softmatch, int fh,
+                                                          const ChannelMeta *meta, int n_channels, int img_first, int32_t *status) {
+    const int z_img = blockIdx.z;
+    const int q = (meta && pm.qsrc >= 0) ? meta[(int64_t)(img_first + z_img) * n_channels + pm.qsrc].q : 0;
+    if (q != 2 * fh * fh + (fh & 1)) {
+        if (status && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&status[img_first + z_img], q == 1 ? ST_UNSUPPORTED : (ST_UNSUPPORTED | ST_CORRUPT));
+        return;
+    }
+    const int w = pm.w, h = pm.h;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= w) return;
+    const int32_t *m = plane_ptr(b, pm, z_img);
+    for (int y = 0; y < h; y++) {
+        const int zv = m[(int64_t)y * w + x];
+        if (!zv) continue;
+        const int64_t src = ((int64_t)y - (int64_t)zv * fh) * w + x;
+        const bool inside = src >= 0 && src < (int64_t)w * h;
+        for (int k = 0; k < n_list; k++) {
+            int32_t *p = plane_ptr(b, list[k], z_img);
+            const int sv = inside ? p[src] : 0;
+            p[(int64_t)y * w + x] = softmatch ? p[(int64_t)y * w + x] + sv : sv;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // transform/dct.h:60-77 -- the constants exactly as the reference prints them
 __constant__ double kDCT[64] = {
@@ -332,7 +364,7 @@ static inline dim3 grid1d(int64_t n, int block, int z, int y = 1) {
 }
 
 void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMeta *meta, int n_channels, int img_first,
-               int n_images, hipStream_t stream) {
+               int n_images, hipStream_t stream, int32_t *status) {
     switch (op.kind) {
         case OP_VSQUEEZE: {
             const int w = op.src[0].w;
@@ -379,6 +411,11 @@ void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMe
             if ((int64_t)op.dst[0].w * op.dst[0].h <= 0) break;
             hipLaunchKernelGGL(k_inv_palette, grid1d((int64_t)op.dst[0].w * op.dst[0].h, 256, n_images), dim3(256), 0, stream, b, op.src[0],
                                op.src[1], op.dst[0], op.p0, op.p1, op.clamp_out, op.lo, op.hi);
+            break;
+        case OP_MATCH:
+            if (!meta || op.src[0].w <= 0) break;
+            hipLaunchKernelGGL(k_inv_match_frames, dim3((op.src[0].w + 255) / 256, 1, n_images), dim3(256), 0, stream, b, op.src[0],
+                               dev_list + op.idct_first, op.pad, op.p0, op.p1, meta, n_channels, img_first, status);
             break;
         case OP_APPROX:
             if (!meta || (int64_t)op.dst[0].w * op.dst[0].h <= 0) break;

@@ -30,6 +30,7 @@
 #define TR_QUANTIZE 5
 #define TR_PALETTE 6
 #define TR_SQUEEZE 7
+#define TR_2DMATCH 8
 #define TR_APPROXIMATE 10
 
 #define CLAMPI(x, l, u) ((x) < (l) ? (l) : ((x) > (u) ? (u) : (x)))
@@ -502,6 +503,22 @@ static int meta_approximate(fo_image *img, const fo_transform *t) {
     return 1;
 }
 
+/* transform/2dmatch.h:115-121,179-194 */
+static void match_default_params(const fo_image *img, int *p) { p[0] = 0; p[1] = img->nb_channels - 1; p[2] = 0; p[3] = 1000000; }
+static int meta_match(fo_image *img, fo_transform *t) {
+    if (!t->nparams) {
+        t->params = (int *)realloc(t->params, sizeof(int) * 4);
+        match_default_params(img, t->params); t->nparams = 4;
+    }
+    if (t->nparams < 3) return 0;
+    int begin_c = img->nb_meta_channels + t->params[0], end_c = img->nb_meta_channels + t->params[1];
+    if (begin_c > end_c || end_c >= img->nch || begin_c < 0) return 0;
+    img->nb_meta_channels++;
+    fo_channel mch; ch_ctor(&mch, img->ch[begin_c].w, img->ch[begin_c].h, 0, 1);
+    img_insert_channel(img, 0, &mch);
+    return 1;
+}
+
 /* transform/transform.h:85-102 */
 static int tr_has_parameters(int id) {
     switch (id) { case 3: case 6: case 7: case 4: case 8: case 9: case 10: return 1; default: return 0; }
@@ -515,7 +532,8 @@ static int meta_apply(fo_image *img, fo_transform *t) {
         case TR_SQUEEZE: return meta_squeeze(img, t);
         case TR_PALETTE: return meta_palette(img, t);
         case TR_APPROXIMATE: return meta_approximate(img, t);
-        default: return -1;   /* 2D match (8), permute (9): not on the path this oracle restates */
+        case TR_2DMATCH: return meta_match(img, t);
+        default: return -1;   /* permute (9): not on the path this oracle restates */
     }
 }
 
@@ -1288,6 +1306,63 @@ static int inv_approximate(fo_image *img, const fo_transform *t) {
     return 1;
 }
 
+/* transform/2dmatch.h:50-78 */
+static void match_offset(int code, int *xo, int *yo) {
+    int layer = 0, size = 4;
+    while (code > size) { code -= size; layer++; size += 4; }
+    if (layer & 1) {
+        if (code <= layer) { *xo = 1 + layer; *yo = -code; }
+        else if (code <= 3 + 3 * layer) { *xo = 2 + 2 * layer - code; *yo = -1 - layer; }
+        else { *xo = -1 - layer; *yo = -4 - 4 * layer + code; }
+    } else {
+        if (code <= 1 + layer) { *xo = -1 - layer; *yo = 1 - code; }
+        else if (code <= 4 + 3 * layer) { *xo = -3 - 2 * layer + code; *yo = -1 - layer; }
+        else { *xo = 1 + layer; *yo = -5 - 4 * layer + code; }
+    }
+}
+/* Channel::value(r,c) on a plane being rewritten in place: image.h:82-85 (linear index check only) */
+static inline int32_t *ch_slot(fo_channel *c, int r, int col, int32_t *zero_slot) {
+    size_t idx = (size_t)((int64_t)r * c->w + col);
+    if (idx >= c->size) { *zero_slot = c->zero; return zero_slot; }
+    return &c->data[idx];
+}
+/* transform/2dmatch.h:123-177 */
+static int inv_match(fo_image *img, fo_transform *t) {
+    if (img->nb_meta_channels < 1) return 0;
+    int dflt[4]; const int *p = t->params; int np = t->nparams;
+    if (!np) { match_default_params(img, dflt); p = dflt; np = 4; }
+    if (np < 3) return 0;
+    fo_channel *m = &img->ch[0];
+    int c0 = img->nb_meta_channels + p[0], cn = img->nb_meta_channels + p[1];
+    if (c0 >= img->nch || cn >= img->nch || c0 < 0) return 0;
+    int softmatch = p[2];
+    int w = img->ch[c0].w, h = img->ch[c0].h;
+    for (int c = c0; c <= cn; c++) ch_materialize(&img->ch[c]);
+    int fh = h / img->nb_frames;
+    int offsetcode = 2 * fh * fh + (fh & 1);
+    if (m->q != 1 && m->q != offsetcode) return 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int z = ch_value(m, y, x);
+            if (!z) continue;
+            int xo = 0, yo;
+            if (m->q == 1) {
+                if (z < 0 || z > m->maxval) return 0;   /* offsets_table[z] out of range in the reference */
+                match_offset(z, &xo, &yo);
+            } else yo = -z * fh;
+            for (int c = c0; c <= cn; c++) {
+                fo_channel *ch = &img->ch[c];
+                int32_t zs_a, zs_b;
+                int32_t *dst = ch_slot(ch, y, x, &zs_a);
+                int32_t src = *ch_slot(ch, y + yo, x + xo, &zs_b);
+                if (softmatch) *dst += src; else *dst = src;
+            }
+        }
+    img->nb_meta_channels--;
+    img_erase_channels(img, 0, 1);
+    return 1;
+}
+
 static int tr_apply_inverse(fo_image *img, fo_transform *t) {
     switch (t->id) {
         case TR_YCBCR: return inv_ycbcr(img);
@@ -1298,6 +1373,7 @@ static int tr_apply_inverse(fo_image *img, fo_transform *t) {
         case TR_SQUEEZE: return inv_squeeze(img, t);
         case TR_PALETTE: return inv_palette(img, t);
         case TR_APPROXIMATE: return inv_approximate(img, t);
+        case TR_2DMATCH: return inv_match(img, t);
         default: return 0;
     }
 }

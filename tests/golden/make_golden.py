@@ -73,6 +73,8 @@ JPEG_SPECS = [
 # animation (FUAF): frames are stacked vertically; -M 0 keeps the 2D-match transform (out of scope) off
 ANIM_SPECS = [
     ("anim3_48x32", dict(w=48, h=32, channels=3, bits=8, seed=700), dict(frames=3)),
+    # default flags for an animation: 2D match against the previous frames (fuif.cpp:440-448, 2dmatch.h:147-171)
+    ("anim4_match_40x28", dict(w=40, h=28, channels=3, bits=8, seed=710, static=True), dict(frames=4, match=True)),
 ]
 PREVIEWS = {"c1_rgb8_512x512": [0, 1, 2, 3, 4], "rgb8_97x61": [0, 2, 4], "jpeg420_256x192_q90": [0, 1, 2, 3, 4],
             "pal_rgb_graphic_120x90": [1, 3], "approx_rgb8_96x80_A3": [2]}
@@ -86,6 +88,7 @@ def main():
     tmp = tempfile.mkdtemp()
     for name, gen, flags in SPECS + GRAPHIC_SPECS + [(n, g, j) for n, g, j in JPEG_SPECS] + ANIM_SPECS:
         gen = dict(gen)
+        static = gen.pop("static", False)
         if "colors" in gen:
             img = graphic(**gen)
         else:
@@ -97,11 +100,16 @@ def main():
         maxval = (1 << gen["bits"]) - 1
         out = os.path.join(HERE, name + ".fuif")
         if isinstance(flags, dict) and "frames" in flags:
+            base = photographic(**gen)
             for i in range(flags["frames"]):
                 g2 = dict(gen); g2["seed"] = gen["seed"] + i
-                write_pnm(os.path.join(tmp, name + "-%02d.ppm" % i), photographic(**g2), maxval)
+                fr = photographic(**g2)
+                if static:   # frames share most pixels with the first one: something for the match transform to find
+                    keep = np.ones(fr.shape[1:], bool); keep[4 + 3 * i: 14 + 3 * i, 6 + 5 * i: 20 + 5 * i] = False
+                    fr = np.where(keep[None], base, fr)
+                write_pnm(os.path.join(tmp, name + "-%02d.ppm" % i), fr, maxval)
             src = os.path.join(tmp, name + "-%02d.ppm")
-            cli_flags = ["-M", "0"]
+            cli_flags = [] if flags.get("match") else ["-M", "0"]
         elif isinstance(flags, dict):
             from PIL import Image
             arr = np.moveaxis(img, 0, -1).astype(np.uint8)
