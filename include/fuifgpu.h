@@ -24,7 +24,7 @@ extern "C" {
 #define FUIFGPU_OK 0
 #define FUIFGPU_E_NOT_FUIF 1      /* bad magic / short header */
 #define FUIFGPU_E_CORRUPT 2       /* header or transform list is inconsistent */
-#define FUIFGPU_E_UNSUPPORTED 3   /* transform outside the hot-path scope (palette, 2D-match, ...) */
+#define FUIFGPU_E_UNSUPPORTED 3   /* feature outside the hot-path scope (Permute, unusual subsampling ratios, ...) */
 #define FUIFGPU_E_ARG 4
 #define FUIFGPU_E_HIP 5           /* a HIP runtime call failed; see fuifgpu_last_error() */
 #define FUIFGPU_E_MISMATCH 6      /* image does not share the batch's plan signature */

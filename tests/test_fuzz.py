@@ -54,3 +54,29 @@ def test_gpu_agrees_with_oracle_on_corrupt_payload(manifest, port, gpulib):
         for g, ch in zip(pre, d.channels):
             if ch["size"] == ch["w"] * ch["h"]:
                 assert np.array_equal(g, ch["data"]), (name, k)
+
+
+def test_planner_survives_corrupt_headers(manifest, gpulib):
+    """host code of the product: random damage to the header / transform list (incl. the Palette, Approximate
+    and 2D-match parameter lists) is either rejected with an error code or planned to a bounded geometry"""
+    rng = np.random.default_rng(7)
+    n = planned = 0
+    for e in manifest["fixtures"]:
+        blob = golden_blob(e, e["cases"][0])
+        hdr = min(len(blob), 120)
+        for k in range(60):
+            b = bytearray(blob)
+            for _ in range(1 + k % 4):
+                pos = int(rng.integers(4, hdr))
+                b[pos] = (b[pos] ^ (1 << int(rng.integers(0, 8)))) if k % 2 else int(rng.integers(0, 256))
+            n += 1
+            try:
+                p = gpulib.Plan(bytes(b))
+            except gpulib.FuifGpuError as err:
+                assert err.code in (1, 2, 3), err      # NOT_FUIF / CORRUPT / UNSUPPORTED
+                continue
+            planned += 1
+            assert p.info.coef_elems < (1 << 34) and p.info.out_elems < (1 << 34)
+            assert len(p.coded_channels) == p.info.nb_coded_channels
+            gpulib.index_parse(bytes(b))               # trailer parser on the same damage
+    assert n > 1000 and planned > 100
