@@ -103,6 +103,40 @@ def cpu_baseline(blobs, w, h, budget_s=25.0):
             "sample": "%d of the bench's %dx%d streams, full decode (entropy + inverse transforms), 1 thread, %.1f s" % (n, w, h, t_total)}
 
 
+def cpu_baseline_all_cores(paths, w, h, seconds=12.0):
+    """the same reference decoder on every host core at once, one process per image; separate
+    processes started with subprocess (this process already holds HIP / RCCL state: no fork)"""
+    import subprocess
+    cores = os.cpu_count() or 1
+    worker = os.path.join(ROOT, "oracle", "cpu_worker.py")
+    start_at = time.time() + 6.0 + cores * 0.01          # let every worker load before the clock starts
+    procs = [subprocess.Popen([sys.executable, worker, str(seconds), str(start_at), str(i)] + paths, stdout=subprocess.PIPE, text=True)
+             for i in range(cores)]
+    images, wall, failed = 0, 0.0, False
+    deadline = start_at + seconds + 120.0
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.communicate()
+            failed = True
+            continue
+        f = out.split()
+        if p.returncode != 0 or len(f) < 3:
+            failed = True
+            continue
+        images += int(f[0])
+        wall = max(wall, float(f[2]))
+    if failed:
+        return None
+    if not images:
+        return None
+    from oracle_py import Ref
+    return {"value": round(images * w * h / 1e6 / wall, 2), "unit": "Mpixels/s", "cores": cores, "kind": "reference" if Ref.available() else "port",
+            "sample": "%d full decodes of the bench's %dx%d streams by %d concurrent processes in %.1f s" % (images, w, h, cores, wall)}
+
+
 def pmc_traffic(batch, mode):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r*_pmc_traffic.json, collected with tools/collect_profiles.sh); None if no profile
@@ -130,6 +164,8 @@ def main():
     ap.add_argument("--distinct", type=int, default=8, help="K distinct images replicated to the batch")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2", help="c2 = BASELINE headline config (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="also time the reference decoder on every host core at once (one process per image, ~40 s extra)")
     ap.add_argument("--no-index", action="store_true", help="ignore the streams' group index: one wavefront per image for the timed steps")
     ap.add_argument("--no-seq-compare", action="store_true", help="skip the extra one-wavefront-per-image step reported next to the headline")
     ap.add_argument("--cache", default=os.environ.get("FUIF_BENCH_CACHE", "/tmp/fuif_bench_cache"))
@@ -291,6 +327,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline([b for _, b in inputs], W, H)
             res["speedup_vs_cpu_1thread"] = round(value / res["cpu_baseline"]["value"], 2)
+            if args.cpu_all_cores:
+                name = "synth_idx_" + wl["kind"] + "_%dx%dx%d_%dbit_seed%d.fuif"
+                paths = [os.path.join(args.cache, name % (W, H, C, BITS, seed)) for seed, _ in inputs]
+                if all(os.path.exists(p) for p in paths):
+                    allc = cpu_baseline_all_cores(paths, W, H)
+                    if allc:
+                        res["cpu_baseline_all_cores"] = allc
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()
