@@ -1,10 +1,15 @@
 // fuif_amd/csrc/maniac_decode.hip -- MANIAC entropy decode of a batch of FUIF streams on gfx950.
 //
-// One 64-lane wavefront (= one workgroup) per stream.  The format has no intra-stream entry
-// points (a channel group's first byte is only known once the previous group is fully decoded,
-// maniac/rac.h:70-104), so a stream is an inherently serial chain: the batch provides the
-// parallelism (1024 streams = one wave per SIMD on 256 CUs) and the kernel's job is to make the
-// per-symbol dependency chain as short as the hardware allows.  The wave is used as one scalar
+// One 64-lane wavefront (= one workgroup) per TILE = a run of channel groups whose first byte is
+// known.  The format has no intra-stream entry points (a channel group's first byte is only known
+// once the previous group is fully decoded, maniac/rac.h:70-104), so a plain stream is one tile: an
+// inherently serial chain, and the batch provides the parallelism (1024 streams = one wave per SIMD
+// on 256 CUs).  A stream that carries a group index (index.cpp) is one tile per channel group; tiles
+// of one image then run concurrently and hand decoded rows to each other (the properties of a pixel
+// read up to 6 previously decoded channels, context_predict.h:233-289): see "tile-to-tile hand-off"
+// below and DESIGN.md 4.1.  Persistent wavefronts take tiles from a work list in dependency order.
+// Inside a tile the kernel's job is to make the per-symbol dependency chain as short as the hardware
+// allows.  The wave is used as one scalar
 // processor (range coder state, tree position: SGPRs via readlane/readfirstlane) plus a 64-lane
 // vector unit:
 //   * compressed bytes: one coalesced 256-byte window per refill, lane i holds dword i,
@@ -26,8 +31,9 @@
 // A single wave issues one instruction every ~4.6 cycles, a taken branch costs ~25 and a
 // VALU<->SALU hand-over ~14 (tools/ubench.hip), so the kernel is bound by the instruction count of
 // the per-symbol chain; every item above trades scalar instructions for vector ones.
-// LDS budget 39 KB per wave so that 4 streams share a CU (160 KB): 29 KB of supernodes,
-// 8.4 KB of chunk properties, the rest small state.  The 16 KB chance transition table is read
+// Two LDS configurations are built: "wide" = 39 KB per wave (29 KB of supernodes, 8.4 KB of chunk
+// properties, small state; 4 waves per CU) and "dense" = 10 KB (2 supernodes; 16 waves per CU, four per
+// SIMD, which fill each other's stalls when tiles outnumber SIMDs).  The 16 KB chance transition table is read
 // through L1/L2 instead: its lookups are off the dependency chain thanks to the batched update.
 //
 // What it replaces in the reference:
