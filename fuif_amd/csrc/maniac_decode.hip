@@ -112,13 +112,22 @@ DEV int wrlane(int val, int l, int old) { return ((int)threadIdx.x == l) ? val :
 // progress words) is therefore stored write-through (sc1, agent-scope relaxed atomics) and read
 // with agent-scope loads that bypass the CU's L1; a progress word is stored only after
 // `s_waitcnt vmcnt(0)` has drained the payload stores of the (single) writing wave.
+#ifdef FUIF_EMU   // tools/emu: the same source compiled for the CPU wavefront emulator (test infrastructure)
+typedef int32_t gi32;
+typedef uint32_t gu32;
+#else
 typedef __attribute__((address_space(1))) int32_t gi32;
 typedef __attribute__((address_space(1))) uint32_t gu32;
+#endif
 DEV void st_agent(int32_t *p, int v) { __hip_atomic_store((gi32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store((gu32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV int ld_agent(const int32_t *p) { return __hip_atomic_load((const gi32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load((const gu32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#ifdef FUIF_EMU
+DEV void drain_stores() {}
+#else
 DEV void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
 constexpr uint32_t kSpinLimit = 1u << 25;   // x (sleep + one L2 round trip) ~ a minute: only a lost producer gets here
 
 struct Node {  // maniac/compound.h:41-51; property -1 = leaf, child = leaf id
@@ -129,6 +138,11 @@ struct Node {  // maniac/compound.h:41-51; property -1 = leaf, child = leaf id
 
 // One 64-bit load per tree level.  hipcc otherwise splits the node into two dependent 32-bit
 // loads (it sinks the splitval load behind the leaf test), doubling the per-level latency.
+#ifdef FUIF_EMU
+static const char *emu_lds_base;   // LDS byte addresses are offsets from the supernode array in the emulator
+DEV uint2 lds_load_node(uint32_t lds_byte_addr) { return *reinterpret_cast<const uint2 *>(emu_lds_base + lds_byte_addr); }
+DEV uint2 global_load_node(const void *p) { return *reinterpret_cast<const uint2 *>(p); }
+#else
 DEV uint2 lds_load_node(uint32_t lds_byte_addr) {
     uint2 v;
     asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_byte_addr) : "memory");
@@ -139,6 +153,7 @@ DEV uint2 global_load_node(const void *p) {
     asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
+#endif
 
 struct Frame {  // one pending inner node of the pre-order tree parse
     int32_t p, oldmin, oldmax, splitval, child, stage;
@@ -405,7 +420,12 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
     int32_t *queue = reinterpret_cast<int32_t *>(scratch + P.queue_off);      // breadth-first work list
     const ChannelGeom *geom = P.geom;
     const int nch = P.n_channels;
+#ifdef FUIF_EMU
+    emu_lds_base = reinterpret_cast<const char *>(&sh.snodes[0]);
+    const uint32_t lds_nodes_addr = 0;
+#else
     const uint32_t lds_nodes_addr = (uint32_t)(uintptr_t)(&sh.snodes[0]);  // LDS byte offset (low half of the flat address)
+#endif
     // geometry of a 6-level supernode in heap order (children of slot k: 2k+1 = "> split", 2k+2 = "<= split"):
     // lane e owns exit e; exp/msk = the decisions its path needs and the slots they sit in
     int exit_q = 0;

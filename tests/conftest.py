@@ -23,7 +23,13 @@ def plane_hash(a):
 @pytest.fixture(scope="session")
 def manifest():
     with open(os.path.join(GOLDEN, "manifest.json")) as f:
-        return json.load(f)
+        m = json.load(f)
+    # FUIF_TEST_MAX_PIXELS: keep only small fixtures (set by tests/test_emulated_kernels.py, where the -m gpu tests
+    # run against the CPU wavefront emulator at ~1 us per cross-lane operation)
+    limit = int(os.environ.get("FUIF_TEST_MAX_PIXELS", "0"))
+    if limit:
+        m["fixtures"] = [e for e in m["fixtures"] if e["cases"][0]["info"]["w"] * e["cases"][0]["info"]["h"] <= limit]
+    return m
 
 
 @pytest.fixture(scope="session")

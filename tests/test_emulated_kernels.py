@@ -1,0 +1,67 @@
+"""CPU: the GPU parity tests, run against the kernels' own sources compiled for a wavefront emulator.
+
+tools/emu/ compiles fuif_amd/csrc/*.hip UNCHANGED (plus -DFUIF_EMU for three inline-asm helpers) with g++ against
+a stand-in hip_runtime.h in which a 64-lane wavefront is 64 cooperative fibers and every cross-lane operation
+(readlane, readfirstlane, ballot, ds_bpermute, __syncthreads) is a rendezvous.  That checks the LOGIC of the
+entropy kernel, the tile scheduler's bookkeeping and every inverse-transform kernel against the golden vectors
+on a machine without a GPU -- each round only has minutes of GPU time, kernel edits should not need them to find
+out that a refactor broke bit-exactness.  It is test infrastructure: the emulated library is built under
+tests/_emu/, is only ever loaded through FUIF_AMD_LIB by this file, and says nothing about speed or about the
+memory-model side of the tile hand-off (those are the -m gpu tests' job on the MI355X)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+EMU_DIR = os.path.join(ROOT, "tests", "_emu")
+EMU_LIB = os.path.join(EMU_DIR, "libfuifgpu_emu.so")
+CSRC = os.path.join(ROOT, "fuif_amd", "csrc")
+SOURCES = ["plan.cpp", "index.cpp", "writer.cpp", "maniac_decode.hip", "transforms.hip", "capi.hip"]
+
+
+def build_emulated_library():
+    os.makedirs(EMU_DIR, exist_ok=True)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "tools", "emu", "emu_runtime.cpp"),
+                                                               os.path.join(ROOT, "tools", "emu", "hip", "hip_runtime.h"),
+                                                               os.path.join(ROOT, "include", "fuifgpu.h")]
+    if os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(d) for d in deps):
+        return EMU_LIB
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DFUIF_EMU", "-ffp-contract=off", "-Wno-attributes",
+           "-I", os.path.join(ROOT, "tools", "emu"), "-x", "c++"] + [os.path.join(CSRC, s) for s in SOURCES] + \
+          [os.path.join(ROOT, "tools", "emu", "emu_runtime.cpp"), "-o", EMU_LIB]
+    subprocess.check_call(cmd)
+    return EMU_LIB
+
+
+SELECTED = [
+    "tests/test_gpu_parity.py::test_golden_fixtures_bit_exact",
+    "tests/test_gpu_parity.py::test_batch_of_replicas_and_distinct_streams",
+    "tests/test_gpu_group_parallel.py::test_reference_written_files_indexed_after_the_fact",
+    "tests/test_gpu_group_parallel.py::test_previews_of_indexed_streams",
+    "tests/test_gpu_group_parallel.py::test_writer_indexed_streams_vs_oracle[97-61-3-8-2]",
+    "tests/test_gpu_group_parallel.py::test_writer_indexed_streams_vs_oracle[301-47-1-8-42]",
+    "tests/test_gpu_group_parallel.py::test_mixed_batch_with_more_tiles_than_wavefronts",
+    "tests/test_gpu_group_parallel.py::test_jpeg_like_indexed",
+    "tests/test_gpu_group_parallel.py::test_truncated_indexed_stream_falls_back_and_side_index_on_truncated_blob",
+    "tests/test_fuzz.py::test_gpu_agrees_with_oracle_on_corrupt_payload",
+]
+
+
+def test_gpu_parity_tests_pass_on_the_wavefront_emulator():
+    if sys.platform != "linux" or os.uname().machine != "x86_64":
+        pytest.skip("the emulator's context switch is x86-64 SysV assembly")
+    lib = build_emulated_library()
+    env = dict(os.environ)
+    env.update(FUIF_AMD_LIB=lib, FUIF_TEST_MAX_PIXELS="50000", FUIF_TEST_BATCH="12", EMU_ALARM="1500")
+    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + SELECTED
+    try:
+        import xdist  # noqa: F401
+        cmd += ["-n", str(max(1, min(4, (os.cpu_count() or 2) // 2)))]
+    except ImportError:
+        pass
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1700)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout

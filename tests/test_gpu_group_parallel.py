@@ -6,6 +6,8 @@ golden vectors of the real reference and to the oracle -- planes, channel ranges
 consumed -- for reference-written files indexed after the fact, for files the product's writer
 indexed itself, for previews, for mixed batches and when there are far more tiles than resident
 wavefronts."""
+import os
+
 import numpy as np
 import pytest
 
@@ -96,7 +98,7 @@ def test_mixed_batch_with_more_tiles_than_wavefronts(gpulib, port):
     indexed = [gpulib.encode_image(im, 8, tree_mode=1, index=True) for im in imgs]
     plain = [gpulib.encode_image(im, 8, tree_mode=1) for im in imgs]
     blobs, want = [], []
-    for k in range(192):
+    for k in range(int(os.environ.get("FUIF_TEST_BATCH", "192"))):
         src = (indexed if (k % 3) else plain)[k % 6]
         blobs.append(src)
         want.append(imgs[k % 6])

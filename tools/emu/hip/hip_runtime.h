@@ -1,0 +1,106 @@
+// tools/emu/hip/hip_runtime.h -- TEST INFRASTRUCTURE: a single-threaded stand-in for the HIP runtime and the
+// gfx950 wavefront intrinsics the kernels of fuif_amd/csrc use, so that the SAME kernel sources can be compiled
+// with g++ (-DFUIF_EMU -I tools/emu) into tests/_emu/libfuifgpu_emu.so and their LOGIC checked against the
+// golden vectors on machines without a GPU (tests/test_emulated_kernels.py).
+//
+// What it is: every workgroup runs as blockDim.x cooperative fibers on one OS thread; a cross-lane operation
+// (readlane, readfirstlane, ballot, ds_bpermute, __syncthreads) is a rendezvous of all fibers of the workgroup.
+// Workgroups run one after the other, so the entropy kernel is always launched with ONE persistent wavefront
+// (the work list is in dependency order: a tile's producers have finished before it starts).
+// What it is NOT: a performance model, a memory-model checker (the tile-to-tile hand-off protocol is only
+// exercised on the GPU), or a product path -- libfuifgpu.so never contains any of this and still fails without a GPU.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __constant__ static
+#define __launch_bounds__(...)
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint2 { unsigned x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+
+namespace emu {
+unsigned coord(int which);                       // 0-2 threadIdx, 3-5 blockIdx, 6-8 blockDim, 9-11 gridDim
+struct Coord { int which; operator unsigned() const { return coord(which); } };
+struct Triple { Coord x, y, z; };
+void launch(dim3 grid, dim3 block, const std::function<void()> &body);
+void yield();
+void sync();
+int readlane(int v, int lane);
+int readfirstlane(int v);
+int bpermute(int byte_addr, int v);
+unsigned long long ballot(bool p);
+bool any(bool p);
+}  // namespace emu
+static const emu::Triple threadIdx = {{0}, {1}, {2}}, blockIdx = {{3}, {4}, {5}}, blockDim = {{6}, {7}, {8}}, gridDim = {{9}, {10}, {11}};
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu::launch((grid), (block), [&]() { (kernel)(__VA_ARGS__); })
+
+// ---- wavefront intrinsics ---------------------------------------------------------------------
+#define __builtin_amdgcn_readfirstlane(v) emu::readfirstlane(v)
+#define __builtin_amdgcn_readlane(v, l) emu::readlane((v), (l))
+#define __builtin_amdgcn_ds_bpermute(a, v) emu::bpermute((a), (v))
+#define __builtin_amdgcn_s_sleep(n) emu::yield()
+#define __builtin_readcyclecounter() 0ull
+#define __ballot(p) emu::ballot(p)
+#define __any(p) emu::any(p)
+#define __syncthreads() emu::sync()
+#define __popcll(x) __builtin_popcountll(x)
+static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
+static inline unsigned atomicMax(unsigned *p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
+// round-to-nearest without contraction: the emulator is built with -ffp-contract=off
+static inline double __dadd_rn(double a, double b) { return a + b; }
+static inline double __dsub_rn(double a, double b) { return a - b; }
+static inline double __dmul_rn(double a, double b) { return a * b; }
+static inline float __fadd_rn(float a, float b) { return a + b; }
+static inline float __fsub_rn(float a, float b) { return a - b; }
+using std::max;
+using std::min;
+
+// ---- host API -----------------------------------------------------------------------------------
+typedef int hipError_t;
+typedef void *hipStream_t;
+typedef void *hipEvent_t;
+enum { hipSuccess = 0 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+struct hipDeviceProp_t { int multiProcessorCount; };
+static inline hipError_t hipMalloc(void **p, size_t n) { *p = calloc(n ? n : 1, 1); return *p ? hipSuccess : 2; }
+static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char *hipGetErrorString(hipError_t) { return "emulated HIP runtime"; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 1; return hipSuccess; }
+template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, K, int, size_t) { *n = 1; return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
