@@ -79,6 +79,7 @@ ABI_SYMBOLS = [
     "fuifgpu_batch_download_out", "fuifgpu_batch_last_timing", "fuifgpu_batch_profile", "fuifgpu_inv_hsqueeze", "fuifgpu_inv_vsqueeze",
     "fuifgpu_inv_ycocg", "fuifgpu_inv_ycbcr", "fuifgpu_idct8x8", "fuifgpu_upsample", "fuifgpu_encode_image", "fuifgpu_encode_channels", "fuifgpu_free_blob",
     "fuifgpu_index_parse", "fuifgpu_index_append", "fuifgpu_batch_group_index", "fuifgpu_batch_set_group_parallel",
+    "fuifgpu_plan_packed_bytes", "fuifgpu_batch_pack_out", "fuifgpu_batch_download_packed",
 ]
 
 
@@ -149,6 +150,9 @@ def lib():
     L.fuifgpu_index_append.argtypes = [C.c_char_p, C.c_size_t, vp, vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.fuifgpu_batch_group_index.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int)]
     L.fuifgpu_batch_set_group_parallel.argtypes = [vp, C.c_int]
+    L.fuifgpu_plan_packed_bytes.argtypes = [vp, C.c_int]; L.fuifgpu_plan_packed_bytes.restype = C.c_size_t
+    L.fuifgpu_batch_pack_out.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.fuifgpu_batch_download_packed.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     _lib = L
     return L
 
@@ -283,6 +287,21 @@ class Batch:
         slab = np.zeros(max(self.plan.info.coef_elems, 1), np.int32)
         _check(lib().fuifgpu_batch_download_coef(self._h, image, slab.ctypes.data, None))
         return [slab[c["offset"]: c["offset"] + c["w"] * c["h"]].reshape(c["h"], c["w"]).copy() for c in self.plan.coded_channels]
+
+    def packed(self, image, components=0):
+        """(h, w, components) uint8 / uint16 samples of one decoded image, interleaved and clamped on the GPU
+        (the payload export/write_pam.h would write); call after undo_transforms()"""
+        info = self.plan.info
+        n = lib().fuifgpu_plan_packed_bytes(self.plan._h, components)
+        if not n:
+            raise FuifGpuError(4, "these output channels cannot be packed")
+        buf = np.zeros(n, np.uint8)
+        _check(lib().fuifgpu_batch_download_packed(self._h, image, components, buf.ctypes.data, None))
+        bps = 2 if info.maxval > 255 else 1
+        comps = n // (info.w * info.h * bps)
+        if bps == 2:
+            return buf.view(">u2").astype(np.uint16).reshape(info.h, info.w, comps)
+        return buf.reshape(info.h, info.w, comps)
 
     def out_planes(self, image):
         slab = np.zeros(max(self.plan.info.out_elems, 1), np.int32)

@@ -436,6 +436,60 @@ int fuifgpu_batch_download_out(fuifgpu_batch *b, int image, int32_t *host, void 
     return FUIFGPU_OK;
 }
 
+// ---- packed output (export/write_pam.h:29-160, the part that turns planes into the bytes of a PNM/PAM) ------
+static int packed_layout(const Plan &p, int components, PackedPlanes *pp, int *bps) {
+    const int nout = (int)p.outputs.size();
+    if (components <= 0) components = std::min(nout, 4);
+    if (components > nout || components > 5) return FUIFGPU_E_ARG;
+    pp->n = components;
+    for (int c = 0; c < components; c++) {
+        const OutputChannel &o = p.outputs[c];
+        if (o.plane.w < p.w || o.plane.h < p.h) return FUIFGPU_E_ARG;   // write_pam.h:50-54 refuses such channels too
+        pp->p[c] = o.plane;
+    }
+    *bps = p.maxval > 255 ? 2 : 1;
+    return FUIFGPU_OK;
+}
+size_t fuifgpu_plan_packed_bytes(const fuifgpu_plan *plan, int components) {
+    if (!plan) return 0;
+    PackedPlanes pp; int bps = 1;
+    if (packed_layout(plan->plan, components, &pp, &bps) != FUIFGPU_OK) return 0;
+    return (size_t)plan->plan.w * plan->plan.h * pp.n * bps;
+}
+int fuifgpu_batch_pack_out(fuifgpu_batch *b, int first_image, int n_images, int components, uint8_t *dst_device, void *stream) {
+    if (!b || !dst_device || first_image < 0 || n_images < 1 || first_image + n_images > b->n_loaded) return FUIFGPU_E_ARG;
+    const Plan &p = b->plan;
+    PackedPlanes pp; int bps = 1;
+    int rc = packed_layout(p, components, &pp, &bps);
+    if (rc != FUIFGPU_OK) return rc;
+    Bases bases;
+    bases.base[BUF_COEF] = b->d_coef + (int64_t)first_image * p.coef_elems; bases.stride[BUF_COEF] = p.coef_elems;
+    bases.base[BUF_OUT] = b->d_out + (int64_t)first_image * p.out_elems; bases.stride[BUF_OUT] = p.out_elems;
+    bases.base[BUF_TMP] = b->d_tmp; bases.stride[BUF_TMP] = p.tmp_elems;
+    launch_pack(bases, pp, p.w, p.h, p.minval, p.maxval, bps, dst_device, (int64_t)p.w * p.h * pp.n * bps, n_images, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return FUIFGPU_OK;
+}
+int fuifgpu_batch_download_packed(fuifgpu_batch *b, int image, int components, uint8_t *host, void *stream) {
+    if (!b || !host || image < 0 || image >= b->n_loaded) return FUIFGPU_E_ARG;
+    PackedPlanes pp; int bps = 1;
+    int rc = packed_layout(b->plan, components, &pp, &bps);
+    if (rc != FUIFGPU_OK) return rc;
+    const size_t bytes = (size_t)b->plan.w * b->plan.h * pp.n * bps;
+    uint8_t *staging = nullptr;
+    HIPCHK(hipMalloc((void **)&staging, bytes ? bytes : 1));
+    rc = fuifgpu_batch_pack_out(b, image, 1, components, staging, stream);
+    hipError_t e = hipSuccess;
+    if (rc == FUIFGPU_OK) {
+        e = hipMemcpyAsync(host, staging, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    }
+    hipFree(staging);
+    if (rc != FUIFGPU_OK) return rc;
+    if (e != hipSuccess) return hip_fail(e, "download_packed");
+    return FUIFGPU_OK;
+}
+
 int fuifgpu_batch_last_timing(fuifgpu_batch *b, float *decode_ms, float *transform_ms) {
     if (!b) return FUIFGPU_E_ARG;
     if (decode_ms) {

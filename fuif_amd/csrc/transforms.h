@@ -15,4 +15,12 @@ struct Bases {
 void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMeta *meta, int n_channels, int img_first,
                int n_images, hipStream_t stream, int32_t *status = nullptr);   // status: per-image FUIFGPU_ST_* words (optional)
 
+// interleaved 8/16-bit samples of up to 5 final planes (export/write_pam.h:136-150)
+struct PackedPlanes {
+    int32_t n;
+    PlaneRef p[5];
+};
+void launch_pack(const Bases &b, const PackedPlanes &pp, int w, int h, int lo, int hi, int bytes_per_sample, uint8_t *dst, int64_t dst_stride,
+                 int n_images, hipStream_t stream);
+
 }  // namespace fuifgpu

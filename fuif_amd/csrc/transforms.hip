@@ -16,6 +16,7 @@
 //   k_inv_palette    transform/palette.h:57-64     gather through the decoded palette meta-channel
 //   k_inv_approx     transform/approximate.h:44-57 quotient * q + remainder, in place
 //   k_inv_match_frames  transform/2dmatch.h:147-171  copy / add the co-located sample of an earlier frame
+//   k_pack_samples   export/write_pam.h:136-150    interleaved 8/16-bit samples of the final planes (what a PNM/PAM holds)
 #include <hip/hip_runtime.h>
 
 #include "fuifgpu_internal.h"
@@ -353,6 +354,29 @@ __global__ __launch_bounds__(256) void k_upsample(Bases b, PlaneRef pi, PlaneRef
         v = hval(Y, X);
     }
     plane_ptr(b, po, blockIdx.z)[(int64_t)Y * po.w + X] = clamp ? clampi(v, lo, hi) : v;
+}
+
+// export/write_pam.h:136-150 (the RGB / gray / +alpha path): for every pixel of the w x h image the first
+// `components` channels, CLAMP(v, minval, maxval), one byte per sample or two bytes big-endian.  Planes may be
+// wider than the image (DCT-padded): the row pitch is the plane's own width.  A quarter of the bytes of the
+// int32 planes (an eighth for 8-bit images) is what a host that only wants the picture has to pull over PCIe.
+__global__ __launch_bounds__(256) void k_pack_samples(Bases b, PackedPlanes pp, int w, int h, int lo, int hi, int bytes_per_sample, uint8_t *dst,
+                                                      int64_t dst_stride) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w) return;
+    uint8_t *o = dst + (int64_t)blockIdx.z * dst_stride + ((int64_t)y * w + x) * pp.n * bytes_per_sample;
+    for (int c = 0; c < pp.n; c++) {
+        const int v = clampi(plane_ptr(b, pp.p[c], blockIdx.z)[(int64_t)y * pp.p[c].w + x], lo, hi);
+        if (bytes_per_sample == 2) { o[2 * c] = (uint8_t)(v >> 8); o[2 * c + 1] = (uint8_t)(v & 0xFF); }
+        else o[c] = (uint8_t)v;
+    }
+}
+
+void launch_pack(const Bases &b, const PackedPlanes &pp, int w, int h, int lo, int hi, int bytes_per_sample, uint8_t *dst, int64_t dst_stride,
+                 int n_images, hipStream_t stream) {
+    if (w <= 0 || h <= 0 || n_images <= 0) return;
+    hipLaunchKernelGGL(k_pack_samples, dim3((w + 255) / 256, h, n_images), dim3(256), 0, stream, b, pp, w, h, lo, hi, bytes_per_sample, dst, dst_stride);
 }
 
 // ---------------------------------------------------------------------------------------------

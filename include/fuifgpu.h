@@ -109,6 +109,17 @@ int32_t *fuifgpu_batch_coef_ptr(fuifgpu_batch *batch, int image);   /* device po
 int32_t *fuifgpu_batch_out_ptr(fuifgpu_batch *batch, int image);    /* device pointer */
 int fuifgpu_batch_download_coef(fuifgpu_batch *batch, int image, int32_t *host, void *stream);
 int fuifgpu_batch_download_out(fuifgpu_batch *batch, int image, int32_t *host, void *stream);
+/* ---- packed output: what export/write_pam.h:136-150 puts in a PNM/PAM file ---------------------------------
+ * For every pixel of the w x h image the first `components` output channels (0 = all, at most 4), clamped to
+ * [0,maxval], 1 byte per sample when maxval < 256 else 2 bytes big-endian, interleaved.  The packing runs on
+ * the GPU after fuifgpu_batch_undo_transforms; a host that only wants the picture pulls 1/4 (16-bit) or 1/8
+ * (8-bit) of the bytes of the int32 planes over PCIe. */
+size_t fuifgpu_plan_packed_bytes(const fuifgpu_plan *plan, int components);                 /* bytes per image */
+/* n_images images starting at first_image into a DEVICE buffer of n_images * packed_bytes */
+int fuifgpu_batch_pack_out(fuifgpu_batch *batch, int first_image, int n_images, int components, uint8_t *dst_device, void *stream);
+/* one image into HOST memory (packs into a temporary device buffer, copies, synchronises the stream) */
+int fuifgpu_batch_download_packed(fuifgpu_batch *batch, int image, int components, uint8_t *host, void *stream);
+
 /* kernel time of the last decode / undo_transforms launch set, measured with hipEvents on the
  * caller's stream (ms); used by bench.py for the roofline */
 int fuifgpu_batch_last_timing(fuifgpu_batch *batch, float *decode_ms, float *transform_ms);

@@ -88,3 +88,31 @@ def test_mixed_streams_scheduler(gpulib, manifest):
     assert not (st & 2).any()
     for n, planes in zip(names, outs):
         assert [plane_hash(p) for p in planes] == [c["sha256"] for c in by[n]["cases"][0]["post"]], n
+
+
+def test_packed_output_is_the_pam_payload(gpulib, manifest, port):
+    """fuifgpu_batch_download_packed: the bytes export/write_pam.h:136-150 would put behind the PNM/PAM header
+    (interleaved, clamped, 8 bit or 16 bit big-endian), produced by the packing kernel from the final planes"""
+    checked = 0
+    for e in manifest["fixtures"]:
+        c = e["cases"][0]
+        blob = golden_blob(e, c)
+        info = c["info"]
+        post = port.decode(blob)
+        w, h = info["w"], info["h"]
+        if len(post.channels) > 4 or any(ch["w"] < w or ch["h"] < h for ch in post.channels):
+            continue
+        plan = gpulib.Plan(blob)
+        batch = gpulib.Batch(plan, 2, 2 * len(blob))
+        try:
+            batch.upload([blob, blob])
+            batch.decode()
+            batch.undo_transforms()
+            batch.sync()
+            got = batch.packed(1)
+        finally:
+            batch.close()
+        want = np.stack([ch["data"][:h, :w] for ch in post.channels], axis=-1)
+        assert got.shape == want.shape and np.array_equal(got.astype(np.int64), np.clip(want, 0, info["maxval"])), e["name"]
+        checked += 1
+    assert checked >= 10
