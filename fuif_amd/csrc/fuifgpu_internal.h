@@ -37,7 +37,9 @@ struct ChannelGeom {
     int32_t w, h;
     int32_t hshift, vshift, hcshift, vcshift;
     int32_t component;
-    int32_t pad;
+    int32_t ctor_data; // 1: the reference's Channel owns w*h zero samples before decoding (Image constructor planes, palette /
+                       // match meta-channels; image.h:64-65), so rows a truncated stream never reaches stay 0; 0: the plane is
+                       // created by Channel::resize() at decode time, which fills with Channel::zero (image.h:73-75)
     int64_t coef_off;  // element offset of the plane inside one image's coefficient slab
 };
 

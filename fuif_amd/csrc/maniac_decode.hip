@@ -634,7 +634,8 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                     }
                     publish(i, (uint32_t)y + 2u);
                 }
-                if (y < gh) { fill_plane<kHandOff>(plane, (int64_t)y * gw, (int64_t)(gh - y) * gw, zero, lane); status |= ST_TRUNCATED; }
+                // rows the stream never reached: Channel::resize() (encoding.cpp:338) only fills planes it creates
+                if (y < gh) { fill_plane<kHandOff>(plane, (int64_t)y * gw, (int64_t)(gh - y) * gw, rfl(geom[i].ctor_data) ? 0 : zero, lane); status |= ST_TRUNCATED; }
                 if (lane == 0) st_agent(&meta[i].decoded, 1);
                 publish(i, (uint32_t)gh + 1u);
                 if (s_limit_hit(s)) break;
@@ -986,7 +987,9 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 };
                 if (predictor == 0) rows(std::true_type{}); else rows(std::false_type{});
             }
-            if (y < h) { __syncthreads(); fill_plane<kHandOff>(plane, (int64_t)y * w, (int64_t)(h - y) * w, zero, lane); status |= ST_TRUNCATED; }
+            // rows the stream never reached keep what Channel::resize() (encoding.cpp:368) left there: `zero` in a plane
+            // it created, the constructor's 0 in a plane that already had its samples (image.h:64-65,73-75)
+            if (y < h) { __syncthreads(); fill_plane<kHandOff>(plane, (int64_t)y * w, (int64_t)(h - y) * w, rfl(geom[i].ctor_data) ? 0 : zero, lane); status |= ST_TRUNCATED; }
             if (lane == 0) st_agent(&meta[i].decoded, 1);
             publish(i, (uint32_t)h + 1u);
             if (s_limit_hit(s)) break;

@@ -764,6 +764,7 @@ int parse_and_plan(const uint8_t *blob, size_t n, Plan &plan) {
         ChannelGeom g{};
         g.w = ch.w; g.h = ch.h; g.hshift = ch.hshift; g.vshift = ch.vshift; g.hcshift = ch.hcshift; g.vcshift = ch.vcshift;
         g.component = ch.component;
+        g.ctor_data = ch.ctor_data ? 1 : 0;
         g.coef_off = off;
         off += align_up((int64_t)ch.w * ch.h, kPlaneAlign);
         plan.coded.push_back(g);

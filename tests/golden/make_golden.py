@@ -53,6 +53,9 @@ SPECS = [
     ("rgb8_96x96_nosqueeze", dict(w=96, h=96, channels=3, bits=8, seed=9), ["-R", "0"]),
     ("rgb8_tall_40x200", dict(w=40, h=200, channels=3, bits=8, seed=10), []),
     ("rgb8_smooth_256x256", dict(w=256, h=256, channels=3, bits=8, seed=11, sigma=0.0), []),
+    # no Squeeze: the planes are the Image constructor's (already hold w*h zeros), and the channel range excludes 0 --
+    # the rows a truncated stream never reaches stay 0, not Channel::zero (encoding.cpp:368, image.h:64-65,73-75)
+    ("gray8_nosqueeze_60x40", dict(w=60, h=40, channels=1, bits=8, seed=14), ["-R", "0"]),
 ]
 # screen content / sparse histograms with DEFAULT CLI flags: the reference picks Palette (transform/palette.h)
 # by itself (fuif.cpp:399-427); -A k,q adds Approximate (transform/approximate.h) on the last k channels
@@ -79,7 +82,8 @@ ANIM_SPECS = [
 PREVIEWS = {"c1_rgb8_512x512": [0, 1, 2, 3, 4], "rgb8_97x61": [0, 2, 4], "jpeg420_256x192_q90": [0, 1, 2, 3, 4],
             "pal_rgb_graphic_120x90": [1, 3], "approx_rgb8_96x80_A3": [2]}
 TRUNCATE = {"rgb8_97x61": [0.2, 0.55, 0.93], "rgb8_128x128_I0": [0.5], "jpeg420_256x192_q90": [0.4], "rgb8_64x64_U": [0.6],
-            "pal_rgba_graphic_72x64": [0.5], "pal_rgb_sparse_128x96": [0.7]}
+            "pal_rgba_graphic_72x64": [0.5], "pal_rgb_sparse_128x96": [0.7],
+            "gray8_nosqueeze_60x40": [0.6], "rgb8_96x96_nosqueeze": [0.45]}
 
 
 def main():

@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the kernels (on the CPU wavefront emulator) against the oracle, over streams written by
+the REAL reference CLI with random encoder options -- build container only (needs oracle/_ref and
+tests/_emu/libfuifgpu_emu.so, see tests/test_emulated_kernels.py).
+
+  python tools/emu_fuzz.py [n_cases] [seed]
+
+Every case: random small image (photographic / posterised / screen content; 1, 3 or 4 channels; 8 or 12-14 bit),
+random flags from {-P predictors, -E max properties, -G group size, -U, -R 0, -Q quality, -C colourspace, -K/-X/-Y
+palettes, -A approximate, -J DCT}; full decode, a random preview and a random truncation; coefficient planes,
+final planes and status must equal the oracle's.  Streams the planner does not take (FUIFGPU_E_UNSUPPORTED) are counted."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("FUIF_AMD_LIB", os.path.join(ROOT, "tests", "_emu", "libfuifgpu_emu.so"))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import fuif_amd  # noqa: E402
+from fuif_amd.synth import graphic, photographic, write_pnm  # noqa: E402
+from oracle_py import Port, run_ref_cli  # noqa: E402
+
+
+def random_case(rng, tmp):
+    ch = int(rng.choice([1, 3, 3, 3, 4]))
+    bits = int(rng.choice([8, 8, 8, 12, 14]))
+    w, h = int(rng.integers(9, 90)), int(rng.integers(9, 80))
+    kind = int(rng.integers(0, 4))
+    if kind == 0:
+        img = graphic(w, h, ch, bits, seed=int(rng.integers(1 << 30)), colors=int(rng.integers(2, 60)), step=int(rng.choice([1, 1, 3, 8])))
+    else:
+        img = photographic(w, h, ch, bits, seed=int(rng.integers(1 << 30)), sigma=float(rng.choice([0.0, 1.0, 3.0])) if bits == 8 else None)
+        if kind == 1:
+            img = img // 8 * 8
+    flags = []
+    if rng.random() < 0.5:
+        flags += ["-P", "".join(str(int(rng.integers(0, 7))) for _ in range(int(rng.integers(1, 4))))]
+    if rng.random() < 0.5:
+        flags += ["-E", str(int(rng.choice([0, 2, 4, 6, 12, 16])))]
+    if rng.random() < 0.3:
+        flags += ["-G", str(int(rng.integers(1, 6)))]
+    if rng.random() < 0.1:
+        flags += ["-U"]
+    if rng.random() < 0.25:
+        flags += ["-R", "0"]
+    if rng.random() < 0.3:
+        flags += ["-Q", str(int(rng.integers(30, 100)))]
+    if ch >= 3 and rng.random() < 0.3:
+        flags += ["-C", str(int(rng.choice([0, 1, 2])))]
+    if rng.random() < 0.3:
+        flags += ["-K", str(int(rng.choice([0, 16, 256, 1024])))]
+    if rng.random() < 0.3:
+        flags += ["-X", str(int(rng.choice([0, 30, 90]))), "-Y", str(int(rng.choice([0, 30, 90])))]
+    if rng.random() < 0.15:
+        flags += ["-A", "%d,%d" % (int(rng.integers(1, 4)), int(rng.integers(1, 6)))]
+    if bits == 8 and ch == 3 and rng.random() < 0.1:
+        flags += ["-J"]
+    flags += ["-I", str(rng.choice(["0", "0.5", "1"]))]
+    src = os.path.join(tmp, "in." + ("pam" if ch in (2, 4) else "ppm" if ch == 3 else "pgm"))
+    out = os.path.join(tmp, "out.fuif")
+    write_pnm(src, img, (1 << bits) - 1)
+    if os.path.exists(out):
+        os.remove(out)
+    r = run_ref_cli(flags + [src, out])
+    if r.returncode != 0 or not os.path.exists(out):
+        return flags, None
+    return flags, open(out, "rb").read()
+
+
+def compare(port, blob, preview):
+    plan = fuif_amd.Plan(blob)
+    batch = fuif_amd.Batch(plan, 1, len(blob))
+    try:
+        batch.upload([blob], preview)
+        batch.decode()
+        batch.sync()
+        st, used = batch.status()
+        pre = batch.coef_planes(0)
+        batch.undo_transforms()
+        batch.sync()
+        post = batch.out_planes(0)
+    finally:
+        batch.close()
+    a, b = port.decode_both(blob, preview=preview)
+    if not a.ok:
+        return "oracle refused"
+    if st[0] & 2:
+        return "kernel says corrupt"
+    for i, (g, c) in enumerate(zip(pre, a.channels)):
+        if c["size"] == c["w"] * c["h"] and not np.array_equal(g, c["data"]):
+            return "coefficient plane %d differs" % i
+    if len(post) != len(b.channels):
+        return "channel count after undo differs"
+    for i, (g, c) in enumerate(zip(post, b.channels)):
+        if not np.array_equal(g, c["data"]):
+            return "final plane %d differs" % i
+    return None
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    port = Port()
+    tmp = tempfile.mkdtemp()
+    done = unsupported = failed_encode = 0
+    bad = []
+    for k in range(n):
+        flags, blob = random_case(rng, tmp)
+        if blob is None:
+            failed_encode += 1
+            continue
+        try:
+            cases = [(blob, -1), (blob, int(rng.integers(0, 5))), (blob[: int(len(blob) * rng.uniform(0.15, 0.95))], -1)]
+            for bl, pv in cases:
+                err = compare(port, bl, pv)
+                if err:
+                    bad.append((k, flags, len(bl), pv, err))
+                    keep = os.path.join(ROOT, "gpurun_out", "emu_fuzz_case_%d_%d.fuif" % (seed, k))
+                    os.makedirs(os.path.dirname(keep), exist_ok=True)
+                    open(keep, "wb").write(bl)
+                    print("MISMATCH case %d flags %s bytes %d preview %d: %s -> %s" % (k, flags, len(bl), pv, err, keep), flush=True)
+            done += 1
+        except fuif_amd.FuifGpuError as e:
+            if e.code == 3:
+                unsupported += 1
+            else:
+                bad.append((k, flags, len(blob), -1, str(e)))
+                print("ERROR case %d flags %s: %s" % (k, flags, e), flush=True)
+        if (k + 1) % 20 == 0:
+            print("%d cases: %d compared, %d unsupported, %d encoder refusals, %d mismatches" % (k + 1, done, unsupported, failed_encode, len(bad)), flush=True)
+    print("done: %d compared, %d unsupported, %d encoder refusals, %d mismatches" % (done, unsupported, failed_encode, len(bad)))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
