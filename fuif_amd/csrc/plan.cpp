@@ -68,6 +68,8 @@ struct ProtoOp {
     int p0 = 0, p1 = 0;
     std::vector<int> list;    // OP_IDCT: 64 source planes; OP_QUANT: planes to scale
     std::vector<int> list_q;  // OP_QUANT: Channel::q source of each listed plane at the time of the op
+    int src_q[3] = {-2, -2, -2};  // Channel::q source of src[k] AT THE TIME OF THE OP (-2: whatever the plane carries at the end);
+                                  // a later Quantize inverse resets q (quantize.h:47), which must not leak back into earlier ops
 };
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
@@ -502,6 +504,7 @@ struct Builder {
             int idx = (int)ops.size();
             op.src[0] = op.dst[0] = ch.plane; op.src[1] = chr.plane;
             op.p0 = q; op.p1 = chr.ctor_data ? 1 : 0;
+            op.src_q[0] = planes[ch.plane].qsrc; op.src_q[1] = planes[chr.plane].qsrc;
             touch(ch.plane, idx); touch(chr.plane, idx);
             ops.push_back(op);
         }
@@ -522,6 +525,7 @@ struct Builder {
         op.kind = OP_MATCH;
         int idx = (int)ops.size();
         op.src[0] = m.plane;
+        op.src_q[0] = planes[m.plane].qsrc;
         touch(m.plane, idx);
         for (int c = c0; c <= cn; c++) {
             if (live[c].w != w || live[c].h != h) return fail(FUIFGPU_E_UNSUPPORTED, "match over channels of different sizes");
@@ -626,7 +630,10 @@ struct Builder {
             op.clamp_out = clamp_fused[k];
             op.lo = plan.minval; op.hi = plan.maxval;
             op.p0 = po.p0; op.p1 = po.p1;
-            for (int d = 0; d < 3; d++) { op.src[d] = ref(po.src[d]); op.dst[d] = ref(po.dst[d]); }
+            for (int d = 0; d < 3; d++) {
+                op.src[d] = ref(po.src[d]); op.dst[d] = ref(po.dst[d]);
+                if (po.src_q[d] != -2) op.src[d].qsrc = po.src_q[d];
+            }
             op.idct_first = (int)plan.idct_src.size();
             op.pad = (int)po.list.size();
             for (size_t li = 0; li < po.list.size(); li++) {
