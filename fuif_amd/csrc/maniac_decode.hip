@@ -876,7 +876,10 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                         // rx = min((x<<hshift)>>ref.hshift, ref.w-1) covers the three cases of context_predict.h:241-284
                                         const RefChan rc = sh.refs[k];
                                         int ry = (y << gvs) >> rc.vshift; if (ry >= rc.h) ry = rc.h - 1;
-                                        int rx = (x << ghs) >> rc.hshift; if (rx >= rc.w) rx = rc.w - 1;
+                                        // a meta-channel (hshift -1) coded AFTER ordinary channels (Approximate on a palette, approximate.h:76)
+                                        // takes the `ch.hshift < rc.hshift` branch with stepsize (1<<rc.hshift) >> -1, which the reference's
+                                        // x86 build evaluates as 0: every x then reads the LAST sample of the reference row (:253-262)
+                                        int rx = ghs < 0 ? rc.w - 1 : (x << ghs) >> rc.hshift; if (rx >= rc.w) rx = rc.w - 1;
                                         const int v = ld_plane<kHandOff>(coef + rc.off + (int64_t)ry * rc.w + rx);
                                         cp[2 * k] = iabs(v); cp[2 * k + 1] = slog(v);
                                     }

@@ -592,7 +592,9 @@ static void precompute_references(const fo_channel *ch, int y, const fo_image *i
         if (ch->hshift == rc->hshift && ch->w <= rc->w) {
             for (int x = 0; x < ch->w; x++) { int v = row[x]; refs[x * nref + offset] = iabs(v); refs[x * nref + offset + 1] = slog(v); }
         } else if (ch->hshift < rc->hshift) {
-            int stepsize = (1 << rc->hshift) >> ch->hshift;
+            /* ch->hshift is -1 for a meta-channel coded after ordinary channels (Approximate on a palette): the reference
+             * shifts by -1 there, which its x86 build evaluates with the count masked to 31, i.e. stepsize 0 */
+            int stepsize = (1 << rc->hshift) >> (ch->hshift & 31);
             int x = 0, rx = 0, v;
             for (; rx < rc->w - 1; rx++) {
                 v = row[rx];

@@ -69,6 +69,9 @@ GRAPHIC_SPECS = [
     # Quantize + Approximate where an approximated channel becomes all zeroes (no q in the stream) while its remainder is
     # not: Channel::q has to come back from the remainder before the Quantize inverse (approximate.h:49-50)
     ("approx_quant_rgb8_40x30", dict(w=40, h=30, channels=3, bits=8, seed=202, photographic=True), ["-Q", "65", "-A", "3,9"]),
+    # 12-bit gray: the CLI compacts the channel into a palette by itself, -A 2 then approximates the palette META-channel too,
+    # whose remainder copy (hshift -1) is coded AFTER an ordinary channel: context_predict.h:253-262 with a negative shift
+    ("approx_on_palette_gray12_24x50", dict(w=24, h=50, channels=1, bits=12, seed=15, photographic=True), ["-R", "0", "-A", "2,4"]),
     ("approx_rgb8_96x80_A3", dict(w=96, h=80, channels=3, bits=8, seed=36, photographic=True), ["-A", "3,3"]),
 ]
 JPEG_SPECS = [
@@ -84,6 +87,7 @@ ANIM_SPECS = [
 ]
 PREVIEWS = {"c1_rgb8_512x512": [0, 1, 2, 3, 4], "rgb8_97x61": [0, 2, 4], "jpeg420_256x192_q90": [0, 1, 2, 3, 4],
             "pal_rgb_graphic_120x90": [1, 3], "approx_rgb8_96x80_A3": [2], "approx_quant_rgb8_40x30": [3]}
+TRUNCATE_EXTRA = {"approx_on_palette_gray12_24x50": [0.8]}
 TRUNCATE = {"rgb8_97x61": [0.2, 0.55, 0.93], "rgb8_128x128_I0": [0.5], "jpeg420_256x192_q90": [0.4], "rgb8_64x64_U": [0.6],
             "pal_rgba_graphic_72x64": [0.5], "pal_rgb_sparse_128x96": [0.7],
             "gray8_nosqueeze_60x40": [0.6], "rgb8_96x96_nosqueeze": [0.45]}
@@ -136,7 +140,7 @@ def main():
                  "source": gen, "cli_flags": cli_flags if not isinstance(flags, dict) else ["<jpeg/anim>", json.dumps(flags)] + cli_flags, "cases": []}
         cases = [("full", -1, len(blob))]
         cases += [("preview%d" % k, k, len(blob)) for k in PREVIEWS.get(name, [])]
-        cases += [("trunc%02d" % int(f * 100), -1, int(len(blob) * f)) for f in TRUNCATE.get(name, [])]
+        cases += [("trunc%02d" % int(f * 100), -1, int(len(blob) * f)) for f in TRUNCATE.get(name, []) + TRUNCATE_EXTRA.get(name, [])]
         for cname, preview, nbytes in cases:
             pre, post = ref.decode_both(blob[:nbytes], preview=preview, io_kind=0)
             entry["cases"].append({"case": cname, "preview": preview, "nbytes": nbytes, "ok": bool(pre.ok),
