@@ -24,7 +24,66 @@ from fuif_amd.synth import graphic, photographic, write_pnm  # noqa: E402
 from oracle_py import Port, run_ref_cli  # noqa: E402
 
 
+def random_jpeg_case(rng, tmp):
+    """JPEG input: the CLI transcodes the DCT coefficients (YCbCr / Subsample / DCT / Quantize [/ Squeeze of DC])"""
+    from PIL import Image
+    ch = int(rng.choice([1, 3, 3]))
+    w, h = int(rng.integers(9, 120)), int(rng.integers(9, 100))
+    img = photographic(w, h, ch, 8, seed=int(rng.integers(1 << 30)), sigma=float(rng.choice([0.0, 1.0, 3.0])))
+    arr = np.moveaxis(img, 0, -1).astype(np.uint8)
+    src = os.path.join(tmp, "in.jpg")
+    kw = dict(quality=int(rng.integers(25, 97)))
+    if ch == 3:
+        kw["subsampling"] = int(rng.choice([0, 1, 2]))
+    Image.fromarray(arr[..., 0] if ch == 1 else arr).save(src, **kw)
+    flags = []
+    if rng.random() < 0.3:
+        flags += ["-R", "0"]
+    if rng.random() < 0.3:
+        flags += ["-E", str(int(rng.choice([0, 4, 12])))]
+    if rng.random() < 0.3:
+        flags += ["-G", str(int(rng.integers(1, 40)))]
+    flags += ["-I", str(rng.choice(["0", "0.5"]))]
+    out = os.path.join(tmp, "out.fuif")
+    if os.path.exists(out):
+        os.remove(out)
+    r = run_ref_cli(flags + [src, out])
+    if r.returncode != 0 or not os.path.exists(out):
+        return ["jpeg", str(kw)] + flags, None
+    return ["jpeg", str(kw)] + flags, open(out, "rb").read()
+
+
+def random_animation_case(rng, tmp):
+    """a few stacked frames; by default the CLI adds the 2D match against previous frames (fuif.cpp:440)"""
+    w, h, n = int(rng.integers(9, 50)), int(rng.integers(9, 40)), int(rng.integers(2, 5))
+    base = photographic(w, h, 3, 8, seed=int(rng.integers(1 << 30)))
+    for i in range(n):
+        fr = photographic(w, h, 3, 8, seed=int(rng.integers(1 << 30)))
+        if rng.random() < 0.7:
+            keep = rng.random((h, w)) < 0.8
+            fr = np.where(keep[None], base, fr)
+        write_pnm(os.path.join(tmp, "fr-%02d.ppm" % i), fr, 255)
+    flags = [] if rng.random() < 0.7 else ["-M", "0"]
+    if rng.random() < 0.3:
+        flags += ["-R", "0"]
+    flags += ["-I", "0"]
+    out = os.path.join(tmp, "out.fuif")
+    if os.path.exists(out):
+        os.remove(out)
+    r = run_ref_cli(flags + [os.path.join(tmp, "fr-%02d.ppm"), out])
+    for i in range(n):
+        os.remove(os.path.join(tmp, "fr-%02d.ppm" % i))
+    if r.returncode != 0 or not os.path.exists(out):
+        return ["anim%d" % n] + flags, None
+    return ["anim%d" % n] + flags, open(out, "rb").read()
+
+
 def random_case(rng, tmp):
+    pick = rng.random()
+    if pick < 0.2:
+        return random_jpeg_case(rng, tmp)
+    if pick < 0.3:
+        return random_animation_case(rng, tmp)
     ch = int(rng.choice([1, 3, 3, 3, 4]))
     bits = int(rng.choice([8, 8, 8, 12, 14]))
     w, h = int(rng.integers(9, 90)), int(rng.integers(9, 80))
@@ -70,18 +129,32 @@ def random_case(rng, tmp):
     return flags, open(out, "rb").read()
 
 
-def compare(port, blob, preview):
+def compare(port, blob, preview, with_index=False):
     plan = fuif_amd.Plan(blob)
-    batch = fuif_amd.Batch(plan, 1, len(blob))
+    batch = fuif_amd.Batch(plan, 1, len(blob) + 4096)
     try:
         batch.upload([blob], preview)
         batch.decode()
         batch.sync()
         st, used = batch.status()
         pre = batch.coef_planes(0)
+        groups = batch.group_index(0)
         batch.undo_transforms()
         batch.sync()
         post = batch.out_planes(0)
+        if with_index and len(groups) > 1:
+            # the same stream, one tile per channel group: must give the same planes
+            indexed = fuif_amd.index_append(blob, groups)
+            batch.upload([indexed], preview)
+            batch.decode()
+            batch.sync()
+            st2, _ = batch.status()
+            pre2 = batch.coef_planes(0)
+            batch.undo_transforms()
+            batch.sync()
+            post2 = batch.out_planes(0)
+            if st2[0] != st[0] or any(not np.array_equal(x, y) for x, y in zip(pre, pre2)) or any(not np.array_equal(x, y) for x, y in zip(post, post2)):
+                return "group-parallel decode differs from the per-image decode"
     finally:
         batch.close()
     a, b = port.decode_both(blob, preview=preview)
@@ -121,7 +194,7 @@ def main():
                     f.write(bl)
                 with open(os.path.join(tmp, "current.txt"), "w") as f:
                     f.write("case %d flags %s preview %d bytes %d\n" % (k, flags, pv, len(bl)))
-                err = compare(port, bl, pv)
+                err = compare(port, bl, pv, with_index=len(bl) == len(blob))
                 if err:
                     bad.append((k, flags, len(bl), pv, err))
                     keep = os.path.join(ROOT, "gpurun_out", "emu_fuzz_case_%d_%d.fuif" % (seed, k))
@@ -132,7 +205,7 @@ def main():
         except fuif_amd.FuifGpuError as e:
             if e.code == 3:
                 unsupported += 1
-            elif e.code == 2 and len(bl) < len(blob) and not port.decode(bl, undo=False).ok:
+            elif e.code in (1, 2) and len(bl) < len(blob) and (len(bl) < 8 or not port.decode(bl, undo=False).ok):
                 done += 1          # a cut inside the header: the oracle refuses it as well
             else:
                 bad.append((k, flags, len(blob), -1, str(e)))
