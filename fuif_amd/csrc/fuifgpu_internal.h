@@ -79,7 +79,11 @@ enum : int {
     OP_UPSAMPLE = 7, OP_COPY_CLAMP = 8, OP_CLAMP = 9,
     OP_PALETTE = 10,   // dst = palette[p0][clamp(index)]: src[0] index plane, src[1] palette plane (p1 colours wide)
     OP_APPROX = 11,    // src[0] = src[0]*p0 + src[1] in place when the remainder src[1] was decoded (p1: it has constructor data)
-    OP_MATCH = 12      // 2D match against previous frames, in place on the listed planes: src[0] match plane, p0 softmatch, p1 frame height
+    OP_MATCH = 12,     // 2D match against previous frames, in place on the listed planes: src[0] match plane, p0 softmatch, p1 frame height
+    // 2D match with free offsets (2dmatch.h:136-146), exact matches only: source map by pointer jumping
+    OP_MATCH_INIT = 13,   // dst[0] = linear index every sample copies from (itself / -1 = before the first sample); src[0] match plane, p0 softmatch
+    OP_MATCH_JUMP = 14,   // dst[0][p] = src[0][src[0][p]]: one doubling step; src[1] match plane (mode check)
+    OP_MATCH_APPLY = 15   // listed planes[p] = planes[src[0][p]] in place; src[1] match plane (mode check)
 };
 struct Op {
     int32_t kind;

@@ -535,7 +535,42 @@ struct Builder {
         if (m.w != w || m.h != h) return fail(FUIFGPU_E_UNSUPPORTED, "match channel geometry differs from the matched channels");
         op.p0 = params[2] ? 1 : 0;
         op.p1 = h / std::max(1, plan.nb_frames);
-        if ((int64_t)w * h > 0) ops.push_back(op);
+        if ((int64_t)w * h > 0) {
+            ops.push_back(op);
+            // free-offset mode (match channel q == 1): every sample copies from an EARLIER sample in scan order, which may
+            // itself be a copy.  The chains are resolved with pointer jumping on a map of linear source indices:
+            // ceil(log2(samples)) doubling steps, then one gather per matched plane.  In the other mode these ops return at once.
+            const std::vector<int> channel_planes = op.list;
+            const int mq = op.src_q[0];
+            int steps = 1;
+            while ((1LL << steps) < (int64_t)w * h) steps++;
+            ProtoOp init;
+            init.kind = OP_MATCH_INIT;
+            int k = (int)ops.size();
+            init.src[0] = m.plane; init.src_q[0] = mq; init.p0 = op.p0;
+            int cur = new_plane(w, h, -1, k);
+            init.dst[0] = cur;
+            touch(m.plane, k);
+            ops.push_back(init);
+            int other = -1;
+            for (int sidx = 0; sidx < steps; sidx++) {
+                ProtoOp j;
+                j.kind = OP_MATCH_JUMP;
+                k = (int)ops.size();
+                if (other < 0) other = new_plane(w, h, -1, k);
+                j.src[0] = cur; j.src[1] = m.plane; j.src_q[1] = mq; j.dst[0] = other;
+                touch(cur, k); touch(other, k); touch(m.plane, k);
+                ops.push_back(j);
+                std::swap(cur, other);
+            }
+            ProtoOp ap;
+            ap.kind = OP_MATCH_APPLY;
+            k = (int)ops.size();
+            ap.src[0] = cur; ap.src[1] = m.plane; ap.src_q[1] = mq; ap.list = channel_planes;
+            touch(cur, k); if (other >= 0) touch(other, k); touch(m.plane, k);
+            for (int pl : channel_planes) touch(pl, k);
+            ops.push_back(ap);
+        }
         nb_meta--;
         live.erase(live.begin());
         return true;
@@ -548,7 +583,7 @@ struct Builder {
         for (int k = 0; k < nops_before; k++) {
             const ProtoOp &op = ops[k];
             for (int d = 0; d < 3; d++) if (op.dst[d] >= 0) { last_writer[op.dst[d]] = k; last_kind[op.dst[d]] = op.kind; }
-            if (op.kind == OP_QUANT || op.kind == OP_MATCH) for (int pl : op.list) { last_writer[pl] = k; last_kind[pl] = op.kind; }
+            if (op.kind == OP_QUANT || op.kind == OP_MATCH || op.kind == OP_MATCH_APPLY) for (int pl : op.list) { last_writer[pl] = k; last_kind[pl] = op.kind; }
         }
         // final planes that are still coded planes need a copy into OUT
         for (auto &ch : live) {

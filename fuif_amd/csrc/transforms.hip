@@ -241,14 +241,14 @@ __global__ __launch_bounds__(256) void k_inv_approx(Bases b, PlaneRef pc, PlaneR
 // stacked vertically, z = m(y,x) != 0 means "equal to (soft: add) the sample z frames up".  One lane per column,
 // serial down the rows (a source may itself be a matched sample of an earlier frame).  Channel::value() only
 // checks the linear index (image.h:82-85): a source before the first sample reads Channel::zero.
-// The general mode (q == 1: offsets into the causal neighbourhood, :136-146) is not built; such an image is
-// flagged FUIFGPU_ST_UNSUPPORTED and left unmatched.
+// The free-offset mode (q == 1) is handled by k_match_init / k_match_jump / k_match_apply below.
 __global__ __launch_bounds__(256) void k_inv_match_frames(Bases b, PlaneRef pm, const PlaneRef *list, int n_list, int softmatch, int fh,
                                                           const ChannelMeta *meta, int n_channels, int img_first, int32_t *status) {
     const int z_img = blockIdx.z;
     const int q = (meta && pm.qsrc >= 0) ? meta[(int64_t)(img_first + z_img) * n_channels + pm.qsrc].q : 0;
     if (q != 2 * fh * fh + (fh & 1)) {
-        if (status && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&status[img_first + z_img], q == 1 ? ST_UNSUPPORTED : (ST_UNSUPPORTED | ST_CORRUPT));
+        // q == 1 is the free-offset mode (next kernels); anything else the reference refuses (2dmatch.h:172-175)
+        if (q != 1 && status && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&status[img_first + z_img], ST_UNSUPPORTED | ST_CORRUPT);
         return;
     }
     const int w = pm.w, h = pm.h;
@@ -264,6 +264,87 @@ __global__ __launch_bounds__(256) void k_inv_match_frames(Bases b, PlaneRef pm, 
             int32_t *p = plane_ptr(b, list[k], z_img);
             const int sv = inside ? p[src] : 0;
             p[(int64_t)y * w + x] = softmatch ? p[(int64_t)y * w + x] + sv : sv;
+        }
+    }
+}
+
+// ---- 2D match with free offsets (transform/2dmatch.h:136-146, match channel q == 1) --------------------------
+// Reference semantics: in scan order, z = m(y,x) != 0 means value(y,x) = value(y+oy, x+ox) with (ox,oy) = the z-th
+// position of a spiral through the already decoded neighbourhood (:33-78) -- the source may itself be a copy.
+// Channel::value() only checks the LINEAR index (image.h:82-85), so the source is sample p + oy*w + ox, and a
+// source before the first sample reads Channel::zero.  Parallel form: S[p] = p for unmatched samples, else the
+// source index; ceil(log2(n)) rounds of S[p] = S[S[p]] make every S[p] a root; one gather finishes the job.
+// Soft matches (value += source, never written by the CLI, fuif.cpp:445) and forward references (only possible in
+// images narrower than the spiral) are flagged FUIFGPU_ST_UNSUPPORTED and the image is left unmatched.
+DEV void match_offset(int code, int &xo, int &yo) {   // 2dmatch.h:50-78
+    int layer = 0, size = 4;
+    while (code > size) { code -= size; layer++; size += 4; }
+    if (layer & 1) {
+        if (code <= layer) { xo = 1 + layer; yo = -code; }
+        else if (code <= 3 + 3 * layer) { xo = 2 + 2 * layer - code; yo = -1 - layer; }
+        else { xo = -1 - layer; yo = -4 - 4 * layer + code; }
+    } else {
+        if (code <= 1 + layer) { xo = -1 - layer; yo = 1 - code; }
+        else if (code <= 4 + 3 * layer) { xo = -3 - 2 * layer + code; yo = -1 - layer; }
+        else { xo = 1 + layer; yo = -5 - 4 * layer + code; }
+    }
+}
+DEV bool match_free_mode(const PlaneRef &pm, const ChannelMeta *meta, int n_channels, int img) {
+    return meta && pm.qsrc >= 0 && meta[(int64_t)img * n_channels + pm.qsrc].q == 1;
+}
+__global__ __launch_bounds__(256) void k_match_init(Bases b, PlaneRef pm, PlaneRef ps, int softmatch, const ChannelMeta *meta, int n_channels,
+                                                    int img_first, int32_t *status) {
+    const int img = img_first + blockIdx.z;
+    if (!match_free_mode(pm, meta, n_channels, img)) return;
+    const int maxz = meta[(int64_t)img * n_channels + pm.qsrc].maxval;
+    const int w = pm.w;
+    const int64_t n = (int64_t)pm.w * pm.h;
+    const int32_t *m = plane_ptr(b, pm, blockIdx.z);
+    int32_t *S = plane_ptr(b, ps, blockIdx.z);
+    int flag = 0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const int z = m[p];
+        int64_t s = p;
+        if (z) {
+            if (softmatch) flag |= ST_UNSUPPORTED;
+            else if (z < 0 || z > maxz) flag |= ST_UNSUPPORTED | ST_CORRUPT;   // offsets_table[z] out of range in the reference
+            else {
+                int xo, yo;
+                match_offset(z, xo, yo);
+                const int64_t src = p + (int64_t)yo * w + xo;
+                if (src < 0 || src >= n) s = -1;
+                else if (src > p) flag |= ST_UNSUPPORTED;                        // would read a sample that is rewritten later
+                else s = src;
+            }
+        }
+        S[p] = (int32_t)s;
+    }
+    if (flag && status) atomicOr(&status[img], flag);
+}
+__global__ __launch_bounds__(256) void k_match_jump(Bases b, PlaneRef pm, PlaneRef pin, PlaneRef pout, const ChannelMeta *meta, int n_channels,
+                                                    int img_first) {
+    if (!match_free_mode(pm, meta, n_channels, img_first + blockIdx.z)) return;
+    const int64_t n = (int64_t)pin.w * pin.h;
+    const int32_t *S = plane_ptr(b, pin, blockIdx.z);
+    int32_t *T = plane_ptr(b, pout, blockIdx.z);
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const int s = S[p];
+        T[p] = s >= 0 ? S[s] : s;
+    }
+}
+__global__ __launch_bounds__(256) void k_match_apply(Bases b, PlaneRef pm, PlaneRef ps, const PlaneRef *list, int n_list, const ChannelMeta *meta,
+                                                     int n_channels, int img_first, const int32_t *status) {
+    const int img = img_first + blockIdx.z;
+    if (!match_free_mode(pm, meta, n_channels, img)) return;
+    if (status && (status[img] & ST_UNSUPPORTED)) return;   // flagged by k_match_init: leave the planes alone
+    const int64_t n = (int64_t)ps.w * ps.h;
+    const int32_t *S = plane_ptr(b, ps, blockIdx.z);
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const int s = S[p];
+        if (s == p) continue;                                // roots are never written: the gather below only reads roots
+        for (int k = 0; k < n_list; k++) {
+            int32_t *pl = plane_ptr(b, list[k], blockIdx.z);
+            pl[p] = s < 0 ? 0 : pl[s];
         }
     }
 }
@@ -440,6 +521,21 @@ void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMe
             if (!meta || op.src[0].w <= 0) break;
             hipLaunchKernelGGL(k_inv_match_frames, dim3((op.src[0].w + 255) / 256, 1, n_images), dim3(256), 0, stream, b, op.src[0],
                                dev_list + op.idct_first, op.pad, op.p0, op.p1, meta, n_channels, img_first, status);
+            break;
+        case OP_MATCH_INIT:
+            if (!meta || (int64_t)op.dst[0].w * op.dst[0].h <= 0) break;
+            hipLaunchKernelGGL(k_match_init, grid1d((int64_t)op.dst[0].w * op.dst[0].h, 256, n_images), dim3(256), 0, stream, b, op.src[0], op.dst[0],
+                               op.p0, meta, n_channels, img_first, status);
+            break;
+        case OP_MATCH_JUMP:
+            if (!meta || (int64_t)op.dst[0].w * op.dst[0].h <= 0) break;
+            hipLaunchKernelGGL(k_match_jump, grid1d((int64_t)op.dst[0].w * op.dst[0].h, 256, n_images), dim3(256), 0, stream, b, op.src[1], op.src[0],
+                               op.dst[0], meta, n_channels, img_first);
+            break;
+        case OP_MATCH_APPLY:
+            if (!meta || (int64_t)op.src[0].w * op.src[0].h <= 0) break;
+            hipLaunchKernelGGL(k_match_apply, grid1d((int64_t)op.src[0].w * op.src[0].h, 256, n_images), dim3(256), 0, stream, b, op.src[1], op.src[0],
+                               dev_list + op.idct_first, op.pad, meta, n_channels, img_first, status);
             break;
         case OP_APPROX:
             if (!meta || (int64_t)op.dst[0].w * op.dst[0].h <= 0) break;

@@ -64,6 +64,9 @@ GRAPHIC_SPECS = [
     ("pal_rgba_graphic_72x64", dict(w=72, h=64, channels=4, bits=8, seed=32, colors=20), []),
     ("pal_gray_sparse_100x70", dict(w=100, h=70, channels=1, bits=8, seed=33, colors=24, step=5), []),
     ("pal_rgb_sparse_128x96", dict(w=128, h=96, channels=3, bits=8, seed=34, colors=700, step=8), []),
+    # -M n on a still: 2D match with free offsets into the already decoded neighbourhood (2dmatch.h:136-146), after a palette
+    ("match_rgb_graphic_96x80", dict(w=96, h=80, channels=3, bits=8, seed=51, colors=400), ["-M", "40"]),
+    ("match_rgb_graphic_nosqueeze_72x60", dict(w=72, h=60, channels=3, bits=8, seed=53, colors=300), ["-M", "200", "-K", "0", "-R", "0"]),
     ("pal_rgb_graphic_nosqueeze_64x48", dict(w=64, h=48, channels=3, bits=8, seed=35, colors=12), ["-R", "0"]),
     ("pal_rgb_channelwise_96x72", dict(w=96, h=72, channels=3, bits=8, seed=37, poster=8), []),
     # Quantize + Approximate where an approximated channel becomes all zeroes (no q in the stream) while its remainder is
@@ -86,8 +89,8 @@ ANIM_SPECS = [
     ("anim4_match_40x28", dict(w=40, h=28, channels=3, bits=8, seed=710, static=True), dict(frames=4, match=True)),
 ]
 PREVIEWS = {"c1_rgb8_512x512": [0, 1, 2, 3, 4], "rgb8_97x61": [0, 2, 4], "jpeg420_256x192_q90": [0, 1, 2, 3, 4],
-            "pal_rgb_graphic_120x90": [1, 3], "approx_rgb8_96x80_A3": [2], "approx_quant_rgb8_40x30": [3]}
-TRUNCATE_EXTRA = {"approx_on_palette_gray12_24x50": [0.8]}
+            "pal_rgb_graphic_120x90": [1, 3], "approx_rgb8_96x80_A3": [2], "approx_quant_rgb8_40x30": [3], "match_rgb_graphic_96x80": [3]}
+TRUNCATE_EXTRA = {"approx_on_palette_gray12_24x50": [0.8], "match_rgb_graphic_96x80": [0.6]}
 TRUNCATE = {"rgb8_97x61": [0.2, 0.55, 0.93], "rgb8_128x128_I0": [0.5], "jpeg420_256x192_q90": [0.4], "rgb8_64x64_U": [0.6],
             "pal_rgba_graphic_72x64": [0.5], "pal_rgb_sparse_128x96": [0.7],
             "gray8_nosqueeze_60x40": [0.6], "rgb8_96x96_nosqueeze": [0.45]}

@@ -117,6 +117,8 @@ def random_case(rng, tmp):
         flags += ["-A", "%d,%d" % (int(rng.integers(1, 4)), int(rng.integers(1, 6)))]
     if bits == 8 and ch == 3 and rng.random() < 0.1:
         flags += ["-J"]
+    if rng.random() < 0.2:
+        flags += ["-M", str(int(rng.choice([3, 20, 100, 1000])))]
     flags += ["-I", str(rng.choice(["0", "0.5", "1"]))]
     src = os.path.join(tmp, "in." + ("pam" if ch in (2, 4) else "ppm" if ch == 3 else "pgm"))
     out = os.path.join(tmp, "out.fuif")
