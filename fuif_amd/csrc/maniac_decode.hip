@@ -139,7 +139,7 @@ struct Node {  // maniac/compound.h:41-51; property -1 = leaf, child = leaf id
 // One 64-bit load per tree level.  hipcc otherwise splits the node into two dependent 32-bit
 // loads (it sinks the splitval load behind the leaf test), doubling the per-level latency.
 #ifdef FUIF_EMU
-static const char *emu_lds_base;   // LDS byte addresses are offsets from the supernode array in the emulator
+static thread_local const char *emu_lds_base;   // LDS byte addresses are offsets from the supernode array in the emulator
 DEV uint2 lds_load_node(uint32_t lds_byte_addr) { return *reinterpret_cast<const uint2 *>(emu_lds_base + lds_byte_addr); }
 DEV uint2 global_load_node(const void *p) { return *reinterpret_cast<const uint2 *>(p); }
 #else

@@ -29,7 +29,7 @@ def build_emulated_library():
                                                                os.path.join(ROOT, "include", "fuifgpu.h")]
     if os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(d) for d in deps):
         return EMU_LIB
-    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DFUIF_EMU", "-ffp-contract=off", "-Wno-attributes",
+    cmd = ["g++", "-std=c++17", "-O2", "-pthread", "-fPIC", "-shared", "-DFUIF_EMU", "-ffp-contract=off", "-Wno-attributes",
            "-I", os.path.join(ROOT, "tools", "emu"), "-x", "c++"] + [os.path.join(CSRC, s) for s in SOURCES] + \
           [os.path.join(ROOT, "tools", "emu", "emu_runtime.cpp"), "-o", EMU_LIB]
     subprocess.check_call(cmd)
@@ -49,6 +49,28 @@ SELECTED = [
     "tests/test_gpu_group_parallel.py::test_truncated_indexed_stream_falls_back_and_side_index_on_truncated_blob",
     "tests/test_fuzz.py::test_gpu_agrees_with_oracle_on_corrupt_payload",
 ]
+
+
+CONCURRENT = [
+    "tests/test_gpu_group_parallel.py::test_reference_written_files_indexed_after_the_fact",
+    "tests/test_gpu_group_parallel.py::test_mixed_batch_with_more_tiles_than_wavefronts",
+    "tests/test_gpu_group_parallel.py::test_jpeg_like_indexed",
+]
+
+
+def test_tile_hand_off_with_concurrent_emulated_wavefronts():
+    """the same group-parallel tests with FOUR persistent wavefronts running at once (one OS thread each, EMU_WAVES /
+    EMU_THREADS): tiles really wait for each other's headers and rows here.  x86 is more strongly ordered than the
+    GPU, so this checks the LOGIC of the protocol (who publishes what, every exit path, no deadlock), not its fences."""
+    if sys.platform != "linux" or os.uname().machine != "x86_64":
+        pytest.skip("the emulator's context switch is x86-64 SysV assembly")
+    lib = build_emulated_library()
+    env = dict(os.environ)
+    env.update(FUIF_AMD_LIB=lib, FUIF_TEST_MAX_PIXELS="50000", FUIF_TEST_BATCH="12", EMU_ALARM="1500", EMU_WAVES="4", EMU_THREADS="4")
+    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + CONCURRENT
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1700)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
 
 
 def test_gpu_parity_tests_pass_on_the_wavefront_emulator():

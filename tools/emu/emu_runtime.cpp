@@ -1,8 +1,11 @@
 // tools/emu/emu_runtime.cpp -- fiber scheduler behind tools/emu/hip/hip_runtime.h (TEST INFRASTRUCTURE).
 // x86-64 SysV only: a 12-instruction context switch keeps a rendezvous of 64 fibers at ~1 us.
+#include <atomic>
 #include <csignal>
 #include <cstdio>
 #include <execinfo.h>
+#include <sched.h>
+#include <thread>
 #include <unistd.h>
 #include <vector>
 
@@ -29,16 +32,20 @@ struct Fiber {
     unsigned tid[3] = {0, 0, 0};
     const void *site = nullptr;   // debugging aid: who called the cross-lane operation this fiber is waiting in
 };
-std::vector<Fiber> fibers;
-void *main_sp = nullptr;
-int cur = -1, n_alive = 0, n_fibers = 0;   // n_fibers: fibers of the running block (the vector only ever grows)
-dim3 g_grid, g_block, g_bidx;
-const std::function<void()> *g_body = nullptr;
+// Everything below is per OS thread: with EMU_THREADS > 1 the workgroups of a launch run on several threads at once
+// (one workgroup at a time per thread, its lanes as fibers of that thread), which is how the tile-to-tile hand-off
+// of the entropy kernel gets real concurrency on a CPU.
+thread_local std::vector<Fiber> fibers;
+thread_local void *main_sp = nullptr;
+thread_local int cur = -1, n_alive = 0, n_fibers = 0;   // n_fibers: fibers of the running block (the vector only ever grows)
+thread_local dim3 g_grid, g_block, g_bidx;
+thread_local const std::function<void()> *g_body = nullptr;
 // generation barrier + double-buffered exchange slots
-int bar_count = 0;
-unsigned long long bar_gen = 0;
-long long slot[2][1024];
-unsigned long long stamp[2][1024];   // generation in which a lane deposited: who took part is fixed at the rendezvous, not when a lane reads
+thread_local int bar_count = 0;
+thread_local unsigned long long bar_gen = 0;
+thread_local long long slot[2][1024];
+thread_local unsigned long long stamp[2][1024];   // generation in which a lane deposited: who took part is fixed at the rendezvous, not when a lane reads
+thread_local bool threaded = false;
 
 void switch_to(int next) {
     int prev = cur;
@@ -93,6 +100,9 @@ unsigned coord(int which) {
 }
 
 void yield() {
+    // s_sleep in a spin loop: every lane of the wavefront comes through here; let other THREADS (= other workgroups,
+    // the producers this one may be waiting for) run once per pass of the wavefront
+    if (threaded && fibers[cur].tid[0] == 0) sched_yield();
     int nx = next_alive(cur);
     if (nx >= 0 && nx != cur) switch_to(nx);
 }
@@ -137,6 +147,31 @@ static void on_alarm(int) {
     }
     _exit(97);
 }
+static void run_block(dim3 grid, dim3 block, dim3 bidx, const std::function<void()> &body) {
+    const unsigned nt = block.x * block.y * block.z;
+    if (fibers.size() < nt) fibers.resize(nt);
+    n_fibers = (int)nt;
+    g_grid = grid; g_block = block; g_body = &body; g_bidx = bidx;
+    n_alive = (int)nt; bar_count = 0;
+    memset(stamp, 0xff, sizeof(stamp));
+    for (unsigned t = 0; t < nt; t++) {
+        Fiber &f = fibers[t];
+        if (!f.stack) f.stack = (char *)malloc(kStack);
+        f.done = false;
+        f.tid[0] = t % block.x; f.tid[1] = (t / block.x) % block.y; f.tid[2] = t / (block.x * block.y);
+        // initial frame: six callee-saved registers (zero) + return address = emu_fiber_main;
+        // after the `ret`, rsp is 16n+8 as the ABI expects at a function's first instruction
+        uintptr_t top = ((uintptr_t)f.stack + kStack) & ~(uintptr_t)15;
+        void **sp = (void **)(top - 8);
+        *--sp = (void *)emu_fiber_main;
+        for (int k = 0; k < 6; k++) *--sp = nullptr;
+        f.sp = sp;
+    }
+    cur = -1;
+    switch_to(0);        // returns when the last fiber of the block has finished
+    g_body = nullptr;
+}
+
 void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
     static bool armed = false;
     if (!armed) {
@@ -145,31 +180,29 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
     }
     const unsigned nt = block.x * block.y * block.z;
     if (nt > 1024 || nt == 0) abort();
-    if (fibers.size() < nt) fibers.resize(nt);
-    n_fibers = (int)nt;
-    g_grid = grid; g_block = block; g_body = &body;
+    const unsigned long long blocks = (unsigned long long)grid.x * grid.y * grid.z;
+    int want = 1;
+    if (const char *e = getenv("EMU_THREADS")) want = atoi(e);
+    if (want > 1 && blocks > 1) {
+        // workgroups on OS threads: block k only starts once a thread is free, in index order (like a GPU's dispatcher)
+        std::atomic<unsigned long long> next{0};
+        const int nthreads = (int)std::min<unsigned long long>((unsigned long long)want, blocks);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; t++)
+            pool.emplace_back([&]() {
+                threaded = true;
+                for (;;) {
+                    const unsigned long long k = next.fetch_add(1);
+                    if (k >= blocks) break;
+                    run_block(grid, block, dim3((unsigned)(k % grid.x), (unsigned)((k / grid.x) % grid.y), (unsigned)(k / ((unsigned long long)grid.x * grid.y))), body);
+                }
+            });
+        for (auto &th : pool) th.join();
+        return;
+    }
+    threaded = false;
     for (unsigned bz = 0; bz < grid.z; bz++)
         for (unsigned by = 0; by < grid.y; by++)
-            for (unsigned bx = 0; bx < grid.x; bx++) {
-                g_bidx = dim3(bx, by, bz);
-                n_alive = (int)nt; bar_count = 0;
-                memset(stamp, 0xff, sizeof(stamp));
-                for (unsigned t = 0; t < nt; t++) {
-                    Fiber &f = fibers[t];
-                    if (!f.stack) f.stack = (char *)malloc(kStack);
-                    f.done = false;
-                    f.tid[0] = t % block.x; f.tid[1] = (t / block.x) % block.y; f.tid[2] = t / (block.x * block.y);
-                    // initial frame: six callee-saved registers (zero) + return address = emu_fiber_main;
-                    // after the `ret`, rsp is 16n+8 as the ABI expects at a function's first instruction
-                    uintptr_t top = ((uintptr_t)f.stack + kStack) & ~(uintptr_t)15;
-                    void **sp = (void **)(top - 8);
-                    *--sp = (void *)emu_fiber_main;
-                    for (int k = 0; k < 6; k++) *--sp = nullptr;
-                    f.sp = sp;
-                }
-                cur = -1;
-                switch_to(0);        // returns when the last fiber of the block has finished
-            }
-    g_body = nullptr;
+            for (unsigned bx = 0; bx < grid.x; bx++) run_block(grid, block, dim3(bx, by, bz), body);
 }
 }  // namespace emu

@@ -5,8 +5,10 @@
 //
 // What it is: every workgroup runs as blockDim.x cooperative fibers on one OS thread; a cross-lane operation
 // (readlane, readfirstlane, ballot, ds_bpermute, __syncthreads) is a rendezvous of all fibers of the workgroup.
-// Workgroups run one after the other, so the entropy kernel is always launched with ONE persistent wavefront
-// (the work list is in dependency order: a tile's producers have finished before it starts).
+// By default workgroups run one after the other and the entropy kernel gets ONE persistent wavefront (the work list
+// is in dependency order: a tile's producers have finished before it starts).  EMU_WAVES=n EMU_THREADS=n runs n
+// persistent wavefronts on n OS threads at once, so tiles really wait for each other (logic of the hand-off; the
+// fences are a GPU matter).
 // What it is NOT: a performance model, a memory-model checker (the tile-to-tile hand-off protocol is only
 // exercised on the GPU), or a product path -- libfuifgpu.so never contains any of this and still fails without a GPU.
 #pragma once
@@ -21,7 +23,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
-#define __shared__ static
+#define __shared__ static thread_local   // one workgroup at a time per OS thread (EMU_THREADS)
 #define __constant__ static
 #define __launch_bounds__(...)
 
@@ -62,12 +64,15 @@ static const emu::Triple threadIdx = {{0}, {1}, {2}}, blockIdx = {{3}, {4}, {5}}
 #define __popcll(x) __builtin_popcountll(x)
 static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 #define __HIP_MEMORY_SCOPE_AGENT 4
-#define __hip_atomic_load(p, order, scope) (*(p))
-#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
-template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
-template <class T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
-template <class T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
-static inline unsigned atomicMax(unsigned *p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_SEQ_CST)
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
+template <class T> static inline T atomicAdd(T *p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+template <class T> static inline T atomicOr(T *p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+template <class T> static inline T atomicMax(T *p, T v) {
+    T o = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+    while (v > o && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+    return o;
+}
 // round-to-nearest without contraction: the emulator is built with -ffp-contract=off
 static inline double __dadd_rn(double a, double b) { return a + b; }
 static inline double __dsub_rn(double a, double b) { return a - b; }
@@ -97,7 +102,8 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char *hipGetErrorString(hipError_t) { return "emulated HIP runtime"; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
-static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 1; return hipSuccess; }
+// EMU_WAVES: persistent wavefronts of the entropy kernel (each becomes a workgroup; run them on EMU_THREADS >= EMU_WAVES threads)
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { const char *e = getenv("EMU_WAVES"); p->multiProcessorCount = e ? std::max(1, atoi(e)) : 1; return hipSuccess; }
 template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, K, int, size_t) { *n = 1; return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
