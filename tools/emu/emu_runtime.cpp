@@ -26,6 +26,15 @@ namespace emu {
 namespace {
 constexpr size_t kStack = 1 << 20;
 struct Fiber {
+    Fiber() = default;
+    Fiber(Fiber &&o) noexcept { *this = std::move(o); }
+    Fiber &operator=(Fiber &&o) noexcept {
+        sp = o.sp; stack = o.stack; done = o.done; site = o.site;
+        tid[0] = o.tid[0]; tid[1] = o.tid[1]; tid[2] = o.tid[2];
+        o.stack = nullptr;
+        return *this;
+    }
+    ~Fiber() { free(stack); }   // a worker thread's fibers go away with the thread
     void *sp = nullptr;
     char *stack = nullptr;
     bool done = true;
@@ -183,8 +192,9 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
     const unsigned long long blocks = (unsigned long long)grid.x * grid.y * grid.z;
     int want = 1;
     if (const char *e = getenv("EMU_THREADS")) want = atoi(e);
-    if (want > 1 && blocks > 1) {
-        // workgroups on OS threads: block k only starts once a thread is free, in index order (like a GPU's dispatcher)
+    if (want > 1 && blocks > 1 && blocks <= (unsigned long long)want) {
+        // Few workgroups that may wait for each other (the persistent wavefronts of the entropy kernel): one OS thread
+        // each, all running at once.  Big grids (the inverse transforms: independent blocks) stay on this thread.
         std::atomic<unsigned long long> next{0};
         const int nthreads = (int)std::min<unsigned long long>((unsigned long long)want, blocks);
         std::vector<std::thread> pool;
