@@ -37,7 +37,7 @@ struct fuifgpu_batch {
     uint32_t *d_consumed = nullptr;
     uint16_t *d_tables = nullptr;
     uint8_t *d_scratch = nullptr;
-    size_t scratch_stride = 0, bfs_off = 0, leaves_off = 0, stack_off = 0, queue_off = 0;
+    size_t scratch_stride = 0, bfs_off = 0, leaves_off = 0, stack_off = 0, queue_off = 0, subtree_off = 0;
     int scratch_waves = 0;            // wavefronts d_scratch is sized for
     int max_waves[2] = {0, 0};        // resident wavefronts the device holds in the wide / dense kernel configuration
     int n_waves = 0, dense = 0;       // persistent wavefronts and configuration of the next decode launch
@@ -80,7 +80,7 @@ namespace fuifgpu {
 #define FUIF_MAX_SUPER 4096
 #endif
 int maniac_max_supernodes(int max_nodes) { return (int)std::min<int64_t>(FUIF_MAX_SUPER, ((int64_t)max_nodes + 1) * 5 / 16 + 66); }
-size_t maniac_scratch_bytes(int max_nodes, size_t *bfs_off, size_t *leaves_off, size_t *stack_off, size_t *queue_off) {
+size_t maniac_scratch_bytes(int max_nodes, size_t *bfs_off, size_t *leaves_off, size_t *stack_off, size_t *queue_off, size_t *subtree_off) {
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     size_t nodes = up((size_t)(max_nodes + 1) * 8);
     size_t snodes = up((size_t)maniac_max_supernodes(max_nodes) * 512);
@@ -91,7 +91,8 @@ size_t maniac_scratch_bytes(int max_nodes, size_t *bfs_off, size_t *leaves_off, 
     *leaves_off = nodes + snodes;
     *stack_off = nodes + snodes + leaves;
     *queue_off = nodes + snodes + leaves + stack;
-    return nodes + snodes + leaves + stack + queue;
+    *subtree_off = nodes + snodes + leaves + stack + queue;
+    return nodes + snodes + leaves + stack + queue + up((size_t)(max_nodes + 1) * 2);
 }
 }  // namespace fuifgpu
 
@@ -214,7 +215,7 @@ int fuifgpu_batch_create(const fuifgpu_plan *plan, int n_images, size_t blob_cap
         CHK(hipMalloc((void **)&b->d_tables, tables.size() * 2));
         CHK(hipMemcpy(b->d_tables, tables.data(), tables.size() * 2, hipMemcpyHostToDevice));
     }
-    b->scratch_stride = maniac_scratch_bytes(b->max_nodes, &b->bfs_off, &b->leaves_off, &b->stack_off, &b->queue_off);
+    b->scratch_stride = maniac_scratch_bytes(b->max_nodes, &b->bfs_off, &b->leaves_off, &b->stack_off, &b->queue_off, &b->subtree_off);
     b->max_waves[0] = maniac_max_waves(0);
     b->max_waves[1] = maniac_max_waves(1);
     if (b->max_waves[0] < 1 || b->max_waves[1] < 1) { g_last_error = "cannot query the device occupancy of the entropy kernel"; fuifgpu_batch_destroy(b); return FUIFGPU_E_HIP; }
@@ -343,7 +344,7 @@ int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
     P.blobs = b->d_blobs; P.jobs = b->d_jobs; P.n_images = b->n_loaded; P.n_channels = nch; P.geom = b->d_geom;
     P.coef = b->d_coef; P.coef_stride = b->plan.coef_elems; P.meta = b->d_meta; P.status = b->d_status; P.consumed = b->d_consumed;
     P.tables = b->d_tables; P.scratch = b->d_scratch; P.scratch_stride = b->scratch_stride; P.bfs_off = b->bfs_off; P.leaves_off = b->leaves_off;
-    P.stack_off = b->stack_off; P.queue_off = b->queue_off; P.max_properties = b->plan.max_properties; P.max_nodes = b->max_nodes; P.max_super = maniac_max_supernodes(b->max_nodes); P.prof = b->d_prof;
+    P.stack_off = b->stack_off; P.queue_off = b->queue_off; P.subtree_off = b->subtree_off; P.max_properties = b->plan.max_properties; P.max_nodes = b->max_nodes; P.max_super = maniac_max_supernodes(b->max_nodes); P.prof = b->d_prof;
     P.tiles = b->d_tiles; P.n_tiles = b->n_tiles; P.queue_head = b->d_queue_head; P.progress = b->d_progress; P.group_start = b->d_group_start;
     HIPCHK(hipEventRecord(b->ev[0], st));
     launch_maniac_decode(P, b->n_waves, b->dense, b->n_tiles > b->n_loaded ? 1 : 0, st);

@@ -26,7 +26,7 @@ struct DecodeParams {
     uint32_t *progress;          // [n_images][n_channels] 0 = nothing yet, 1 + rows finished once the header is known; zeroed before the launch
     uint32_t *group_start;       // [n_images][n_channels] 1 + byte offset of the group that starts at this channel (0 = none); zeroed before the launch
     uint8_t *scratch;            // per wavefront: parse-order nodes | breadth-first nodes | leaves | parse stack | BFS queue
-    size_t scratch_stride, bfs_off, leaves_off, stack_off, queue_off;
+    size_t scratch_stride, bfs_off, leaves_off, stack_off, queue_off, subtree_off;
     int32_t max_properties;
     int32_t max_nodes;
     int32_t max_super;           // supernodes the scratch area holds
@@ -34,7 +34,7 @@ struct DecodeParams {
 };
 
 int maniac_max_supernodes(int max_nodes);
-size_t maniac_scratch_bytes(int max_nodes, size_t *bfs_off, size_t *leaves_off, size_t *stack_off, size_t *queue_off);
+size_t maniac_scratch_bytes(int max_nodes, size_t *bfs_off, size_t *leaves_off, size_t *stack_off, size_t *queue_off, size_t *subtree_off);
 // The kernel exists in two LDS configurations: wide (1 wavefront per SIMD, most of the context tree in
 // LDS) and dense (4 per SIMD).  maniac_max_waves = wavefronts the device holds at once in that configuration.
 int maniac_max_waves(int dense);

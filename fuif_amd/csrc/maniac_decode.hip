@@ -84,6 +84,10 @@ constexpr int CH_ZERO = 0, CH_SIGN = 1, CH_EXP = 2, CH_MANT = 16, CH_N = 31;
 #define FUIF_LDS_DENSE 2
 #endif
 constexpr int kLdsWide = FUIF_LDS_WIDE, kLdsDense = FUIF_LDS_DENSE;
+#ifndef FUIF_SIZE_ORDERED
+#define FUIF_SIZE_ORDERED 64   // supernodes (breadth first) whose children are numbered by subtree size; 0 = exit order everywhere
+#endif
+constexpr int kSizeOrdered = FUIF_SIZE_ORDERED;
 constexpr uint32_t kLeafFlag = 0x800000u;
 constexpr uint32_t kSlowFlag = 0x400000u;   // exit leads to a plain tree node (index in the low 16 bits), not to a supernode
 constexpr int kPropPitch = 33;    // odd pitch: conflict-free column writes / row reads
@@ -139,10 +143,14 @@ struct Node {  // maniac/compound.h:41-51; property -1 = leaf, child = leaf id
 // One 64-bit load per tree level.  hipcc otherwise splits the node into two dependent 32-bit
 // loads (it sinks the splitval load behind the leaf test), doubling the per-level latency.
 #ifdef FUIF_EMU
+// emulator-only statistics (tools/emu_walk_stats.py): where the walk rounds behind the root supernode are served from
+extern unsigned long long g_emu_stats[4];   // symbols with a walk, rounds from LDS, rounds from scratch memory, -
+#define EMU_COUNT(k) do { if (lane == 0) __atomic_fetch_add(&g_emu_stats[k], 1ull, __ATOMIC_RELAXED); } while (0)
 static thread_local const char *emu_lds_base;   // LDS byte addresses are offsets from the supernode array in the emulator
 DEV uint2 lds_load_node(uint32_t lds_byte_addr) { return *reinterpret_cast<const uint2 *>(emu_lds_base + lds_byte_addr); }
 DEV uint2 global_load_node(const void *p) { return *reinterpret_cast<const uint2 *>(p); }
 #else
+#define EMU_COUNT(k)
 DEV uint2 lds_load_node(uint32_t lds_byte_addr) {
     uint2 v;
     asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_byte_addr) : "memory");
@@ -418,6 +426,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
     uint16_t *leaves = reinterpret_cast<uint16_t *>(scratch + P.leaves_off);
     Frame *stack = reinterpret_cast<Frame *>(scratch + P.stack_off);
     int32_t *queue = reinterpret_cast<int32_t *>(scratch + P.queue_off);      // breadth-first work list
+    uint16_t *subtree = reinterpret_cast<uint16_t *>(scratch + P.subtree_off); // nodes under every tree node (saturating)
     const ChannelGeom *geom = P.geom;
     const int nch = P.n_channels;
 #ifdef FUIF_EMU
@@ -719,6 +728,19 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         // are the ones that stay in LDS.
         const int nleaves = (tree_size + 1) / 2;
         int n_super = 1;
+        // Subtree sizes (nodes, saturating): children always have larger indices than their parent in the parse-order
+        // array, so one backward sweep does it.  The learner splits contexts that see many samples, so a child
+        // supernode with a big subtree is (statistically) a frequently walked one: numbering them big-first puts the
+        // busiest part of the tree into the LDS-resident prefix instead of whatever hangs under the first exits.
+        if (lane == 0) {
+            for (int i = tree_size - 1; i >= 0; i--) {
+                const Node n = nodes[i];
+                uint32_t sz = 1;
+                if (n.property >= 0) sz += (uint32_t)subtree[n.child] + (uint32_t)subtree[n.child + 1];
+                subtree[i] = (uint16_t)(sz > 65535u ? 65535u : sz);
+            }
+        }
+        __syncthreads();
         {
             int32_t *slot_node = sh.cprops;        // [127] tree node behind every heap slot (cprops is idle here)
             int32_t *st_split = sh.cprops + 128;   // [64]
@@ -748,7 +770,16 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 const Node n = nodes[t];
                 const bool inner = n.property >= 0;
                 const unsigned long long im = __ballot(inner);
-                const int rank = __popcll(im & ((1ull << lane) - 1ull));
+                int rank = __popcll(im & ((1ull << lane) - 1ull));
+                if (sn < kSizeOrdered) {
+                    // children of the top supernodes are numbered by subtree size (descending; ties by exit)
+                    const int mine = inner ? (int)subtree[t] : -1;
+                    rank = 0;
+                    for (int j = 0; j < 64; j++) {
+                        const int other = rdlane(mine, j);
+                        rank += (other > mine) | ((other == mine) & (j < lane));
+                    }
+                }
                 uint32_t tgt;
                 // The scratch area holds P.max_super supernodes.  Subtrees beyond that (only trees with tens of
                 // thousands of nodes get there) are walked node by node from the parse-order array instead.
@@ -761,7 +792,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 out.x = (uint32_t)st_split[lane];
                 out.y = ((uint32_t)st_prop[lane] & 0xFFu) | (tgt << 8);
                 snodes_g[(size_t)sn * 64 + lane] = out;
-                if (sn < kLdsSuper) sh.snodes[sn * 64 + lane] = out;
+                if (sn >= 1 && sn <= kLdsSuper) sh.snodes[(sn - 1) * 64 + lane] = out;   // the root (0) lives in registers: LDS holds 1..kLdsSuper
                 __syncthreads();
             }
         }
@@ -940,12 +971,15 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                         return (uint32_t)rdlane((int)nd.y, e) >> 8;
                                     };
                                     uint32_t tgt = walk_round(root_nd);
+                                    EMU_COUNT(0);
                                     while (!(tgt & (kLeafFlag | kSlowFlag))) {
+                                        EMU_COUNT(tgt <= (uint32_t)kLdsSuper ? 1 : 2);
                                         // LDS-resident supernodes are the common case; the load is issued unconditionally
                                         // (index clamped) and replaced in the rare deep case
-                                        const uint32_t li = tgt < (uint32_t)kLdsSuper ? tgt : (uint32_t)(kLdsSuper - 1);
-                                        uint2 nd = lds_load_node(lds_nodes_addr + li * 512u + (uint32_t)lane * 8u);
-                                        if (UNLIKELY(tgt >= (uint32_t)kLdsSuper)) nd = global_load_node(&snodes_g[(size_t)tgt * 64 + lane]);
+                                        // (supernode i sits in LDS slot i-1: the -512 folds into the base address)
+                                        const uint32_t li = tgt <= (uint32_t)kLdsSuper ? tgt : (uint32_t)kLdsSuper;
+                                        uint2 nd = lds_load_node(lds_nodes_addr + (li - 1u) * 512u + (uint32_t)lane * 8u);
+                                        if (UNLIKELY(tgt > (uint32_t)kLdsSuper)) nd = global_load_node(&snodes_g[(size_t)tgt * 64 + lane]);
                                         tgt = walk_round(nd);
                                     }
                                     if (UNLIKELY(tgt & kSlowFlag)) {
@@ -1039,3 +1073,12 @@ void launch_maniac_decode(const DecodeParams &P, int n_waves, int dense, int han
 }
 
 }  // namespace fuifgpu
+
+
+#ifdef FUIF_EMU
+namespace fuifgpu { namespace { unsigned long long g_emu_stats[4]; } }
+// emulator builds only (tools/emu_walk_stats.py): {symbols that walked the tree, rounds served from LDS, rounds from scratch}
+extern "C" void fuifgpu_emu_walk_stats(unsigned long long *out4, int reset) {
+    for (int k = 0; k < 4; k++) { out4[k] = fuifgpu::g_emu_stats[k]; if (reset) fuifgpu::g_emu_stats[k] = 0; }
+}
+#endif

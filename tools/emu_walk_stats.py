@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Where do the tree-walk rounds behind the root supernode get their supernode from -- LDS or scratch memory?
+Emulator builds count it (fuifgpu_emu_walk_stats).  Used to judge supernode numbering schemes without a GPU:
+
+  FUIF_AMD_LIB=<emulated library> python tools/emu_walk_stats.py [w h]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("FUIF_AMD_LIB", os.path.join(ROOT, "tests", "_emu", "libfuifgpu_emu.so"))
+sys.path.insert(0, ROOT)
+import fuif_amd  # noqa: E402
+from fuif_amd.synth import photographic  # noqa: E402
+
+w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (640, 360)
+img = photographic(w, h, 3, 8, seed=1000)
+blob = fuif_amd.encode_image(img, 8, tree_mode=1, index=True)
+L = fuif_amd.lib()
+st = (C.c_ulonglong * 4)()
+for parallel, name in ((False, "wide  (58 supernodes in LDS, one tile per image)"), (True, "dense ( 2 supernodes in LDS, one tile per group)")):
+    plan = fuif_amd.Plan(blob)
+    b = fuif_amd.Batch(plan, 1, len(blob))
+    b.set_group_parallel(parallel)
+    b.upload([blob])
+    L.fuifgpu_emu_walk_stats(st, 1)
+    b.decode(); b.sync()
+    L.fuifgpu_emu_walk_stats(st, 1)
+    ok = all(np.array_equal(p, q) for p, q in zip(fuif_amd.decode_batch([blob])[0][0], img))
+    b.close()
+    sym, lds, glob = st[0], st[1], st[2]
+    print("%s: %d symbols, %.3f rounds/symbol behind the root, %.1f %% of them from LDS, %.3f scratch fetches per symbol (lossless %s)" % (
+        name, sym, (lds + glob) / max(sym, 1), 100.0 * lds / max(lds + glob, 1), glob / max(sym, 1), ok))
