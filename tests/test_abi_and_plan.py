@@ -86,3 +86,16 @@ def test_group_by_signature_is_host_only(gpulib, manifest):
     assert sorted(idx for _, idx in groups.values()) == [[0, 3], [1, 4], [2], [5]]
     for plan, idx in groups.values():
         assert gpulib.plan_bytes_per_image(plan) > 4 * (plan.info.coef_elems + plan.info.out_elems)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/fuifgpu.h is the C-ABI: it has to compile as C99 with nothing but <stddef.h>/<stdint.h> behind it"""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text('#include "fuifgpu.h"\nint use(void) { fuifgpu_encode_options o; (void)o; return FUIFGPU_OK + (int)sizeof(fuifgpu_image_info); }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
