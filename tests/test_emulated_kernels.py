@@ -88,3 +88,33 @@ def test_gpu_parity_tests_pass_on_the_wavefront_emulator():
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1700)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_reference_cli_through_the_boundary_writes_the_reference_files(tmp_path):
+    """build container only: the UNCHANGED reference CLI linked through fuif_amd/boundary to the emulated library
+    (found via LD_LIBRARY_PATH under the product library's name) must write byte for byte the file the real reference
+    CLI writes -- palette, approximate, 2D-match, truncation-sensitive and JPEG-transcoded fixtures included"""
+    import shutil
+    gpu_cli = os.path.join(ROOT, "fuif_amd", "boundary", "_build", "fuif_gpu")
+    ref_cli = os.path.join(ROOT, "oracle", "_ref", "fuif")
+    if not (os.path.exists(gpu_cli) and os.path.exists(ref_cli)):
+        pytest.skip("needs the boundary binary and oracle/_ref/fuif (built from /root/reference)")
+    if sys.platform != "linux" or os.uname().machine != "x86_64":
+        pytest.skip("the emulator's context switch is x86-64 SysV assembly")
+    libdir = tmp_path / "lib"
+    libdir.mkdir()
+    shutil.copy(build_emulated_library(), libdir / "libfuifgpu.so")
+    env = dict(os.environ)
+    if os.path.exists("/opt/conda/lib/libjpeg.so.9"):
+        env["LD_PRELOAD"] = "/opt/conda/lib/libjpeg.so.9"
+    env_gpu = dict(env, LD_LIBRARY_PATH=str(libdir), EMU_ALARM="600")
+    names = ["rgb8_97x61", "pal_rgb_graphic_120x90", "pal_rgba_graphic_72x64", "pal_rgb_channelwise_96x72", "approx_quant_rgb8_40x30",
+             "approx_on_palette_gray12_24x50", "match_rgb_graphic_96x80", "gray8_nosqueeze_60x40", "jpeg420_256x192_q90", "rgba14_80x72"]
+    for name in names:
+        src = os.path.join(ROOT, "tests", "golden", name + ".fuif")
+        for extra in ([], ["-R", "2"]):
+            a, b = str(tmp_path / "gpu.pam"), str(tmp_path / "ref.pam")
+            ra = subprocess.run([gpu_cli, "-d"] + extra + [src, a], env=env_gpu, capture_output=True, text=True, timeout=600)
+            rb = subprocess.run([ref_cli, "-d"] + extra + [src, b], env=env, capture_output=True, text=True, timeout=600)
+            assert ra.returncode == rb.returncode == 0, (name, extra, ra.stderr[-300:], rb.stderr[-300:])
+            assert open(a, "rb").read() == open(b, "rb").read(), (name, extra)
