@@ -82,7 +82,7 @@ def test_gpu_parity_tests_pass_on_the_wavefront_emulator():
     cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + SELECTED
     try:
         import xdist  # noqa: F401
-        cmd += ["-n", str(max(1, min(4, (os.cpu_count() or 2) // 2)))]
+        cmd += ["-n", str(max(1, min(6, (os.cpu_count() or 2) - 2)))]
     except ImportError:
         pass
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1700)
