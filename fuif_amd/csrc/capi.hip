@@ -296,17 +296,29 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
     b->tiles.clear();
     size_t deepest = 0;
     for (auto &g : groups) deepest = std::max(deepest, g.size());
-    for (size_t k = 0; k < deepest; k++)
-        for (int i = 0; i < n_images; i++) {
-            const std::vector<GroupEntry> &g = groups[group_of[i]];
-            if (k >= g.size()) continue;
-            Tile t;
-            t.image = (uint32_t)i;
-            t.start = g[k].start;
-            t.first_channel = k == 0 ? 0 : g[k].first_channel;
-            t.last_channel = k + 1 < g.size() ? g[k + 1].first_channel - 1 : nch - 1;
-            b->tiles.push_back(t);
-        }
+    auto push_tile = [&](int i, size_t k) {
+        const std::vector<GroupEntry> &g = groups[group_of[i]];
+        if (k >= g.size()) return;
+        Tile t;
+        t.image = (uint32_t)i;
+        t.start = g[k].start;
+        t.first_channel = k == 0 ? 0 : g[k].first_channel;
+        t.last_channel = k + 1 < g.size() ? g[k + 1].first_channel - 1 : nch - 1;
+        b->tiles.push_back(t);
+    };
+    // diagnostic: FUIFGPU_TILE_ORDER=image[:cohort] lists the tiles image by image (inside cohorts of that many images)
+    int cohort = 0;
+    if (const char *ord = getenv("FUIFGPU_TILE_ORDER")) {
+        if (!strncmp(ord, "image", 5)) cohort = ord[5] == ':' ? std::max(1, atoi(ord + 6)) : 1;
+    }
+    if (cohort > 0) {
+        for (int i0 = 0; i0 < n_images; i0 += cohort)
+            for (size_t k = 0; k < deepest; k++)
+                for (int i = i0; i < std::min(n_images, i0 + cohort); i++) push_tile(i, k);
+    } else {
+        for (size_t k = 0; k < deepest; k++)
+            for (int i = 0; i < n_images; i++) push_tile(i, k);
+    }
     b->n_tiles = (int)b->tiles.size();
     if (b->n_tiles > b->tiles_cap) {
         hipFree(b->d_tiles); b->d_tiles = nullptr; b->tiles_cap = 0;

@@ -188,22 +188,26 @@ static inline int coder_read(fo_rac *r, uint16_t *ch, const uint16_t *table) {
     return bit;
 }
 
+static int g_stats;
+static struct fo_stats_s { uint64_t sym, walked, steps, predepth, same_leaf, zero, nsign, edec, mdec, ehist[16], prehist[24]; } g_st;
 /* maniac/symbol.h:154-185 reader<bits>(coder,min,max) */
 static int read_symbol(fo_rac *r, uint16_t *ch, const uint16_t *table, int min, int max) {
     if (min == max) return min;
-    if (coder_read(r, &ch[CH_ZERO], table)) return 0;
+    if (coder_read(r, &ch[CH_ZERO], table)) { if (g_stats > 0) g_st.zero++; return 0; }
     int sign;
-    if (min < 0) { if (max > 0) sign = coder_read(r, &ch[CH_SIGN], table); else sign = 0; }
+    if (min < 0) { if (max > 0) { sign = coder_read(r, &ch[CH_SIGN], table); if (g_stats > 0) g_st.nsign++; } else sign = 0; }
     else sign = 1;
     const int amax = sign ? max : -min;
     const int emax = ilog2u((uint32_t)amax);
     int e = 0;
-    for (; e < emax; e++) if (coder_read(r, &ch[CH_EXP + e], table)) break;
+    for (; e < emax; e++) { if (g_stats > 0) g_st.edec++; if (coder_read(r, &ch[CH_EXP + e], table)) break; }
+    if (g_stats > 0) g_st.ehist[e & 15]++;
     int have = 1 << e;
     for (int pos = e; pos > 0;) {
         pos--;
         int minabs1 = have | (1 << pos);
         if (minabs1 > amax) continue;
+        if (g_stats > 0) g_st.mdec++;
         if (coder_read(r, &ch[CH_MANT + pos], table)) have = minabs1;
     }
     return sign ? have : -have;
@@ -669,6 +673,10 @@ static int corrupt_or_truncated(fo_io *io, fo_channel *c, size_t btl) {
     return 0;
 }
 
+/* optional per-group stream statistics (FO_STATS=1, printed to stderr): what the HIP kernel's per-symbol phases see
+ * (walk depth, depth of the first left-dependent test, leaf repeats, exponent lengths); not part of the decode semantics */
+/* (g_stats / g_st are declared next to read_symbol) */
+
 /* optional leaf-locality statistics (FO_LEAFSIM=1): hit rates of direct-mapped leaf caches, used to
  * size the LDS leaf cache of the HIP kernel; not part of the decode semantics */
 static int g_leafsim = -1;
@@ -792,6 +800,10 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
     int32_t props[FO_MAX_PROPS];
     memset(props, 0, sizeof(props));
     if (g_leafsim < 0) g_leafsim = getenv("FO_LEAFSIM") ? 1 : 0;
+    if (g_stats <= 0 && g_stats != -2) g_stats = getenv("FO_STATS") ? 1 : -2;
+    int st_prev_leaf = -1;
+    if (g_stats > 0) memset(&g_st, 0, sizeof(g_st));
+    const uint64_t st_dec0 = rac.decisions;
     int *ls_ids = NULL, ls_prev = -1;
     if (g_leafsim) { ls_ids = (int *)malloc(sizeof(int) * nleaves); int nx = 0; dfs_number(tree.n, 0, ls_ids, &nx); leafsim_reset(); }
     const int nref = nprops - FO_NB_NONREF;
@@ -824,10 +836,22 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
                     else {
                         /* find_leaf: compound.h:142-153 */
                         int pos = 0;
+                        int depth = 0, pre = -1;
                         while (tree.n[pos].property != -1) {
                             img->stat_tree_steps++;
+                            if (g_stats > 0 && pre < 0) {
+                                const int kl = tree.n[pos].property - nref;  /* local properties that read `left` */
+                                if (kl == 1 || kl == 3 || kl == 12 || (y ? (kl == 6 || kl == 8) : (kl == 7 || kl == 9))) pre = depth;
+                            }
+                            depth++;
                             if (props[tree.n[pos].property] > tree.n[pos].splitval) pos = tree.n[pos].childID;
                             else pos = tree.n[pos].childID + 1;
+                        }
+                        if (g_stats > 0) {
+                            if (pre < 0) pre = depth;
+                            g_st.walked++; g_st.steps += depth; g_st.predepth += pre; g_st.prehist[pre > 23 ? 23 : pre]++;
+                            if ((int)tree.n[pos].childID == st_prev_leaf) g_st.same_leaf++;
+                            st_prev_leaf = tree.n[pos].childID;
                         }
                         if (g_leafsim) leafsim_access(ls_ids[tree.n[pos].childID], &ls_prev);
                         diff = read_symbol(&rac, leaves + (size_t)tree.n[pos].childID * CH_N, g_table_pixel, mn, mx);
@@ -839,6 +863,18 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
             free(refs);
         }
         if (LIMIT_HIT(io, btl)) break;
+    }
+    if (g_stats > 0) {
+        fprintf(stderr, "group c%d-%d %dx%d pred %d tree %d leaves %d walked %llu depth %.2f predepth %.2f sameleaf %.3f zero %.3f sign %.3f edec %.2f mdec %.2f dec/sym %.2f\n  ehist",
+                beginc, endc, img->ch[beginc].w, img->ch[beginc].h, predictor, tree.size, nleaves, (unsigned long long)g_st.walked,
+                g_st.walked ? (double)g_st.steps / g_st.walked : 0.0, g_st.walked ? (double)g_st.predepth / g_st.walked : 0.0,
+                g_st.walked ? (double)g_st.same_leaf / g_st.walked : 0.0, g_st.walked ? (double)g_st.zero / g_st.walked : 0.0,
+                g_st.walked ? (double)g_st.nsign / g_st.walked : 0.0, g_st.walked ? (double)g_st.edec / g_st.walked : 0.0,
+                g_st.walked ? (double)g_st.mdec / g_st.walked : 0.0, g_st.walked ? (double)(rac.decisions - st_dec0) / g_st.walked : 0.0);
+        for (int k = 0; k < 12; k++) fprintf(stderr, " %.3f", g_st.walked ? (double)g_st.ehist[k] / g_st.walked : 0.0);
+        fprintf(stderr, "\n  prehist");
+        for (int k = 0; k < 16; k++) fprintf(stderr, " %.3f", g_st.walked ? (double)g_st.prehist[k] / g_st.walked : 0.0);
+        fprintf(stderr, "\n");
     }
     img->stat_rac_decisions += rac.decisions;
     free(ls_ids);
