@@ -44,14 +44,18 @@ struct fuifgpu_batch {
     bool group_parallel = true;       // use group indices (index.cpp) when streams carry them
     Tile *d_tiles = nullptr;
     int tiles_cap = 0, n_tiles = 0;
-    uint32_t *d_progress = nullptr, *d_group_start = nullptr, *d_queue_head = nullptr;
+    uint32_t *d_progress = nullptr, *d_group_start = nullptr;
+    // work queues of the entropy kernel (maniac_decode.h): d_sched = [q_head: queues_cap][simd_claim: 2*16384+1], zeroed per launch
+    uint32_t *d_sched = nullptr, *d_qbegin = nullptr;
+    int queues_cap = 0, n_queues = 1, waves_per_simd = 4;
     std::vector<Tile> tiles;
     int max_nodes = kMaxNodes;
     int32_t *d_coef = nullptr, *d_out = nullptr, *d_tmp = nullptr;
     bool own_coef = false, own_out = false;
     int tmp_images = 0;
     PlaneRef *d_list = nullptr;
-    unsigned long long *d_prof = nullptr;
+    unsigned long long *d_prof = nullptr, *d_tile_log = nullptr;   // d_tile_log: only allocated once fuifgpu_batch_tile_log has been asked for
+    int tile_log_cap = 0; bool want_tile_log = false;
     // host staging (pinned)
     uint8_t *h_blobs = nullptr;
     std::vector<StreamJob> jobs;
@@ -172,8 +176,8 @@ int fuifgpu_plan_transform(const fuifgpu_plan *plan, int index, int32_t *id, int
 void fuifgpu_batch_destroy(fuifgpu_batch *b) {
     if (!b) return;
     hipFree(b->d_blobs); hipFree(b->d_jobs); hipFree(b->d_geom); hipFree(b->d_meta); hipFree(b->d_status); hipFree(b->d_consumed);
-    hipFree(b->d_tables); hipFree(b->d_scratch); hipFree(b->d_tmp); hipFree(b->d_list); hipFree(b->d_prof);
-    hipFree(b->d_tiles); hipFree(b->d_progress); hipFree(b->d_group_start); hipFree(b->d_queue_head);
+    hipFree(b->d_tables); hipFree(b->d_scratch); hipFree(b->d_tmp); hipFree(b->d_list); hipFree(b->d_prof); hipFree(b->d_tile_log);
+    hipFree(b->d_tiles); hipFree(b->d_progress); hipFree(b->d_group_start); hipFree(b->d_sched); hipFree(b->d_qbegin);
     if (b->own_coef) hipFree(b->d_coef);
     if (b->own_out) hipFree(b->d_out);
     if (b->h_blobs) hipHostFree(b->h_blobs);
@@ -217,11 +221,10 @@ int fuifgpu_batch_create(const fuifgpu_plan *plan, int n_images, size_t blob_cap
     }
     b->scratch_stride = maniac_scratch_bytes(b->max_nodes, &b->bfs_off, &b->leaves_off, &b->stack_off, &b->queue_off, &b->subtree_off);
     b->max_waves[0] = maniac_max_waves(0);
-    b->max_waves[1] = maniac_max_waves(1);
+    b->max_waves[1] = maniac_max_waves(1, &b->waves_per_simd);
     if (b->max_waves[0] < 1 || b->max_waves[1] < 1) { g_last_error = "cannot query the device occupancy of the entropy kernel"; fuifgpu_batch_destroy(b); return FUIFGPU_E_HIP; }
     CHK(hipMalloc((void **)&b->d_progress, sizeof(uint32_t) * (size_t)n_images * std::max(nch, 1)));
     CHK(hipMalloc((void **)&b->d_group_start, sizeof(uint32_t) * (size_t)n_images * std::max(nch, 1)));
-    CHK(hipMalloc((void **)&b->d_queue_head, 256));
     if (coef_ext) b->d_coef = coef_ext;
     else { CHK(hipMalloc((void **)&b->d_coef, sizeof(int32_t) * (size_t)std::max<int64_t>(p.coef_elems, 1) * n_images)); b->own_coef = true; }
     if (out_ext) b->d_out = out_ext;
@@ -263,7 +266,7 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
         int src = -1;
         for (auto &sp : seen) if (sp.first == blobs[i] && b->jobs[sp.second].blob_size == sizes[i]) { src = sp.second; break; }
         size_t padded = (sizes[i] + 15) / 16 * 16 + 16;
-        if (off + padded > b->blob_cap) { g_last_error = "blob capacity exceeded"; return FUIFGPU_E_NOMEM; }
+        if (off + padded + 256 > b->blob_cap) { g_last_error = "blob capacity exceeded"; return FUIFGPU_E_NOMEM; }  // the last 256-byte read window stays inside the allocation
         StreamJob &j = b->jobs[i];
         if (src < 0) {
             int r = parse_and_plan(blobs[i], sizes[i], tmp);
@@ -290,12 +293,13 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
         off += padded;
     }
     HIPCHK(hipMemcpyAsync(b->d_jobs, b->jobs.data(), sizeof(StreamJob) * n_images, hipMemcpyHostToDevice, st));
-    // Work list in dependency order: tile k of every image before tile k+1 of any image, so a tile's
-    // producers (earlier groups of the same image) are always ahead of it in the list, and the big
-    // final groups of all images sit together at the end, where they balance the machine.
-    b->tiles.clear();
-    size_t deepest = 0;
+    // Work list.  Which configuration runs is known from the tile count alone: more tiles than the wide configuration
+    // has wavefronts -> dense (4 wavefronts per SIMD).
+    size_t total_tiles = 0, deepest = 0;
+    for (int i = 0; i < n_images; i++) total_tiles += groups[group_of[i]].size();
     for (auto &g : groups) deepest = std::max(deepest, g.size());
+    b->dense = (int64_t)total_tiles > b->max_waves[0] ? 1 : 0;
+    b->n_waves = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)total_tiles, b->max_waves[b->dense]));
     auto push_tile = [&](int i, size_t k) {
         const std::vector<GroupEntry> &g = groups[group_of[i]];
         if (k >= g.size()) return;
@@ -306,19 +310,38 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
         t.last_channel = k + 1 < g.size() ? g[k + 1].first_channel - 1 : nch - 1;
         b->tiles.push_back(t);
     };
-    // diagnostic: FUIFGPU_TILE_ORDER=image[:cohort] lists the tiles image by image (inside cohorts of that many images)
-    int cohort = 0;
-    if (const char *ord = getenv("FUIFGPU_TILE_ORDER")) {
-        if (!strncmp(ord, "image", 5)) cohort = ord[5] == ':' ? std::max(1, atoi(ord + 6)) : 1;
-    }
-    if (cohort > 0) {
-        for (int i0 = 0; i0 < n_images; i0 += cohort)
-            for (size_t k = 0; k < deepest; k++)
-                for (int i = i0; i < std::min(n_images, i0 + cohort); i++) push_tile(i, k);
-    } else {
+    // Dense launches: one queue per SIMD (= per waves_per_simd resident wavefronts), image i in queue i % n_queues, an image's tiles
+    // in stream order (a tile only ever waits for EARLIER tiles of its own queue).  A SIMD's wavefronts then work
+    // through whole images: every SIMD gets the same work, and the long final groups of an image start as soon as
+    // four of its tiles are done instead of when the whole batch has reached them (measured, 1024 x 4K: see
+    // profiles/r2_*).  FUIFGPU_TILE_ORDER=group (diagnostic) restores the single group-major list of round 1: tile k
+    // of every image before tile k+1 of any.
+    const char *ord = getenv("FUIFGPU_TILE_ORDER");
+    const bool group_major = !b->dense || (ord && !strcmp(ord, "group"));
+    b->tiles.clear();
+    std::vector<uint32_t> qbegin;
+    if (group_major) {
+        b->n_queues = 1;
         for (size_t k = 0; k < deepest; k++)
             for (int i = 0; i < n_images; i++) push_tile(i, k);
+        qbegin = {0u, (uint32_t)b->tiles.size()};
+    } else {
+        b->n_queues = std::max(1, std::min(n_images, b->n_waves / std::max(1, b->waves_per_simd)));
+        for (int q = 0; q < b->n_queues; q++) {
+            qbegin.push_back((uint32_t)b->tiles.size());
+            for (int i = q; i < n_images; i += b->n_queues)
+                for (size_t k = 0; k < groups[group_of[i]].size(); k++) push_tile(i, k);
+        }
+        qbegin.push_back((uint32_t)b->tiles.size());
     }
+    if (b->n_queues > b->queues_cap) {
+        hipFree(b->d_sched); hipFree(b->d_qbegin); b->d_sched = b->d_qbegin = nullptr; b->queues_cap = 0;
+        HIPCHK(hipMalloc((void **)&b->d_sched, sizeof(uint32_t) * ((size_t)b->n_queues + 2 * 16384 + 1)));
+        HIPCHK(hipMalloc((void **)&b->d_qbegin, sizeof(uint32_t) * ((size_t)b->n_queues + 1)));
+        b->queues_cap = b->n_queues;
+    }
+    HIPCHK(hipMemcpyAsync(b->d_qbegin, qbegin.data(), sizeof(uint32_t) * qbegin.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));  // qbegin is a local
     b->n_tiles = (int)b->tiles.size();
     if (b->n_tiles > b->tiles_cap) {
         hipFree(b->d_tiles); b->d_tiles = nullptr; b->tiles_cap = 0;
@@ -328,9 +351,6 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
     if (b->n_tiles) HIPCHK(hipMemcpyAsync(b->d_tiles, b->tiles.data(), sizeof(Tile) * (size_t)b->n_tiles, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));  // b->tiles / b->jobs may be rebuilt by the next upload
     // one persistent wavefront per tile up to what the device holds at once; each owns a scratch area
-    // more tiles than the wide configuration has wavefronts: go dense (4 per SIMD)
-    b->dense = b->n_tiles > b->max_waves[0] ? 1 : 0;
-    b->n_waves = std::max(1, std::min(b->n_tiles, b->max_waves[b->dense]));
     if (b->n_waves > b->scratch_waves) {
         hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_waves = 0;
         HIPCHK(hipMalloc((void **)&b->d_scratch, b->scratch_stride * (size_t)b->n_waves));
@@ -348,7 +368,7 @@ int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
     // every word the tiles poll or accumulate into is zeroed before every launch
     HIPCHK(hipMemsetAsync(b->d_progress, 0, sizeof(uint32_t) * (size_t)b->n_loaded * std::max(nch, 1), st));
     HIPCHK(hipMemsetAsync(b->d_group_start, 0, sizeof(uint32_t) * (size_t)b->n_loaded * std::max(nch, 1), st));
-    HIPCHK(hipMemsetAsync(b->d_queue_head, 0, 256, st));
+    HIPCHK(hipMemsetAsync(b->d_sched, 0, sizeof(uint32_t) * ((size_t)b->queues_cap + 2 * 16384 + 1), st));
     HIPCHK(hipMemsetAsync(b->d_status, 0, sizeof(int32_t) * b->n_loaded, st));
     HIPCHK(hipMemsetAsync(b->d_consumed, 0, sizeof(uint32_t) * b->n_loaded, st));
     HIPCHK(hipMemsetAsync(b->d_prof, 0, sizeof(unsigned long long) * 8 * b->n_loaded, st));
@@ -357,7 +377,13 @@ int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
     P.coef = b->d_coef; P.coef_stride = b->plan.coef_elems; P.meta = b->d_meta; P.status = b->d_status; P.consumed = b->d_consumed;
     P.tables = b->d_tables; P.scratch = b->d_scratch; P.scratch_stride = b->scratch_stride; P.bfs_off = b->bfs_off; P.leaves_off = b->leaves_off;
     P.stack_off = b->stack_off; P.queue_off = b->queue_off; P.subtree_off = b->subtree_off; P.max_properties = b->plan.max_properties; P.max_nodes = b->max_nodes; P.max_super = maniac_max_supernodes(b->max_nodes); P.prof = b->d_prof;
-    P.tiles = b->d_tiles; P.n_tiles = b->n_tiles; P.queue_head = b->d_queue_head; P.progress = b->d_progress; P.group_start = b->d_group_start;
+    if (b->want_tile_log && b->tile_log_cap < b->n_tiles) {
+        hipFree(b->d_tile_log); b->d_tile_log = nullptr; b->tile_log_cap = 0;
+        HIPCHK(hipMalloc((void **)&b->d_tile_log, sizeof(unsigned long long) * 4 * (size_t)b->n_tiles));
+        b->tile_log_cap = b->n_tiles;
+    }
+    P.tile_log = b->want_tile_log ? b->d_tile_log : nullptr;
+    P.tiles = b->d_tiles; P.n_tiles = b->n_tiles; P.q_begin = b->d_qbegin; P.q_head = b->d_sched; P.n_queues = b->n_queues; P.simd_claim = b->d_sched + b->queues_cap; P.progress = b->d_progress; P.group_start = b->d_group_start;
     HIPCHK(hipEventRecord(b->ev[0], st));
     launch_maniac_decode(P, b->n_waves, b->dense, b->n_tiles > b->n_loaded ? 1 : 0, st);
     HIPCHK(hipGetLastError());
@@ -521,6 +547,18 @@ int fuifgpu_batch_profile(fuifgpu_batch *b, uint64_t *out8_per_image) {
     if (!b || !out8_per_image || b->n_loaded < 1) return FUIFGPU_E_ARG;
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out8_per_image, b->d_prof, sizeof(unsigned long long) * 8 * b->n_loaded, hipMemcpyDeviceToHost));
+    return FUIFGPU_OK;
+}
+
+// diagnostic: schedule of the last decode launch.  The first call (cap 0 is fine) switches logging on for later launches.
+int fuifgpu_batch_tile_log(fuifgpu_batch *b, uint64_t *out4_per_tile, int cap, int *n_tiles) {
+    if (!b || !n_tiles) return FUIFGPU_E_ARG;
+    const bool had = b->want_tile_log && b->d_tile_log && b->tile_log_cap >= b->n_tiles;
+    b->want_tile_log = true;
+    *n_tiles = had ? b->n_tiles : 0;
+    if (!had || !out4_per_tile) return FUIFGPU_OK;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out4_per_tile, b->d_tile_log, sizeof(unsigned long long) * 4 * (size_t)std::min(cap, b->n_tiles), hipMemcpyDeviceToHost));
     return FUIFGPU_OK;
 }
 

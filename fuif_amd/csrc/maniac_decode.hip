@@ -132,6 +132,11 @@ DEV void drain_stores() {}
 #else
 DEV void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #endif
+#ifdef FUIF_EMU
+DEV unsigned long long realtime() { return 0; }
+#else
+DEV unsigned long long realtime() { return __builtin_amdgcn_s_memrealtime(); }   // 100 MHz, same clock on every CU
+#endif
 constexpr uint32_t kSpinLimit = 1u << 25;   // x (sleep + one L2 round trip) ~ a minute: only a lost producer gets here
 
 struct Node {  // maniac/compound.h:41-51; property -1 = leaf, child = leaf id
@@ -446,16 +451,55 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         exit_q = 2 * exit_q + (gt ? 1 : 2);
     }
 
-    // ---- persistent wavefront: take tiles in list order until the list is empty ----------------
-    // A tile only waits for tiles EARLIER in the list, and a tile that has been taken is running on
-    // a resident wavefront, so the earliest unfinished tile can always make progress: no deadlock,
-    // whatever the dispatch order or placement of the wavefronts.
+    // ---- persistent wavefront: take tiles in list order until every queue is empty ---------------
+    // A tile only waits for tiles EARLIER in its queue, and a tile that has been taken is running on
+    // a resident wavefront, so the earliest unfinished tile of a queue can always make progress: no
+    // deadlock, whatever the dispatch order or placement of the wavefronts.
+    const int n_queues = P.n_queues;
+    int cur_q = 0, q_exhausted = 0;
+    uint32_t simd_key = 0;
+    if (n_queues > 1) {
+        // home queue = dense index of the SIMD this wavefront sits on (first arrival numbers it)
+#ifdef FUIF_EMU
+        const uint32_t key = (uint32_t)blockIdx.x >> 2;
+#else
+        const uint32_t hw = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID: simd [5:4], cu/sh/se [15:8]
+        const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+        const uint32_t key = ((hw >> 4) & 3u) | (((hw >> 8) & 0xFFu) << 2) | ((xcc & 15u) << 10);
+#endif
+        simd_key = key;
+        uint32_t idx = 0;
+        if (lane == 0) {
+            if (atomicAdd(&P.simd_claim[2 * key], 1u) == 0u) {
+                idx = atomicAdd(&P.simd_claim[2 * 16384], 1u);
+                st_agent(&P.simd_claim[2 * key + 1], idx + 1u);
+            } else {
+                uint32_t v = 0;
+                while ((v = ld_agent(&P.simd_claim[2 * key + 1])) == 0u) __builtin_amdgcn_s_sleep(2);
+                idx = v - 1u;
+            }
+        }
+        cur_q = (int)(rflu(idx) % (uint32_t)n_queues);
+    }
     for (;;) {
-    uint32_t tix = 0;
-    if (lane == 0) tix = atomicAdd(P.queue_head, 1u);
+    uint32_t tix = 0xFFFFFFFFu;
+    if (lane == 0) {
+        const uint32_t qb = P.q_begin[cur_q], qn = P.q_begin[cur_q + 1] - qb;
+        if (ld_agent(&P.q_head[cur_q]) < qn) {
+            const uint32_t k = atomicAdd(&P.q_head[cur_q], 1u);
+            if (k < qn) tix = qb + k;
+        }
+    }
     tix = rflu(tix);
-    if (tix >= (uint32_t)P.n_tiles) break;
+    if (tix == 0xFFFFFFFFu) {
+        // this queue is empty: help with the next one (each queue is found empty once)
+        if (++q_exhausted >= n_queues) break;
+        cur_q = cur_q + 1 == n_queues ? 0 : cur_q + 1;
+        continue;
+    }
     const Tile tile = P.tiles[tix];
+    const unsigned long long tile_t0 = realtime();
+    unsigned long long waited = 0;
     const int img = rfl((int)tile.image);
     const int first_c = rfl(tile.first_channel), last_c = rfl(tile.last_channel);
 
@@ -482,9 +526,13 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
     };
     auto wait_header = [&](int c) {
         uint32_t spins = 0;
-        while (!stalled && rflu(ld_agent(progress + c)) == 0u) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > kSpinLimit) { stalled = true; status |= ST_STALLED | ST_CORRUPT; }
+        if (!stalled && rflu(ld_agent(progress + c)) == 0u) {
+            const unsigned long long w0 = realtime();
+            while (!stalled && rflu(ld_agent(progress + c)) == 0u) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > kSpinLimit) { stalled = true; status |= ST_STALLED | ST_CORRUPT; }
+            }
+            waited += realtime() - w0;
         }
     };
 
@@ -865,11 +913,16 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                 fp = progress + rc.chan;
                             }
                             uint32_t spins = 0;
-                            while (__any(ref_seen < need) && !stalled) {
+                            if (__any(ref_seen < need)) {
                                 if (ref_seen < need) ref_seen = ld_agent(fp);
                                 if (__any(ref_seen < need)) {
-                                    __builtin_amdgcn_s_sleep(8);
-                                    if (++spins > kSpinLimit) { stalled = true; status |= ST_STALLED | ST_CORRUPT; }
+                                    const unsigned long long w0 = realtime();
+                                    while (__any(ref_seen < need) && !stalled) {
+                                        __builtin_amdgcn_s_sleep(8);
+                                        if (++spins > kSpinLimit) { stalled = true; status |= ST_STALLED | ST_CORRUPT; }
+                                        if (ref_seen < need) ref_seen = ld_agent(fp);
+                                    }
+                                    waited += realtime() - w0;
                                 }
                             }
                         }
@@ -1048,6 +1101,12 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         }
     }
     if (lane == 0) { atomicOr(&P.status[img], status); atomicMax(&P.consumed[img], s.pos); }
+    if (lane == 0 && P.tile_log) {
+        unsigned long long *tl = P.tile_log + (size_t)tix * 4;
+        tl[0] = ((unsigned long long)(uint32_t)img << 32) | (uint32_t)first_c;
+        tl[1] = tile_t0; tl[2] = realtime();
+        tl[3] = (waited & 0xFFFFFFFFFFFFull) | ((unsigned long long)simd_key << 48);
+    }
 #ifdef FUIF_PROF
     if (lane == 0 && P.prof) for (int k = 0; k < 8; k++) atomicAdd(&P.prof[(size_t)img * 8 + k], prof_acc[k]);
 #endif
@@ -1055,13 +1114,14 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
     }  // tile loop
 }
 
-int maniac_max_waves(int dense) {
+int maniac_max_waves(int dense, int *per_simd) {
     int dev = 0, per_cu = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
     hipError_t e = dense ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_maniac_decode<kLdsDense, true>, 64, 0)
                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_maniac_decode<kLdsWide, true>, 64, 0);
     if (e != hipSuccess || per_cu < 1) per_cu = 1;
+    if (per_simd) *per_simd = per_cu / 4 > 0 ? per_cu / 4 : 1;   // a CU has 4 SIMDs
     return per_cu * prop.multiProcessorCount;
 }
 

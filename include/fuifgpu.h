@@ -127,6 +127,10 @@ int fuifgpu_batch_last_timing(fuifgpu_batch *batch, float *decode_ms, float *tra
  * {vector phase, property patch, tree walk, leaf switch, symbol decode, per-pixel rest, row store, -};
  * all zero in release builds */
 int fuifgpu_batch_profile(fuifgpu_batch *batch, uint64_t *out8_per_image);
+/* diagnostic: the schedule of the last decode launch, 4 words per tile of the work list {image << 32 | first channel,
+ * start, end, ticks spent waiting for other tiles' rows | SIMD key << 48}, times in 100 MHz s_memrealtime ticks.
+ * Logging starts with the first call (which returns *n_tiles = 0); tools/tile_timeline.py turns it into a report. */
+int fuifgpu_batch_tile_log(fuifgpu_batch *batch, uint64_t *out4_per_tile, int cap, int *n_tiles);
 
 /* ---- group index (csrc/index.cpp) --------------------------------------
  * A FUIF stream is a chain of channel groups (fuif_decode_channel, encoding/encoding.cpp:259-429),
