@@ -76,7 +76,7 @@ ABI_SYMBOLS = [
     "fuifgpu_build_chance_table", "fuifgpu_batch_create", "fuifgpu_batch_destroy", "fuifgpu_batch_upload",
     "fuifgpu_batch_decode", "fuifgpu_batch_undo_transforms", "fuifgpu_batch_sync", "fuifgpu_batch_status",
     "fuifgpu_batch_channel_meta", "fuifgpu_batch_coef_ptr", "fuifgpu_batch_out_ptr", "fuifgpu_batch_download_coef",
-    "fuifgpu_batch_download_out", "fuifgpu_batch_last_timing", "fuifgpu_batch_profile", "fuifgpu_batch_tile_log", "fuifgpu_inv_hsqueeze", "fuifgpu_inv_vsqueeze",
+    "fuifgpu_batch_download_out", "fuifgpu_batch_last_timing", "fuifgpu_batch_profile", "fuifgpu_batch_tile_log", "fuifgpu_batch_sched_stats", "fuifgpu_inv_hsqueeze", "fuifgpu_inv_vsqueeze",
     "fuifgpu_inv_ycocg", "fuifgpu_inv_ycbcr", "fuifgpu_idct8x8", "fuifgpu_upsample", "fuifgpu_encode_image", "fuifgpu_encode_channels", "fuifgpu_free_blob",
     "fuifgpu_index_parse", "fuifgpu_index_append", "fuifgpu_batch_group_index", "fuifgpu_batch_set_group_parallel",
     "fuifgpu_plan_packed_bytes", "fuifgpu_batch_pack_out", "fuifgpu_batch_download_packed",
@@ -139,6 +139,7 @@ def lib():
     L.fuifgpu_batch_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.fuifgpu_batch_profile.argtypes = [vp, vp]
     L.fuifgpu_batch_tile_log.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
+    L.fuifgpu_batch_sched_stats.argtypes = [vp, vp]
     L.fuifgpu_inv_hsqueeze.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, vp]
     L.fuifgpu_inv_vsqueeze.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, vp]
     L.fuifgpu_inv_ycocg.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
@@ -291,6 +292,11 @@ class Batch:
         if n.value:
             _check(lib().fuifgpu_batch_tile_log(self._h, out.ctypes.data, n.value, C.byref(n)))
         return out[: n.value]
+
+    def sched_stats(self):
+        out = np.zeros(8, np.uint64)
+        _check(lib().fuifgpu_batch_sched_stats(self._h, out.ctypes.data))
+        return out
 
     def coef_planes(self, image):
         """coded channel planes of one image as a list of (h,w) int32 arrays (device -> host)"""

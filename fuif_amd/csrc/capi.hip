@@ -45,9 +45,13 @@ struct fuifgpu_batch {
     Tile *d_tiles = nullptr;
     int tiles_cap = 0, n_tiles = 0;
     uint32_t *d_progress = nullptr, *d_group_start = nullptr;
-    // work queues of the entropy kernel (maniac_decode.h): d_sched = [q_head: queues_cap][simd_claim: 2*16384+1], zeroed per launch
-    uint32_t *d_sched = nullptr, *d_qbegin = nullptr;
-    int queues_cap = 0, n_queues = 1, waves_per_simd = 4;
+    // scheduler state of the entropy kernel (maniac_decode.h), zeroed per launch, and the queue / image layout tables
+    uint32_t *d_sched = nullptr, *d_layout = nullptr;
+    size_t sched_words = 0, layout_cap = 0;
+    int sched = 0, n_queues = 1, waves_per_simd = 4;
+    uint8_t *d_ctx = nullptr;         // context areas of suspendable tiles (sched == 1)
+    size_t ctx_bytes = 0;
+    uint32_t ctx_units_per_queue = 0;
     std::vector<Tile> tiles;
     int max_nodes = kMaxNodes;
     int32_t *d_coef = nullptr, *d_out = nullptr, *d_tmp = nullptr;
@@ -177,7 +181,7 @@ void fuifgpu_batch_destroy(fuifgpu_batch *b) {
     if (!b) return;
     hipFree(b->d_blobs); hipFree(b->d_jobs); hipFree(b->d_geom); hipFree(b->d_meta); hipFree(b->d_status); hipFree(b->d_consumed);
     hipFree(b->d_tables); hipFree(b->d_scratch); hipFree(b->d_tmp); hipFree(b->d_list); hipFree(b->d_prof); hipFree(b->d_tile_log);
-    hipFree(b->d_tiles); hipFree(b->d_progress); hipFree(b->d_group_start); hipFree(b->d_sched); hipFree(b->d_qbegin);
+    hipFree(b->d_tiles); hipFree(b->d_progress); hipFree(b->d_group_start); hipFree(b->d_sched); hipFree(b->d_layout); hipFree(b->d_ctx);
     if (b->own_coef) hipFree(b->d_coef);
     if (b->own_out) hipFree(b->d_out);
     if (b->h_blobs) hipHostFree(b->h_blobs);
@@ -310,39 +314,76 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
         t.last_channel = k + 1 < g.size() ? g[k + 1].first_channel - 1 : nch - 1;
         b->tiles.push_back(t);
     };
-    // Dense launches: one queue per SIMD (= per waves_per_simd resident wavefronts), image i in queue i % n_queues, an image's tiles
-    // in stream order (a tile only ever waits for EARLIER tiles of its own queue).  A SIMD's wavefronts then work
-    // through whole images: every SIMD gets the same work, and the long final groups of an image start as soon as
-    // four of its tiles are done instead of when the whole batch has reached them (measured, 1024 x 4K: see
-    // profiles/r2_*).  FUIFGPU_TILE_ORDER=group (diagnostic) restores the single group-major list of round 1: tile k
-    // of every image before tile k+1 of any.
+    // Dense launches with more tiles than wavefronts use the context scheduler (maniac_decode.h, sched == 1): tiles image by
+    // image in stream order, images dealt to one queue per CU, a tile that would wait for another tile's rows is
+    // suspended instead of holding its wavefront (measured on 1024 x 4K: a quarter of all wavefront time was spent in
+    // such waits, profiles/r2_tile_timeline_baseline.txt).  Otherwise -- and with FUIFGPU_TILE_ORDER=group, a diagnostic
+    // -- one group-major list as in round 1: tile k of every image before tile k+1 of any.
     const char *ord = getenv("FUIFGPU_TILE_ORDER");
-    const bool group_major = !b->dense || (ord && !strcmp(ord, "group"));
+    b->sched = b->dense && (int64_t)total_tiles > b->n_waves && !(ord && !strcmp(ord, "group")) ? 1 : 0;
     b->tiles.clear();
-    std::vector<uint32_t> qbegin;
-    if (group_major) {
+    std::vector<uint32_t> layout;   // sched: q_img_begin [Q+1] | q_images [n] | img_tile_begin [n+1]
+    if (!b->sched) {
         b->n_queues = 1;
         for (size_t k = 0; k < deepest; k++)
             for (int i = 0; i < n_images; i++) push_tile(i, k);
-        qbegin = {0u, (uint32_t)b->tiles.size()};
     } else {
-        b->n_queues = std::max(1, std::min(n_images, b->n_waves / std::max(1, b->waves_per_simd)));
-        for (int q = 0; q < b->n_queues; q++) {
-            qbegin.push_back((uint32_t)b->tiles.size());
-            for (int i = q; i < n_images; i += b->n_queues)
-                for (size_t k = 0; k < groups[group_of[i]].size(); k++) push_tile(i, k);
+        const int waves_per_cu = 4 * std::max(1, b->waves_per_simd);
+        b->n_queues = std::max(1, std::min(n_images, b->n_waves / waves_per_cu));
+        const int Q = b->n_queues;
+        layout.resize((size_t)Q + 1 + n_images + n_images + 1);
+        uint32_t *qib = layout.data(), *qim = qib + Q + 1, *itb = qim + n_images;
+        uint32_t pos = 0;
+        for (int q = 0; q < Q; q++) {
+            qib[q] = pos;
+            for (int i = q; i < n_images; i += Q) qim[pos++] = (uint32_t)i;
         }
-        qbegin.push_back((uint32_t)b->tiles.size());
+        qib[Q] = pos;
+        for (int i = 0; i < n_images; i++) {
+            itb[i] = (uint32_t)b->tiles.size();
+            for (size_t k = 0; k < groups[group_of[i]].size(); k++) push_tile(i, k);
+        }
+        itb[n_images] = (uint32_t)b->tiles.size();
     }
-    if (b->n_queues > b->queues_cap) {
-        hipFree(b->d_sched); hipFree(b->d_qbegin); b->d_sched = b->d_qbegin = nullptr; b->queues_cap = 0;
-        HIPCHK(hipMalloc((void **)&b->d_sched, sizeof(uint32_t) * ((size_t)b->n_queues + 2 * 16384 + 1)));
-        HIPCHK(hipMalloc((void **)&b->d_qbegin, sizeof(uint32_t) * ((size_t)b->n_queues + 1)));
-        b->queues_cap = b->n_queues;
-    }
-    HIPCHK(hipMemcpyAsync(b->d_qbegin, qbegin.data(), sizeof(uint32_t) * qbegin.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));  // qbegin is a local
     b->n_tiles = (int)b->tiles.size();
+    {
+        // scheduler state, zeroed before every launch: q_head | done_total | cu claim table | img_next | img_done | ctx_used | tile records
+        const size_t words = 18 + (2 * 4096 + 1) + 2 * (size_t)n_images + 2 * (size_t)b->n_queues + (b->sched ? (size_t)b->n_tiles * (sizeof(TileRec) / 4) : 0);
+        if (words > b->sched_words) {
+            hipFree(b->d_sched); b->d_sched = nullptr; b->sched_words = 0;
+            HIPCHK(hipMalloc((void **)&b->d_sched, words * 4));
+            b->sched_words = words;
+        }
+        if (layout.size() > b->layout_cap) {
+            hipFree(b->d_layout); b->d_layout = nullptr; b->layout_cap = 0;
+            HIPCHK(hipMalloc((void **)&b->d_layout, layout.size() * 4));
+            b->layout_cap = layout.size();
+        }
+        if (!layout.empty()) HIPCHK(hipMemcpyAsync(b->d_layout, layout.data(), layout.size() * 4, hipMemcpyHostToDevice, st));
+        if (b->sched) {
+            // Context arenas: a suspendable tile keeps its supernodes and leaf chances in its image's queue arena (bump
+            // allocation inside a launch).  16 MiB per image covers trees of ~2000 nodes on every tile of a 61-tile image
+            // three times over (FUIFGPU_CTX_MB overrides); a tile that finds the arena full is simply not suspendable.
+            size_t per_image = 16u << 20;
+            if (const char *e = getenv("FUIFGPU_CTX_MB")) per_image = (size_t)std::max(1, atoi(e)) << 20;
+            const size_t images_per_queue = ((size_t)n_images + b->n_queues - 1) / b->n_queues;
+            size_t per_queue = per_image * images_per_queue;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const size_t budget = (free_b + b->ctx_bytes) / 2;   // never more than half of what is left
+                if (per_queue * (size_t)b->n_queues > budget) per_queue = budget / (size_t)b->n_queues;
+            }
+            per_queue = std::min<size_t>(per_queue / 256 * 256, (size_t)0xFFFFFF00u / (size_t)b->n_queues * 256);
+            b->ctx_units_per_queue = (uint32_t)(per_queue / 256);
+            const size_t need = per_queue * (size_t)b->n_queues;
+            if (need > b->ctx_bytes) {
+                hipFree(b->d_ctx); b->d_ctx = nullptr; b->ctx_bytes = 0;
+                HIPCHK(hipMalloc((void **)&b->d_ctx, std::max<size_t>(need, 256)));
+                b->ctx_bytes = need;
+            }
+        }
+        HIPCHK(hipStreamSynchronize(st));  // layout is a local
+    }
     if (b->n_tiles > b->tiles_cap) {
         hipFree(b->d_tiles); b->d_tiles = nullptr; b->tiles_cap = 0;
         HIPCHK(hipMalloc((void **)&b->d_tiles, sizeof(Tile) * (size_t)b->n_tiles));
@@ -368,7 +409,7 @@ int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
     // every word the tiles poll or accumulate into is zeroed before every launch
     HIPCHK(hipMemsetAsync(b->d_progress, 0, sizeof(uint32_t) * (size_t)b->n_loaded * std::max(nch, 1), st));
     HIPCHK(hipMemsetAsync(b->d_group_start, 0, sizeof(uint32_t) * (size_t)b->n_loaded * std::max(nch, 1), st));
-    HIPCHK(hipMemsetAsync(b->d_sched, 0, sizeof(uint32_t) * ((size_t)b->queues_cap + 2 * 16384 + 1), st));
+    HIPCHK(hipMemsetAsync(b->d_sched, 0, b->sched_words * 4, st));
     HIPCHK(hipMemsetAsync(b->d_status, 0, sizeof(int32_t) * b->n_loaded, st));
     HIPCHK(hipMemsetAsync(b->d_consumed, 0, sizeof(uint32_t) * b->n_loaded, st));
     HIPCHK(hipMemsetAsync(b->d_prof, 0, sizeof(unsigned long long) * 8 * b->n_loaded, st));
@@ -383,7 +424,21 @@ int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
         b->tile_log_cap = b->n_tiles;
     }
     P.tile_log = b->want_tile_log ? b->d_tile_log : nullptr;
-    P.tiles = b->d_tiles; P.n_tiles = b->n_tiles; P.q_begin = b->d_qbegin; P.q_head = b->d_sched; P.n_queues = b->n_queues; P.simd_claim = b->d_sched + b->queues_cap; P.progress = b->d_progress; P.group_start = b->d_group_start;
+    P.tiles = b->d_tiles; P.n_tiles = b->n_tiles; P.sched = b->sched; P.n_queues = b->n_queues;
+    {
+        uint32_t *w = b->d_sched;
+        P.q_head = w; P.done_total = w + 1; P.sched_stats = reinterpret_cast<unsigned long long *>(w + 2); w += 18;
+        P.yield_slack = 8;
+        if (const char *e = getenv("FUIFGPU_YIELD_SLACK")) P.yield_slack = (uint32_t)std::max(0, atoi(e));
+        P.simd_claim = w; w += 2 * 4096 + 1;
+        P.img_next = w; w += b->n_loaded;
+        P.img_done = w; w += b->n_loaded;
+        P.ctx_used = w; w += b->n_queues;
+        P.q_turn = w; w += b->n_queues;
+        P.tile_rec = reinterpret_cast<TileRec *>(w);
+        P.q_img_begin = b->d_layout; P.q_images = b->d_layout + b->n_queues + 1; P.img_tile_begin = b->d_layout + b->n_queues + 1 + b->n_loaded;
+        P.ctx_scratch = b->d_ctx; P.ctx_units_per_queue = b->ctx_units_per_queue;
+    } P.progress = b->d_progress; P.group_start = b->d_group_start;
     HIPCHK(hipEventRecord(b->ev[0], st));
     launch_maniac_decode(P, b->n_waves, b->dense, b->n_tiles > b->n_loaded ? 1 : 0, st);
     HIPCHK(hipGetLastError());
@@ -559,6 +614,14 @@ int fuifgpu_batch_tile_log(fuifgpu_batch *b, uint64_t *out4_per_tile, int cap, i
     if (!had || !out4_per_tile) return FUIFGPU_OK;
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out4_per_tile, b->d_tile_log, sizeof(unsigned long long) * 4 * (size_t)std::min(cap, b->n_tiles), hipMemcpyDeviceToHost));
+    return FUIFGPU_OK;
+}
+
+// diagnostic: scheduler counters of the last dense launch {idle ticks (100 MHz) summed over wavefronts, tiles picked up, suspensions, ticks spent picking, ticks spent spinning inside tiles, suspendable tiles that found the arena full}
+int fuifgpu_batch_sched_stats(fuifgpu_batch *b, uint64_t *out8) {
+    if (!b || !out8 || !b->d_sched) return FUIFGPU_E_ARG;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out8, b->d_sched + 2, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return FUIFGPU_OK;
 }
 

@@ -6,6 +6,21 @@
 
 namespace fuifgpu {
 
+// Saved state of a suspended tile (sched == 1).  Written by the wavefront that suspends it, then `state` is released;
+// read by the wavefront that wins the READY -> RUNNING exchange.
+enum : uint32_t { TS_NEW = 0, TS_READY = 1, TS_RUNNING = 2, TS_DONE = 3 };
+struct TileRec {
+    uint32_t state;
+    uint32_t wait_chan, wait_val;   // runnable once progress[wait_chan] >= wait_val
+    uint32_t y;                     // next row
+    uint32_t range, low, pos;       // range coder + stream position
+    uint32_t flags;                 // status bits 0..7 | eof_flag << 8 | predictor << 9
+    uint32_t ctx, ctx_leaves;       // context area: offset into ctx_scratch, offset of the leaf chances inside it (256-byte units)
+    uint32_t tree_size, n_super, cur_leaf;
+    uint32_t t_first_lo, t_first_hi, run_ticks, pad[3];
+    uint32_t owner;                 // 1 + CU key of the wavefronts that may resume it (the CU that suspended it)
+};
+
 struct DecodeParams {
     const uint8_t *blobs;        // all streams of the batch, each 16-byte aligned and padded
     const StreamJob *jobs;
@@ -22,15 +37,34 @@ struct DecodeParams {
     // out to persistent wavefronts through *queue_head
     const Tile *tiles;
     int32_t n_tiles;
-    // The list is cut into n_queues queues (tiles [q_begin[q], q_begin[q+1]), each with its own head counter).  A
-    // wavefront's home queue follows from the SIMD it runs on (simd_claim: physical id -> dense index, filled in by
-    // the first wavefront of every SIMD); with one image per queue a SIMD's resident wavefronts work through one
-    // image, so every SIMD gets the same amount of work whatever the order wavefronts finish in.  A wavefront whose
-    // home queue is empty goes through the other queues (the mapping is an affinity, never a requirement).
-    const uint32_t *q_begin;     // [n_queues + 1]
-    uint32_t *q_head;            // [n_queues], zeroed before the launch
+    // Two ways of handing tiles to the persistent wavefronts:
+    //  sched == 0: one list, one head counter (q_head[0]); a tile runs to completion on the wavefront that took it and
+    //              spins when it needs rows another tile has not finished yet;
+    //  sched == 1: "contexts" (dense launches with more tiles than wavefronts).  The tiles of an image are contiguous
+    //              and in stream order; images are dealt to n_queues queues, one per CU (simd_claim: physical CU ->
+    //              dense index, numbered by first arrival; an affinity, never a requirement).  A wavefront looks for
+    //              work in its home queue, then in the next few: first a SUSPENDED tile whose awaited rows have
+    //              arrived, else the next unstarted tile of an image.  A tile that meets unfinished reference rows
+    //              saves its coder state in its TileRec (its tree and leaf chances live in a context area, not in the
+    //              wavefront's scratch) and gives the wavefront back instead of spinning; a wavefront of the same CU
+    //              resumes it later.
+    int32_t sched;
+    uint32_t yield_slack;        // a suspended tile is runnable again once the rows it waits for are this many rows ahead (or final)
     int32_t n_queues;
-    uint32_t *simd_claim;        // [2 * 16384 + 1] {arrivals, 1 + dense index} per physical SIMD key, then the SIMD counter; zeroed before the launch
+    uint32_t *q_head;            // sched 0: [1] head of the single list; zeroed before the launch
+    const uint32_t *q_img_begin; // sched 1: [n_queues + 1] into q_images
+    const uint32_t *q_images;    // sched 1: image ids, queue by queue
+    const uint32_t *img_tile_begin; // sched 1: [n_images + 1]: tiles of image i are tiles[img_tile_begin[i] .. img_tile_begin[i+1])
+    uint32_t *img_next;          // sched 1: [n_images] tiles started; zeroed before the launch
+    uint32_t *img_done;          // sched 1: [n_images] tiles finished; zeroed before the launch
+    uint32_t *q_turn;            // sched 1: [n_queues] whose turn it is to start a tile; zeroed before the launch
+    uint32_t *done_total;        // sched 1: tiles finished; zeroed before the launch
+    TileRec *tile_rec;           // sched 1: [n_tiles]; zeroed before the launch
+    uint8_t *ctx_scratch;        // sched 1: one arena per queue for the context areas (supernodes | leaf chances) of its images' tiles
+    uint32_t ctx_units_per_queue; //         arena size in 256-byte units
+    uint32_t *ctx_used;          // sched 1: [n_queues] units handed out (bump allocation: a launch never frees); zeroed before the launch
+    unsigned long long *sched_stats; // sched 1: {ticks wavefronts spent without work before the last tile finished, tiles picked up, suspensions}; zeroed before the launch
+    uint32_t *simd_claim;        // [2 * 4096 + 1] {arrivals, 1 + dense index} per physical CU key, then the CU counter; zeroed before the launch
     uint32_t *progress;          // [n_images][n_channels] 0 = nothing yet, 1 + rows finished once the header is known; zeroed before the launch
     uint32_t *group_start;       // [n_images][n_channels] 1 + byte offset of the group that starts at this channel (0 = none); zeroed before the launch
     uint8_t *scratch;            // per wavefront: parse-order nodes | breadth-first nodes | leaves | parse stack | BFS queue

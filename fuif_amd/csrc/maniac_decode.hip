@@ -98,11 +98,12 @@ constexpr int kPropPitch = 33;    // odd pitch: conflict-free column writes / ro
 #endif
 constexpr int kChunk = FUIF_CHUNK;
 static_assert(kChunk == 64 || kChunk == 32 || kChunk == 16, "chunk must divide the wavefront");
-#ifdef FUIF_WAVES
-#define FUIF_OCCUPANCY __attribute__((amdgpu_waves_per_eu(FUIF_WAVES, FUIF_WAVES)))
-#else
-#define FUIF_OCCUPANCY
+// The dense configuration is built for 4 wavefronts per SIMD: 128 VGPRs (the compiler may spill a few
+// SGPR-to-VGPR homes; without the bound the scheduler code pushed it to 134 and the CU lost a quarter of its wavefronts)
+#ifndef FUIF_WAVES
+#define FUIF_WAVES 4
 #endif
+#define FUIF_OCCUPANCY __attribute__((amdgpu_waves_per_eu(FUIF_WAVES, FUIF_WAVES)))
 
 DEV int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 DEV uint32_t rflu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -137,7 +138,9 @@ DEV unsigned long long realtime() { return 0; }
 #else
 DEV unsigned long long realtime() { return __builtin_amdgcn_s_memrealtime(); }   // 100 MHz, same clock on every CU
 #endif
-constexpr uint32_t kSpinLimit = 1u << 25;   // x (sleep + one L2 round trip) ~ a minute: only a lost producer gets here
+constexpr uint32_t kSpinLimit = 1u << 25;
+constexpr uint32_t kYieldSlack = 8;
+constexpr uint32_t kActiveImages = 6;  // images of a queue that are being worked on at a time (context scheduler)   // a suspended tile is resumed once the rows it waits for are this many rows ahead (or final)   // x (sleep + one L2 round trip) ~ a minute: only a lost producer gets here
 
 struct Node {  // maniac/compound.h:41-51; property -1 = leaf, child = leaf id
     int32_t splitval;
@@ -149,7 +152,7 @@ struct Node {  // maniac/compound.h:41-51; property -1 = leaf, child = leaf id
 // loads (it sinks the splitval load behind the leaf test), doubling the per-level latency.
 #ifdef FUIF_EMU
 // emulator-only statistics (tools/emu_walk_stats.py): where the walk rounds behind the root supernode are served from
-extern unsigned long long g_emu_stats[4];   // symbols with a walk, rounds from LDS, rounds from scratch memory, -
+extern unsigned long long g_emu_stats[4];   // symbols with a walk, rounds from LDS, rounds from scratch memory, suspended tiles
 #define EMU_COUNT(k) do { if (lane == 0) __atomic_fetch_add(&g_emu_stats[k], 1ull, __ATOMIC_RELAXED); } while (0)
 static thread_local const char *emu_lds_base;   // LDS byte addresses are offsets from the supernode array in the emulator
 DEV uint2 lds_load_node(uint32_t lds_byte_addr) { return *reinterpret_cast<const uint2 *>(emu_lds_base + lds_byte_addr); }
@@ -357,6 +360,175 @@ DEV int leaf_symbol(Rac &r, Stream &s, int lane, LeafRegs &L, int min, int max) 
     }
     return result;
 }
+// ---- the common case of leaf_symbol, written for the instruction count ---------------------------------------
+// Preconditions (checked by the caller): min < 0 < max (zero and sign are both coded), and the next 64 stream bytes lie
+// inside the 256-byte window (a symbol reads at most 2 bytes per decision, 31 decisions), so a renormalisation is a
+// register shuffle with no end-of-stream or refill case.  Differences to leaf_symbol: the decision is a SCALAR compare of
+// `low` with the threshold of the chance in use (v_readlane of the per-lane thresholds) instead of a vector compare whose
+// mask is then picked apart; the (index, bit) bookkeeping of the exponent and mantissa is reconstructed after the loops
+// from e and the magnitude instead of being updated per decision; a mantissa bit can only be impossible when e == emax.
+struct FastSym {
+    int amax_pos, amax_neg, emax_pos, emax_neg;
+};
+DEV uint32_t lane_thresholds(uint32_t range, int leafv) {   // rac.h:43-52 for every lane's own chance: range - chance
+    return range - (uint32_t)(((unsigned long long)range * (uint32_t)leafv + 0x800ull) >> 12);
+}
+DEV void fast_renorm(Rac &r, Stream &s) {   // rac.h:70-81 with the bytes taken from the window registers
+    if (UNLIKELY(r.range <= 0x10000u)) {
+        uint32_t idx = s.pos - s.win_base;
+        uint32_t word = (uint32_t)rdlane((int)s.win, (int)(idx >> 2));
+        r.low = (r.low << 8) | ((word >> ((idx & 3u) * 8u)) & 0xFFu); r.range <<= 8; s.pos++;
+        if (UNLIKELY(r.range <= 0x10000u)) {
+            idx = s.pos - s.win_base;
+            word = (uint32_t)rdlane((int)s.win, (int)(idx >> 2));
+            r.low = (r.low << 8) | ((word >> ((idx & 3u) * 8u)) & 0xFFu); r.range <<= 8; s.pos++;
+        }
+    }
+}
+DEV int fast_symbol(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
+    uint32_t thr = (uint32_t)rdlane((int)lane_thresholds(r.range, L.leafv), CH_ZERO);
+    if (r.low >= thr) {   // the symbol is zero
+        r.low -= thr; r.range -= thr;
+        fast_renorm(r, s);
+        L.touched = 1u; L.bits = 1u;
+        return 0;
+    }
+    r.range = thr;
+    fast_renorm(r, s);
+    thr = (uint32_t)rdlane((int)lane_thresholds(r.range, L.leafv), CH_SIGN);
+    const bool sign = r.low >= thr;
+    r.range = sign ? r.range - thr : thr;
+    r.low -= sign ? thr : 0u;
+    fast_renorm(r, s);
+    const int amax = sign ? F.amax_pos : F.amax_neg, emax = sign ? F.emax_pos : F.emax_neg;
+    int e = 0;
+    uint32_t one = 0;
+    while (e < emax) {   // unary exponent: symbol.h:167-170
+        thr = (uint32_t)rdlane((int)lane_thresholds(r.range, L.leafv), CH_EXP + e);
+        if (r.low >= thr) { r.low -= thr; r.range -= thr; fast_renorm(r, s); one = 1u; break; }
+        r.range = thr;
+        fast_renorm(r, s);
+        e++;
+    }
+    int have = 1 << e;
+    uint32_t skipped = 0;
+    if (LIKELY(e < emax)) {
+        // have | 1 << pos < 2^(e+1) <= 2^emax <= amax: every mantissa bit is coded (symbol.h:173-183)
+        for (int pos = e - 1; pos >= 0; pos--) {
+            thr = (uint32_t)rdlane((int)lane_thresholds(r.range, L.leafv), CH_MANT + pos);
+            const bool b = r.low >= thr;
+            r.range = b ? r.range - thr : thr;
+            r.low -= b ? thr : 0u;
+            fast_renorm(r, s);
+            have |= b ? (1 << pos) : 0;
+        }
+    } else {
+        for (int pos = e - 1; pos >= 0; pos--) {
+            const int minabs1 = have | (1 << pos);
+            if (minabs1 > amax) { skipped |= 1u << pos; continue; }   // the 1-bit is impossible (symbol.h:180)
+            thr = (uint32_t)rdlane((int)lane_thresholds(r.range, L.leafv), CH_MANT + pos);
+            const bool b = r.low >= thr;
+            r.range = b ? r.range - thr : thr;
+            r.low -= b ? thr : 0u;
+            fast_renorm(r, s);
+            have = b ? minabs1 : have;
+        }
+    }
+    const uint32_t emask = (1u << e) - 1u;
+    L.touched = 3u | (((1u << (e + (int)one)) - 1u) << CH_EXP) | ((emask & ~skipped) << CH_MANT);
+    L.bits = ((uint32_t)sign << CH_SIGN) | (one << (CH_EXP + e)) | (((uint32_t)have & emask) << CH_MANT);
+    return sign ? have : -have;
+}
+#ifndef FUIF_EMU
+// The same symbol decoder as fast_symbol (the C++ above is the specification and what the CPU emulator runs), hand
+// written: hipcc turns the loops with their several exits into ~30 instructions and 4-5 branches per decision (flag
+// registers and copies for every exit); this is 13 per exponent bit and 21 per mantissa bit.  v125..v127 are scratch
+// (clobbers).  Per decision: per-lane thresholds range - ((range * chance + 0x800) >> 12) as one 64-bit mad,
+// v_readlane of the lane of the chance in use, scalar compare with `low`; renormalisation out of line.
+#define FS_THR_PREP "v_mad_u64_u32 v[126:127], vcc, %[R], %[leafv], %[k800]\n\tv_alignbit_b32 v125, v127, v126, 12\n\tv_sub_u32 v125, %[R], v125\n\t"
+// one or two bytes from the window registers into `low` (rac.h:70-81), then back to label `back`
+#define FS_RENORM(lbl, back) \
+    lbl ":\n\t" \
+    "s_lshr_b32 %[t0], %[widx], 2\n\tv_readlane_b32 %[t0], %[win], %[t0]\n\ts_lshl_b32 %[t1], %[widx], 3\n\ts_lshr_b32 %[t0], %[t0], %[t1]\n\t" \
+    "s_and_b32 %[t0], %[t0], 0xff\n\ts_lshl_b32 %[L], %[L], 8\n\ts_or_b32 %[L], %[L], %[t0]\n\ts_add_u32 %[widx], %[widx], 1\n\ts_lshl_b32 %[R], %[R], 8\n\t" \
+    "s_cmp_gt_u32 %[R], 0x10000\n\ts_cbranch_scc1 " back "\n\t" \
+    "s_lshr_b32 %[t0], %[widx], 2\n\tv_readlane_b32 %[t0], %[win], %[t0]\n\ts_lshl_b32 %[t1], %[widx], 3\n\ts_lshr_b32 %[t0], %[t0], %[t1]\n\t" \
+    "s_and_b32 %[t0], %[t0], 0xff\n\ts_lshl_b32 %[L], %[L], 8\n\ts_or_b32 %[L], %[L], %[t0]\n\ts_add_u32 %[widx], %[widx], 1\n\ts_lshl_b32 %[R], %[R], 8\n\t" \
+    "s_branch " back "\n\t"
+#define FS_RN_CHECK(lbl, back) "s_cmp_le_u32 %[R], 0x10000\n\ts_cbranch_scc1 " lbl "\n" back ":\n\t"
+DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F, unsigned long long k800) {
+    uint32_t R = r.range, Lo = r.low, widx = s.pos - s.win_base;
+    uint32_t res, touched, bits, t0, t1, thr, e, amax, emax, sign, have, one, skipped;
+    asm volatile(
+        // ---- zero?  (chance 0)
+        FS_THR_PREP "s_nop 0\n\tv_readlane_b32 %[thr], v125, 0\n\t"
+        "s_cmp_ge_u32 %[L], %[thr]\n\ts_cbranch_scc1 70f\n\t"
+        "s_mov_b32 %[R], %[thr]\n\t"
+        FS_RN_CHECK("91f", "81")
+        // ---- sign  (chance 1): 1 = positive
+        FS_THR_PREP "s_nop 0\n\tv_readlane_b32 %[thr], v125, 1\n\t"
+        "s_sub_u32 %[t0], %[R], %[thr]\n\ts_cmp_ge_u32 %[L], %[thr]\n\t"
+        "s_cselect_b32 %[R], %[t0], %[thr]\n\ts_cselect_b32 %[t1], %[thr], 0\n\ts_cselect_b32 %[sign], 2, 0\n\t"
+        "s_cselect_b32 %[amax], %[amaxp], %[amaxn]\n\ts_cselect_b32 %[emax], %[emaxp], %[emaxn]\n\ts_sub_u32 %[L], %[L], %[t1]\n\t"
+        FS_RN_CHECK("92f", "82")
+        // ---- unary exponent  (chances 2 + e)
+        "s_mov_b32 %[e], 0\n\ts_mov_b32 %[one], 0\n\ts_cmp_lg_u32 %[emax], 0\n\ts_cbranch_scc0 40f\n"
+        "20:\n\t"
+        FS_THR_PREP "s_add_u32 %[t0], %[e], 2\n\tv_readlane_b32 %[thr], v125, %[t0]\n\t"
+        "s_cmp_ge_u32 %[L], %[thr]\n\ts_cbranch_scc1 25f\n\t"
+        "s_mov_b32 %[R], %[thr]\n\t"
+        FS_RN_CHECK("93f", "83")
+        "s_add_u32 %[e], %[e], 1\n\ts_cmp_lt_u32 %[e], %[emax]\n\ts_cbranch_scc1 20b\n\t"
+        "s_branch 40f\n"
+        "25:\n\t"
+        "s_sub_u32 %[L], %[L], %[thr]\n\ts_sub_u32 %[R], %[R], %[thr]\n\ts_mov_b32 %[one], 1\n\t"
+        FS_RN_CHECK("94f", "84")
+        // ---- mantissa, top bit first  (chances 16 + pos); a 1 that would exceed amax is not coded (symbol.h:180)
+        "40:\n\t"
+        "s_lshl_b32 %[have], 1, %[e]\n\ts_mov_b32 %[skipped], 0\n\ts_mov_b32 %[t1], %[e]\n"
+        "41:\n\t"
+        "s_sub_u32 %[t1], %[t1], 1\n\ts_cbranch_scc1 60f\n\t"
+        "s_lshl_b32 %[t0], 1, %[t1]\n\ts_or_b32 %[res], %[have], %[t0]\n\ts_cmp_gt_i32 %[res], %[amax]\n\ts_cbranch_scc1 45f\n\t"
+        FS_THR_PREP "s_add_u32 %[t0], %[t1], 16\n\tv_readlane_b32 %[thr], v125, %[t0]\n\t"
+        "s_sub_u32 %[t0], %[R], %[thr]\n\ts_cmp_ge_u32 %[L], %[thr]\n\t"
+        "s_cselect_b32 %[R], %[t0], %[thr]\n\ts_cselect_b32 %[t0], %[thr], 0\n\ts_cselect_b32 %[have], %[res], %[have]\n\ts_sub_u32 %[L], %[L], %[t0]\n\t"
+        "s_cmp_le_u32 %[R], 0x10000\n\ts_cbranch_scc0 41b\n\t"
+        // (renormalisation inside the mantissa loop uses t0 and bits as scratch: t1 is the loop counter)
+        "s_lshr_b32 %[t0], %[widx], 2\n\tv_readlane_b32 %[t0], %[win], %[t0]\n\ts_lshl_b32 %[bits], %[widx], 3\n\ts_lshr_b32 %[t0], %[t0], %[bits]\n\t"
+        "s_and_b32 %[t0], %[t0], 0xff\n\ts_lshl_b32 %[L], %[L], 8\n\ts_or_b32 %[L], %[L], %[t0]\n\ts_add_u32 %[widx], %[widx], 1\n\ts_lshl_b32 %[R], %[R], 8\n\t"
+        "s_cmp_gt_u32 %[R], 0x10000\n\ts_cbranch_scc1 41b\n\t"
+        "s_lshr_b32 %[t0], %[widx], 2\n\tv_readlane_b32 %[t0], %[win], %[t0]\n\ts_lshl_b32 %[bits], %[widx], 3\n\ts_lshr_b32 %[t0], %[t0], %[bits]\n\t"
+        "s_and_b32 %[t0], %[t0], 0xff\n\ts_lshl_b32 %[L], %[L], 8\n\ts_or_b32 %[L], %[L], %[t0]\n\ts_add_u32 %[widx], %[widx], 1\n\ts_lshl_b32 %[R], %[R], 8\n\t"
+        "s_branch 41b\n"
+        "45:\n\t"
+        "s_or_b32 %[skipped], %[skipped], %[t0]\n\ts_branch 41b\n"
+        // ---- the (index, bit) pairs of the decisions taken, for leaf_commit; the value
+        "60:\n\t"
+        "s_bfm_b32 %[t0], %[e], 0\n\t"                                          // (1 << e) - 1
+        "s_add_u32 %[t1], %[e], %[one]\n\ts_bfm_b32 %[t1], %[t1], 2\n\t"       // exponent decisions taken: chances 2 .. 2 + e + one - 1
+        "s_andn2_b32 %[touched], %[t0], %[skipped]\n\ts_lshl_b32 %[touched], %[touched], 16\n\ts_or_b32 %[touched], %[touched], %[t1]\n\ts_or_b32 %[touched], %[touched], 3\n\t"
+        "s_and_b32 %[bits], %[have], %[t0]\n\ts_lshl_b32 %[bits], %[bits], 16\n\ts_add_u32 %[t1], %[e], 2\n\ts_lshl_b32 %[t1], %[one], %[t1]\n\t"
+        "s_or_b32 %[bits], %[bits], %[t1]\n\ts_or_b32 %[bits], %[bits], %[sign]\n\t"
+        "s_sub_u32 %[t1], 0, %[have]\n\ts_cmp_lg_u32 %[sign], 0\n\ts_cselect_b32 %[res], %[have], %[t1]\n\t"
+        "s_branch 99f\n"
+        // ---- the symbol is zero
+        "70:\n\t"
+        "s_sub_u32 %[L], %[L], %[thr]\n\ts_sub_u32 %[R], %[R], %[thr]\n\ts_mov_b32 %[res], 0\n\ts_mov_b32 %[touched], 1\n\ts_mov_b32 %[bits], 1\n\t"
+        FS_RN_CHECK("95f", "85")
+        "s_branch 99f\n"
+        FS_RENORM("91", "81b") FS_RENORM("92", "82b") FS_RENORM("93", "83b") FS_RENORM("94", "84b") FS_RENORM("95", "85b")
+        "99:\n\t"
+        : [R] "+s"(R), [L] "+s"(Lo), [widx] "+s"(widx), [res] "=&s"(res), [touched] "=&s"(touched), [bits] "=&s"(bits), [t0] "=&s"(t0),
+          [t1] "=&s"(t1), [thr] "=&s"(thr), [e] "=&s"(e), [amax] "=&s"(amax), [emax] "=&s"(emax), [sign] "=&s"(sign), [have] "=&s"(have),
+          [one] "=&s"(one), [skipped] "=&s"(skipped)
+        : [leafv] "v"(L.leafv), [win] "v"(s.win), [k800] "v"(k800), [amaxp] "s"(F.amax_pos), [amaxn] "s"(F.amax_neg), [emaxp] "s"(F.emax_pos),
+          [emaxn] "s"(F.emax_neg)
+        : "scc", "vcc", "v125", "v126", "v127");
+    r.range = R; r.low = Lo; s.pos = s.win_base + widx;
+    L.touched = touched; L.bits = bits;
+    return (int)res;
+}
+#endif
 DEV void leaf_commit(LeafRegs &L, int lane, const uint16_t *table) {
     if ((L.touched >> lane) & 1u) L.leafv = table[L.leafv * 2 + ((L.bits >> lane) & 1u)];
     L.touched = 0; L.bits = 0;
@@ -427,8 +599,8 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
 
     uint8_t *scratch = P.scratch + (size_t)blockIdx.x * P.scratch_stride;  // per wavefront, reused from tile to tile
     Node *nodes = reinterpret_cast<Node *>(scratch);                          // parse-order nodes
-    uint2 *snodes_g = reinterpret_cast<uint2 *>(scratch + P.bfs_off);         // supernodes (64 x 8 B each)
-    uint16_t *leaves = reinterpret_cast<uint16_t *>(scratch + P.leaves_off);
+    uint2 *const snodes_w = reinterpret_cast<uint2 *>(scratch + P.bfs_off);   // supernodes (64 x 8 B each)
+    uint16_t *const leaves_w = reinterpret_cast<uint16_t *>(scratch + P.leaves_off);
     Frame *stack = reinterpret_cast<Frame *>(scratch + P.stack_off);
     int32_t *queue = reinterpret_cast<int32_t *>(scratch + P.queue_off);      // breadth-first work list
     uint16_t *subtree = reinterpret_cast<uint16_t *>(scratch + P.subtree_off); // nodes under every tree node (saturating)
@@ -451,27 +623,31 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         exit_q = 2 * exit_q + (gt ? 1 : 2);
     }
 
-    // ---- persistent wavefront: take tiles in list order until every queue is empty ---------------
-    // A tile only waits for tiles EARLIER in its queue, and a tile that has been taken is running on
-    // a resident wavefront, so the earliest unfinished tile of a queue can always make progress: no
-    // deadlock, whatever the dispatch order or placement of the wavefronts.
+    // ---- persistent wavefront ---------------------------------------------------------------------
+    // sched == 0: take tiles from one list until it is empty.  A tile only waits for tiles EARLIER in the list, and a
+    // tile that has been taken is running on a resident wavefront, so the earliest unfinished tile can always make
+    // progress: no deadlock, whatever the dispatch order or placement of the wavefronts.
+    // sched == 1 (maniac_decode.h): the same argument per image -- tiles of an image are started in stream order, a
+    // suspended tile waits for rows of earlier tiles of its image only, and the earliest unfinished tile of an image is
+    // either running or runnable, so whichever wavefront looks at that image next picks it up.
     const int n_queues = P.n_queues;
-    int cur_q = 0, q_exhausted = 0;
+    const bool sched = P.sched != 0;
+    int home_q = 0;
     uint32_t simd_key = 0;
-    if (n_queues > 1) {
-        // home queue = dense index of the SIMD this wavefront sits on (first arrival numbers it)
+    if (sched) {
+        // home queue = dense index of the CU this wavefront sits on (the first arrival numbers it)
 #ifdef FUIF_EMU
         const uint32_t key = (uint32_t)blockIdx.x >> 2;
 #else
-        const uint32_t hw = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID: simd [5:4], cu/sh/se [15:8]
+        const uint32_t hw = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID: cu / sh / se in [15:8]
         const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
-        const uint32_t key = ((hw >> 4) & 3u) | (((hw >> 8) & 0xFFu) << 2) | ((xcc & 15u) << 10);
+        const uint32_t key = ((hw >> 8) & 0xFFu) | ((xcc & 15u) << 8);
 #endif
         simd_key = key;
         uint32_t idx = 0;
         if (lane == 0) {
             if (atomicAdd(&P.simd_claim[2 * key], 1u) == 0u) {
-                idx = atomicAdd(&P.simd_claim[2 * 16384], 1u);
+                idx = atomicAdd(&P.simd_claim[2 * 4096], 1u);
                 st_agent(&P.simd_claim[2 * key + 1], idx + 1u);
             } else {
                 uint32_t v = 0;
@@ -479,23 +655,110 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 idx = v - 1u;
             }
         }
-        cur_q = (int)(rflu(idx) % (uint32_t)n_queues);
+        home_q = (int)(rflu(idx) % (uint32_t)n_queues);
     }
-    for (;;) {
-    uint32_t tix = 0xFFFFFFFFu;
-    if (lane == 0) {
-        const uint32_t qb = P.q_begin[cur_q], qn = P.q_begin[cur_q + 1] - qb;
-        if (ld_agent(&P.q_head[cur_q]) < qn) {
-            const uint32_t k = atomicAdd(&P.q_head[cur_q], 1u);
-            if (k < qn) tix = qb + k;
+    constexpr uint32_t kNoWork = 0xFFFFFFFFu, kResume = 0x80000000u;
+    // sched == 1: work in queue q -- a suspended tile whose awaited rows have arrived (lowest first: an image's
+    // leaders before its followers), else the next unstarted tile of the first image that has one
+    auto scan_queue = [&](int q) -> uint32_t {
+        const uint32_t ib = P.q_img_begin[q], ie = P.q_img_begin[q + 1];
+        // 1. an unstarted tile of one of the first kActiveImages unfinished images of the queue (stream order inside an
+        //    image).  Starting comes first: the long final groups of an image must be under way early, and a tile that
+        //    has nothing to do yet suspends itself at its first row.
+        uint32_t active = 0, k_end = ib;
+        for (uint32_t k = ib; k < ie && active < kActiveImages; k++) {
+            const uint32_t im = P.q_images[k];
+            const uint32_t tb = P.img_tile_begin[im], tn = P.img_tile_begin[im + 1] - tb;
+            k_end = k + 1;
+            if (rflu(ld_agent(&P.img_done[im])) >= tn) continue;
+            active++;
+            uint32_t fresh = kNoWork;
+            if (lane == 0 && ld_agent(&P.img_next[im]) < tn) {
+                const uint32_t n = atomicAdd(&P.img_next[im], 1u);
+                if (n < tn) fresh = tb + n;
+            }
+            fresh = rflu(fresh);
+            if (fresh != kNoWork) return fresh;
         }
-    }
-    tix = rflu(tix);
-    if (tix == 0xFFFFFFFFu) {
-        // this queue is empty: help with the next one (each queue is found empty once)
-        if (++q_exhausted >= n_queues) break;
-        cur_q = cur_q + 1 == n_queues ? 0 : cur_q + 1;
-        continue;
+        // 2. a suspended tile whose awaited rows have arrived: the active images take turns (they should finish together,
+        //    the last one alone could not keep a CU busy)
+        uint32_t turn = 0;
+        if (lane == 0) turn = atomicAdd(&P.q_turn[q], 1u);
+        turn = rflu(turn);
+        const uint32_t nwin = k_end - ib;
+        for (uint32_t j = 0; j < nwin; j++) {
+            const uint32_t k = ib + (turn + j) % nwin;
+            const uint32_t im = P.q_images[k];
+            const uint32_t tb = P.img_tile_begin[im], tn = P.img_tile_begin[im + 1] - tb;
+            if (rflu(ld_agent(&P.img_done[im])) >= tn) continue;
+            // Inside an image the LAST runnable tile first: a tile can only run when the tiles it reads from are ahead of
+            // it, so serving the downstream end of that pipeline first keeps every stage moving and the long final
+            // groups finish with their leaders instead of after them (lowest-first starved them: measured).
+            for (uint32_t t0 = (tn - 1u) & ~63u;; t0 -= 64) {
+                bool run = false;
+                if (t0 + lane < tn) {
+                    TileRec *r = P.tile_rec + tb + t0 + lane;
+                    // A suspended tile is resumed on the CU that suspended it: its tree and leaf chances were written with
+                    // plain cached stores, and only that CU's own L1 / XCD's L2 are guaranteed to show them (agent-scope
+                    // release / acquire fences at every suspension cost an L2 write-back each: measured, 1.3x slower).
+                    if (ld_agent(&r->state) == TS_READY && ld_agent(&r->owner) == simd_key + 1u) {
+                        const uint32_t wc = ld_agent(&r->wait_chan), wv = ld_agent(&r->wait_val);
+                        run = ld_agent(&P.progress[(size_t)im * nch + wc]) >= wv;
+                    }
+                }
+                unsigned long long m = __ballot(run);
+                while (m) {
+                    const int l = 63 - __builtin_clzll(m);
+                    uint32_t ok = 0;
+                    if (lane == 0) ok = atomicCAS(&P.tile_rec[tb + t0 + l].state, (uint32_t)TS_READY, (uint32_t)TS_RUNNING) == TS_READY ? 1u : 0u;
+                    if (rflu(ok)) return (tb + t0 + (uint32_t)l) | kResume;
+                    m &= ~(1ull << l);
+                }
+                if (t0 == 0) break;
+            }
+        }
+        return kNoWork;
+    };
+    uint32_t idle_rounds = 0;
+    unsigned long long st_idle = 0, st_picks = 0, st_yields = 0, st_scan = 0, st_spin = 0, st_noctx = 0, st_busy = 0, st_pick_t = 0, st_t0 = realtime();
+    const unsigned long long st_begin = st_t0;   // scheduler statistics of this wavefront
+    for (;;) {
+    uint32_t tix = kNoWork;
+    bool resumed = false;
+    if (!sched) {
+        if (lane == 0) { const uint32_t k = atomicAdd(&P.q_head[0], 1u); if (k < (uint32_t)P.n_tiles) tix = k; }
+        tix = rflu(tix);
+        if (tix == kNoWork) break;
+    } else {
+        // The home queue only, as long as it has anything left: a tile started by a wavefront of another CU can only be
+        // resumed by that CU, which serves its own queue first (such tiles finished seconds late: measured).  A wavefront
+        // that has found nothing for a long while (its queue is done, or this CU is not the one the queue was meant
+        // for) looks at all queues, so a queue without wavefronts of its own is still served.
+        const int reach = idle_rounds > 4096 ? n_queues : 1;
+        const unsigned long long sc0 = realtime();
+        if (st_pick_t) { st_busy += sc0 - st_pick_t; st_pick_t = 0; }
+        for (int d = 0; d < reach && tix == kNoWork; d++) tix = scan_queue(home_q + d < n_queues ? home_q + d : home_q + d - n_queues);
+        if (tix == kNoWork) {
+            if (idle_rounds == 0) st_t0 = sc0;
+            if (rflu(ld_agent(P.done_total)) >= (uint32_t)P.n_tiles) { st_idle += realtime() - st_t0; break; }
+            if (++idle_rounds > (kSpinLimit >> 4)) {
+                // only a lost tile gets here (never observed): flag the unfinished images of the home queue and leave
+                for (uint32_t k = P.q_img_begin[home_q]; k < P.q_img_begin[home_q + 1]; k++) {
+                    const uint32_t im = P.q_images[k];
+                    if (lane == 0 && ld_agent(&P.img_done[im]) < P.img_tile_begin[im + 1] - P.img_tile_begin[im]) atomicOr(&P.status[im], ST_STALLED | ST_CORRUPT);
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(127);
+            continue;
+        }
+        if (idle_rounds) st_idle += sc0 - st_t0;
+        st_pick_t = realtime();
+        st_scan += st_pick_t - sc0;
+        idle_rounds = 0;
+        st_picks++;
+        resumed = (tix & kResume) != 0u;
+        tix &= ~kResume;
     }
     const Tile tile = P.tiles[tix];
     const unsigned long long tile_t0 = realtime();
@@ -519,6 +782,29 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
     uint32_t *progress = P.progress + (size_t)img * nch;
     int status = 0;
     bool stalled = false;
+    // sched == 1: this tile's record; supernodes and leaf chances of a tile that may be suspended live in a context area
+    TileRec *const rec = sched ? P.tile_rec + tix : nullptr;
+    uint2 *snodes_g = snodes_w;
+    uint16_t *leaves = leaves_w;
+    int ctx_slot = -1;          // >= 0: the tile owns a context area (256-byte units into ctx_scratch) and gives the wavefront back instead of spinning
+    uint32_t ctx_leaves_units = 0;
+    bool yielded = false;
+    uint32_t yield_chan = 0, yield_val = 0, resume_y = 0, run_ticks0 = 0;
+    unsigned long long tile_first = tile_t0;
+    if (resumed) {
+        s.pos = rflu(rec->pos);
+        const uint32_t fl = rflu(rec->flags);
+        status = (int)(fl & 0xFFu);
+        s.eof_flag = (int)((fl >> 8) & 1u);
+        ctx_slot = rfl((int)rec->ctx);
+        resume_y = rflu(rec->y);
+        run_ticks0 = rflu(rec->run_ticks);
+        tile_first = ((unsigned long long)rflu(rec->t_first_hi) << 32) | rflu(rec->t_first_lo);
+        ctx_leaves_units = rflu(rec->ctx_leaves);
+        uint8_t *cb = P.ctx_scratch + (size_t)(uint32_t)ctx_slot * 256u;
+        snodes_g = reinterpret_cast<uint2 *>(cb);
+        leaves = reinterpret_cast<uint16_t *>(cb + (size_t)ctx_leaves_units * 256u);
+    }
     PROF_DECL;
     // progress word of channel c: 1 = ChannelMeta valid, 1 + r = rows [0,r) final, 1 + h = plane final
     auto publish = [&](int c, uint32_t v) {
@@ -537,19 +823,23 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
     };
 
     // ---- fuif_decode channel loop: encoding.cpp:708-717 -------------------------------------
-    for (int ci = first_c; ci <= last_c; ci++) {
+    for (int ci = resumed ? last_c : first_c; ci <= last_c; ci++) {
+        // a resumed tile is one single-channel group (its last channel; earlier ones, if any, are empty planes): the
+        // header, tree and leaves exist, the code below only rebuilds what lives in registers and LDS
+        int beginc = ci, endc = ci, compress = 1, predictor = 0, firstrealc = ci;
+        if (resumed) predictor = (int)((rflu(rec->flags) >> 9) & 7u);
+        if (!resumed) {
         if (!((s.limit == 0 || s.pos < s.limit) && !s_eof(s))) break;
         if (!rfl(geom[ci].w) || !rfl(geom[ci].h)) continue;
 
         // ---- fuif_decode_channel: encoding.cpp:259-429 --------------------------------------
-        const int beginc = ci;
         if (s_limit_hit(s)) continue;
         const uint32_t group_pos = s.pos;
         int firstbyte = s_varint(s, lane);
         if (s_limit_hit(s)) continue;
-        const int endc = beginc + (firstbyte >> 4);
-        const int compress = firstbyte & 1;
-        const int predictor = (firstbyte & 14) >> 1;
+        endc = beginc + (firstbyte >> 4);
+        compress = firstbyte & 1;
+        predictor = (firstbyte & 14) >> 1;
         int global_minv = 1 - s_varint(s, lane);
         if (s_limit_hit(s)) continue;
         if (global_minv == 1) global_minv = s_varint(s, lane);
@@ -559,7 +849,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         if (endc > last_c || endc < beginc) { status |= ST_CORRUPT; break; }  // a group never crosses a tile (or the channel list)
         if (lane == 0) P.group_start[(size_t)img * nch + beginc] = group_pos + 1u;
 
-        int firstrealc = beginc;
+        firstrealc = beginc;
         bool fatal = false, early = false;
         for (int i = beginc; i <= endc; i++) {
             const int gw = rfl(geom[i].w), gh = rfl(geom[i].h);
@@ -597,6 +887,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         if (fatal) { status |= ST_UNSUPPORTED | ST_CORRUPT; break; }
         if (early) continue;
         if (firstrealc > endc) { ci = endc; continue; }
+        }  // !resumed
 
         // ---- init_properties: context_predict.h:67-120 --------------------------------------
         int nrefs = 0;
@@ -653,6 +944,15 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         const int nrefprops = nprops - kNonRefProps;
 
         int predictability = 2048;
+        Rac rac;
+        int tree_size = 1, n_super = 1, cur_leaf = 0;
+        if (resumed) {
+            rac.range = rflu(rec->range); rac.low = rflu(rec->low);
+            tree_size = rfl((int)rec->tree_size); n_super = rfl((int)rec->n_super); cur_leaf = rfl((int)rec->cur_leaf);
+            for (int sn = 1; sn <= kLdsSuper && sn < n_super; sn++) sh.snodes[(sn - 1) * 64 + lane] = snodes_g[(size_t)sn * 64 + lane];
+            __syncthreads();
+        }
+        if (!resumed) {
         if (predictor == 0 && compress) {
             int rounded = s_varint(s, lane);
             if (rounded < 1 || rounded > 127) {
@@ -669,7 +969,6 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
             predictability = rounded * 32;
         }
 
-        Rac rac;
         rac_init(rac, s, lane);
 
         if (!compress) {
@@ -708,7 +1007,8 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         __syncthreads();
         if (lane == 0) for (int k = 0; k < 3; k++) symbol_chance_init(sh.meta_ctx[k], 1024);
         __syncthreads();
-        int tree_size = 1, leaf_count = 0;
+        tree_size = 1;
+        int leaf_count = 0;
         bool tree_ok = true;
         {
             int pos = 0, depth = 0;
@@ -775,7 +1075,35 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         // leaf points to it.  Supernodes are numbered breadth first, so the ones nearest the root
         // are the ones that stay in LDS.
         const int nleaves = (tree_size + 1) / 2;
-        int n_super = 1;
+        n_super = 1;
+        // A group that may be suspended: the tile's single, last, one-channel group, with references to wait for and a
+        // tree the context areas are sized for.  Its supernodes and leaves are built in a context area of its image's
+        // queue; without a free one the tile simply runs to completion on this wavefront like every other tile.
+        int max_super_here = P.max_super;
+        if (sched && kHandOff && beginc == endc && endc == last_c && nrefs > 0 && tree_size > 1) {
+            // (7n+5)/12 supernodes are enough for n inner nodes (capi.hip), so nothing falls to the node-by-node walk
+            const uint32_t inner = (uint32_t)(tree_size - 1) / 2u;
+            const uint32_t sn_cap = (7u * inner + 5u) / 12u + 1u;
+            const uint32_t units = sn_cap * 2u + ((uint32_t)nleaves * (uint32_t)kLeafStride * 2u + 255u) / 256u;   // 256-byte units
+            uint32_t off = 0xFFFFFFFFu;
+            if (lane == 0) {
+                const uint32_t q = (uint32_t)(img % n_queues);
+                if (ld_agent(&P.ctx_used[q]) + units <= P.ctx_units_per_queue) {
+                    const uint32_t o = atomicAdd(&P.ctx_used[q], units);
+                    if (o + units <= P.ctx_units_per_queue) off = q * P.ctx_units_per_queue + o;
+                }
+            }
+            off = rflu(off);
+            if (off == 0xFFFFFFFFu) st_noctx++;
+            if (off != 0xFFFFFFFFu) {
+                ctx_slot = (int)off;
+                uint8_t *cb = P.ctx_scratch + (size_t)off * 256u;
+                snodes_g = reinterpret_cast<uint2 *>(cb);
+                leaves = reinterpret_cast<uint16_t *>(cb + (size_t)sn_cap * 512u);
+                ctx_leaves_units = sn_cap * 2u;
+                max_super_here = (int)sn_cap;
+            }
+        }
         // Subtree sizes (nodes, saturating): children always have larger indices than their parent in the parse-order
         // array, so one backward sweep does it.  The learner splits contexts that see many samples, so a child
         // supernode with a big subtree is (statistically) a frequently walked one: numbering them big-first puts the
@@ -831,7 +1159,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 uint32_t tgt;
                 // The scratch area holds P.max_super supernodes.  Subtrees beyond that (only trees with tens of
                 // thousands of nodes get there) are walked node by node from the parse-order array instead.
-                const bool admit = inner && (n_super + rank < P.max_super);
+                const bool admit = inner && (n_super + rank < max_super_here);
                 if (admit) { tgt = (uint32_t)(n_super + rank); queue[n_super + rank] = t; }
                 else if (inner) tgt = kSlowFlag | (uint32_t)t;
                 else tgt = kLeafFlag | (uint32_t)n.child;
@@ -844,7 +1172,6 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 __syncthreads();
             }
         }
-        const uint2 root_nd = snodes_g[lane];  // the root supernode lives in registers
         // FinalPropertySymbolCoder ctor: every leaf starts from SymbolChance(zero_chance) (compound.h:213-219)
         {
             if (lane == 0) { symbol_chance_init(leaves, predictability); leaves[31] = 0; }
@@ -855,10 +1182,11 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
             for (int64_t i = 16 + lane; i < (int64_t)nleaves * 16; i += 64) lw[i] = mine;  // (i & 15) == (lane & 15)
             __syncthreads();
         }
+        }  // !resumed
+        const uint2 root_nd = snodes_g[lane];  // the root supernode lives in registers
         LeafRegs L;
-        L.leafv = (lane < 32) ? (int)leaves[lane] : 0;
+        L.leafv = (lane < 32) ? (int)leaves[(int64_t)cur_leaf * kLeafStride + lane] : 0;
         L.touched = 0; L.bits = 0;
-        int cur_leaf = 0;
         auto switch_leaf = [&](int id) {
             if (LIKELY(id != cur_leaf)) {
                 if (lane < 32) {
@@ -877,7 +1205,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
             if (minv == maxv) continue;
             int32_t *plane = coef + geom[i].coef_off;
             const int zero = minv > 0 ? minv : (maxv < 0 ? maxv : 0);
-            int y = 0;
+            int y = resumed ? (int)resume_y : 0;
             uint32_t ref_seen = 0;  // lane k: last progress word seen for reference channel k
             if (tree_size == 1 && predictor == 0 && zero == 0) {
                 // fast track: encoding.cpp:371-383 (single leaf, no properties)
@@ -896,6 +1224,11 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 }
             } else {
                 // PRED0 = predictor 0 (all Squeeze residual / DCT coefficient channels): guess is a constant
+                FastSym fsym;
+                fsym.amax_pos = maxv - zero; fsym.amax_neg = zero - minv;
+                fsym.emax_pos = ilog2u((uint32_t)fsym.amax_pos); fsym.emax_neg = ilog2u((uint32_t)fsym.amax_neg);
+                const unsigned long long k800 = 0x800ull;   // rounding term of rac.h:50, as the 64-bit addend of the mad
+                const bool sym_fast = minv < zero && zero < maxv;   // both signs possible: symbol.h:160-165 codes zero and sign
                 auto rows = [&](auto pred0_tag) {
                     constexpr bool PRED0 = decltype(pred0_tag)::value;
                     for (; y < h; y++) {
@@ -915,6 +1248,17 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                             uint32_t spins = 0;
                             if (__any(ref_seen < need)) {
                                 if (ref_seen < need) ref_seen = ld_agent(fp);
+                                if (__any(ref_seen < need) && ctx_slot >= 0) {
+                                    // suspend: the scheduler resumes this tile when the first missing reference is yield_slack rows ahead
+                                    const int bl = __builtin_ctzll(__ballot(ref_seen < need));
+                                    const RefChan rcb = sh.refs[bl];
+                                    const uint32_t nb = (uint32_t)rdlane((int)need, bl) + P.yield_slack, fin = (uint32_t)rfl(rcb.h) + 1u;
+                                    yield_chan = (uint32_t)rfl(rcb.chan); yield_val = nb < fin ? nb : fin;
+                                    resume_y = (uint32_t)y;
+                                    EMU_COUNT(3);
+                                    yielded = true;
+                                    break;
+                                }
                                 if (__any(ref_seen < need)) {
                                     const unsigned long long w0 = realtime();
                                     while (__any(ref_seen < need) && !stalled) {
@@ -1055,7 +1399,19 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                     prof_acc[7] += (unsigned)rdlane(L.leafv, 0) & 0u;  // force the leaf load to complete inside this lap
 #endif
                                     PROF_LAP(3);
-                                    diff = leaf_symbol(rac, s, lane, L, mn, mx);
+                                    if (PRED0 && sym_fast && LIKELY(s.pos + 64u <= s.size)) {
+                                        // the symbol's bytes (at most 62) are in the stream; keep them in the window registers
+                                        // (the reload starts at a 4-byte boundary; the 256 bytes it reads lie inside the allocation)
+                                        if (UNLIKELY(s.pos - s.win_base > 188u)) {
+                                            s.win_base = s.pos & ~3u;
+                                            s.win = reinterpret_cast<const uint32_t *>(s.p + s.win_base)[lane];
+                                        }
+#ifdef FUIF_EMU
+                                        diff = fast_symbol(rac, s, L, fsym);
+#else
+                                        diff = fast_symbol_hw(rac, s, L, fsym, k800);
+#endif
+                                    } else diff = leaf_symbol(rac, s, lane, L, mn, mx);
                                     PROF_LAP(4);
                                     // advance the touched chances now: the table lookup overlaps the next pixel's tree walk
                                     leaf_commit(L, lane, pixel_table);
@@ -1077,6 +1433,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 };
                 if (predictor == 0) rows(std::true_type{}); else rows(std::false_type{});
             }
+            if (yielded) break;
             // rows the stream never reached keep what Channel::resize() (encoding.cpp:368) left there: `zero` in a plane
             // it created, the constructor's 0 in a plane that already had its samples (image.h:64-65,73-75)
             if (y < h) { __syncthreads(); fill_plane<kHandOff>(plane, (int64_t)y * w, (int64_t)(h - y) * w, rfl(geom[i].ctor_data) ? 0 : zero, lane); status |= ST_TRUNCATED; }
@@ -1084,9 +1441,26 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
             publish(i, (uint32_t)h + 1u);
             if (s_limit_hit(s)) break;
         }
+        if (yielded) {
+            // suspend: current leaf back to its slot, coder state into the tile's record, then release the record
+            if (lane < 32) leaves[(int64_t)cur_leaf * kLeafStride + lane] = (uint16_t)L.leafv;
+            if (lane == 0) {
+                rec->wait_chan = yield_chan; rec->wait_val = yield_val; rec->y = resume_y;
+                rec->range = rac.range; rec->low = rac.low; rec->pos = s.pos;
+                rec->flags = ((uint32_t)status & 0xFFu) | ((uint32_t)(s.eof_flag & 1) << 8) | ((uint32_t)predictor << 9);
+                rec->ctx = (uint32_t)ctx_slot; rec->ctx_leaves = ctx_leaves_units; rec->tree_size = (uint32_t)tree_size; rec->n_super = (uint32_t)n_super; rec->cur_leaf = (uint32_t)cur_leaf;
+                rec->t_first_lo = (uint32_t)tile_first; rec->t_first_hi = (uint32_t)(tile_first >> 32);
+                rec->run_ticks = run_ticks0 + (uint32_t)(realtime() - tile_t0);
+                rec->owner = simd_key + 1u;
+            }
+            drain_stores();   // the record and the leaf are in this XCD's L2 before the state says so
+            if (lane == 0) st_agent(&rec->state, (uint32_t)TS_READY);
+            break;
+        }
         __syncthreads();
         ci = endc;
     }
+    if (yielded) { st_yields++; __syncthreads(); continue; }   // the tile goes on later, on whichever wavefront picks it up
     if (s_limit_hit(s)) status |= ST_TRUNCATED;
     // planes the tile never reached read as zeros in the reference (empty Channel::data,
     // image/image.h:82-85; zero-filled residuals, transform/squeeze.h:379-383).  Every channel of
@@ -1101,10 +1475,19 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         }
     }
     if (lane == 0) { atomicOr(&P.status[img], status); atomicMax(&P.consumed[img], s.pos); }
+    st_spin += waited;
+    if (sched && lane == 0) {
+        st_agent(&rec->state, (uint32_t)TS_DONE);
+        atomicAdd(&P.img_done[img], 1u);
+        atomicAdd(P.done_total, 1u);
+    }
     if (lane == 0 && P.tile_log) {
+        // waited = spinning for rows + suspended (first start .. end minus the time some wavefront was running the tile)
         unsigned long long *tl = P.tile_log + (size_t)tix * 4;
+        const unsigned long long t_end = realtime();
+        waited += (t_end - tile_first) - ((unsigned long long)run_ticks0 + (t_end - tile_t0));
         tl[0] = ((unsigned long long)(uint32_t)img << 32) | (uint32_t)first_c;
-        tl[1] = tile_t0; tl[2] = realtime();
+        tl[1] = tile_first; tl[2] = t_end;
         tl[3] = (waited & 0xFFFFFFFFFFFFull) | ((unsigned long long)simd_key << 48);
     }
 #ifdef FUIF_PROF
@@ -1112,6 +1495,9 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
 #endif
     __syncthreads();
     }  // tile loop
+    if (sched && lane == 0 && P.sched_stats) {
+        atomicAdd(&P.sched_stats[0], st_idle); atomicAdd(&P.sched_stats[1], st_picks); atomicAdd(&P.sched_stats[2], st_yields); atomicAdd(&P.sched_stats[3], st_scan); atomicAdd(&P.sched_stats[4], st_spin); atomicAdd(&P.sched_stats[5], st_noctx); atomicAdd(&P.sched_stats[6], st_busy); atomicAdd(&P.sched_stats[7], realtime() - st_begin);
+    }
 }
 
 int maniac_max_waves(int dense, int *per_simd) {

@@ -131,6 +131,11 @@ int fuifgpu_batch_profile(fuifgpu_batch *batch, uint64_t *out8_per_image);
  * start, end, ticks spent waiting for other tiles' rows | SIMD key << 48}, times in 100 MHz s_memrealtime ticks.
  * Logging starts with the first call (which returns *n_tiles = 0); tools/tile_timeline.py turns it into a report. */
 int fuifgpu_batch_tile_log(fuifgpu_batch *batch, uint64_t *out4_per_tile, int cap, int *n_tiles);
+/* diagnostic: counters of the tile scheduler for the last dense launch {ticks (100 MHz) wavefronts spent without work while
+ * tiles were unfinished, tiles picked up (starts + resumptions), suspensions, ticks spent looking for the tile picked up, ticks spent spinning inside tiles (waits a tile could not be
+ * suspended for), suspendable tiles that found their context arena full, ticks between picking a tile up and looking for
+ * the next one, ticks the wavefronts lived} */
+int fuifgpu_batch_sched_stats(fuifgpu_batch *batch, uint64_t *out8);
 
 /* ---- group index (csrc/index.cpp) --------------------------------------
  * A FUIF stream is a chain of channel groups (fuif_decode_channel, encoding/encoding.cpp:259-429),

@@ -68,6 +68,7 @@ static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
 template <class T> static inline T atomicAdd(T *p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 template <class T> static inline T atomicOr(T *p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+template <class T> static inline T atomicCAS(T *p, T expected, T desired) { __atomic_compare_exchange_n(p, &expected, desired, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST); return expected; }
 template <class T> static inline T atomicMax(T *p, T v) {
     T o = __atomic_load_n(p, __ATOMIC_SEQ_CST);
     while (v > o && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
@@ -104,6 +105,7 @@ static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; 
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 // EMU_WAVES: persistent wavefronts of the entropy kernel (each becomes a workgroup; run them on EMU_THREADS >= EMU_WAVES threads)
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { const char *e = getenv("EMU_WAVES"); p->multiProcessorCount = e ? std::max(1, atoi(e)) : 1; return hipSuccess; }
+static inline hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) { *free_b = (size_t)1 << 30; *total_b = (size_t)2 << 30; return hipSuccess; }
 template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, K, int, size_t) { *n = 1; return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }

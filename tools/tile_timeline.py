@@ -27,6 +27,8 @@ batch.decode(); batch.sync()
 ms = batch.timing()[0]
 log = batch.tile_log().astype(np.float64)
 raw = batch.tile_log()
+if os.environ.get("TILE_LOG_NPY"):
+    np.save(os.environ["TILE_LOG_NPY"], raw)
 img = (raw[:, 0] >> np.uint64(32)).astype(np.int64)
 ch = (raw[:, 0] & np.uint64(0xFFFFFFFF)).astype(np.int64)
 t0 = raw[:, 1].astype(np.float64); t1 = raw[:, 2].astype(np.float64)
@@ -51,5 +53,8 @@ for k, e in zip(key.tolist(), t1.tolist()):
     ends[k] = max(ends.get(k, 0.0), e)
 e = np.array(sorted(ends.values()))
 print("per-SIMD finish time: min %.0f  p10 %.0f  median %.0f  p90 %.0f  max %.0f ms" % (e.min(), np.percentile(e, 10), np.median(e), np.percentile(e, 90), e.max()))
+ss = batch.sched_stats()
+print("scheduler: idle %.0f wavefront-seconds, picking %.0f, spinning inside tiles %.0f; %d pick-ups, %d suspensions, %d tiles without a context area" % (float(ss[0]) / 1e8, float(ss[3]) / 1e8, float(ss[4]) / 1e8, int(ss[1]), int(ss[2]), int(ss[5])))
+print("scheduler: busy (pick-up to next look) %.0f wavefront-seconds, wavefront lifetime %.0f" % (float(ss[6]) / 1e8, float(ss[7]) / 1e8))
 st, _ = batch.status()
 assert not st.any()
