@@ -4,7 +4,9 @@
 Workload (config.workload = "C2"): a batch of 1024 3840x2160 8-bit photographic RGB images,
 YCoCg+Squeeze lossless .fuif, per GPU (weak scaling: every rank decodes its own 1024 streams; the
 path shards by independent images and has no data-path collective -- the only exchange is the
-final gather of per-image output checksums over RCCL).
+final gather of the decoded pictures, packed to 8-bit RGB on the GPU, to rank 0 over RCCL, outside
+the timed region and reported separately).  `--workload c5` is BASELINE config 5:
+8192 mixed Squeeze / DCT 1920x1080 images sharded over the ranks (strong scaling).
 
 One "step" = one pass of the hot path over the batch with the compressed streams already resident
 in HBM: entropy kernel (k_maniac_decode) + inverse-transform schedule, ending with all int32
@@ -100,7 +102,27 @@ def cpu_baseline(blobs, w, h, budget_s=25.0):
         if t_total > budget_s:
             break
     return {"value": round(n * w * h / 1e6 / t_total, 4), "unit": "Mpixels/s", "cores": 1, "kind": kind,
-            "sample": "%d of the bench's %dx%d streams, full decode (entropy + inverse transforms), 1 thread, %.1f s" % (n, w, h, t_total)}
+            "sample": "%d of the bench's %dx%d streams, full decode (entropy + inverse transforms), 1 thread, %.1f s" % (n, w, h, t_total),
+            "host": host_description()}
+
+
+def host_description():
+    """the GPU box's host CPU: model, hardware threads, physical cores (lscpu-free: /proc/cpuinfo)"""
+    model, cores, threads = "?", set(), 0
+    try:
+        phys = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "?":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("processor"):
+                threads += 1
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cores.add((phys, line.split(":", 1)[1].strip()))
+    except OSError:
+        pass
+    return {"model": model, "hardware_threads": threads or (os.cpu_count() or 1), "physical_cores": len(cores) or None}
 
 
 def cpu_baseline_all_cores(paths, w, h, seconds=12.0):
@@ -161,11 +183,12 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="images per GPU (BASELINE config: 1024)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--distinct", type=int, default=8, help="K distinct images replicated to the batch")
+    ap.add_argument("--distinct", type=int, default=16, help="K distinct images replicated to the batch (SURVEY.md §8(d): 16)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2", help="c2 = BASELINE headline config (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-all-cores", action="store_true",
-                    help="also time the reference decoder on every host core at once (one process per image, ~40 s extra)")
+    ap.add_argument("--no-cpu-all-cores", action="store_true",
+                    help="skip the all-host-cores leg of the CPU baseline (one reference process per hardware thread, ~30 s)")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive measurement (one upload of the whole batch from distinct host buffers)")
     ap.add_argument("--no-index", action="store_true", help="ignore the streams' group index: one wavefront per image for the timed steps")
     ap.add_argument("--no-seq-compare", action="store_true", help="skip the extra one-wavefront-per-image step reported next to the headline")
     ap.add_argument("--cache", default=os.environ.get("FUIF_BENCH_CACHE", "/tmp/fuif_bench_cache"))
@@ -261,9 +284,43 @@ def main():
                     # picture must be the source within JPEG-q90 error, and (below) every replica must agree
                     err = (got[:H, :W].to(torch.float32) - src[c].to(torch.float32)).pow(2).mean().item()
                     ok = ok and err < 40.0
-    # the only cross-rank exchange: gather of per-image output checksums (RCCL all_gather)
+    # cross-rank exchange 1: per-image output checksums (RCCL all_gather)
     checks = fd.plane_checksums(view)
     gathered = fd.gather_checksums(checks, dist)
+    # cross-rank exchange 2, the final gather of SURVEY.md §8(e): the decoded pictures, packed on the GPU to the interleaved
+    # 8-bit samples of a PNM file (k_pack_samples), go to rank 0 in chunks over RCCL (7 xGMI links into the root).  Outside
+    # the timed region; the root checks every rank's byte sum and does not keep the pictures (at C2 they would be 25 GB per
+    # rank).  On one GPU there is nothing to move: a sample is packed to time the kernel.
+    gather_info = None
+    pb = batch.packed_bytes()
+    if pb:
+        per_chunk = max(1, min(args.batch, (2 << 30) // pb))
+        n_pack = args.batch if world > 1 else min(args.batch, per_chunk)
+        packed = torch.empty(per_chunk * pb, dtype=torch.uint8, device=dev)
+        t_pack = t_gather = 0.0
+        sums_ok = True
+        for i0 in range(0, n_pack, per_chunk):
+            cnt = min(per_chunk, n_pack - i0)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            batch.pack_out(packed.data_ptr(), i0, cnt)
+            batch.sync(); t_pack += time.perf_counter() - t0
+            local = packed[: cnt * pb]
+            mine = torch.sum(local, dtype=torch.int64).reshape(1)
+            fence(); t0 = time.perf_counter()
+            got = fd.gather_packed(local, dist, root=0, keep=False)
+            fence(); t_gather += time.perf_counter() - t0
+            if dist is not None:
+                every = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(every, mine)
+                if rank == 0:
+                    sums_ok = sums_ok and got == [int(e.item()) for e in every]
+        del packed
+        ok = ok and sums_ok
+        moved = (world - 1) * n_pack * pb
+        gather_info = {"payload": "packed 8-bit interleaved pictures (k_pack_samples), %d bytes per image" % pb,
+                       "images_per_rank": n_pack, "pack_ms": round(t_pack * 1e3, 3), "pack_GBps": round(n_pack * (pb + 4.0 * info.out_elems) / max(t_pack, 1e-9) / 1e9, 1),
+                       "gather_ms": round(t_gather * 1e3, 3) if world > 1 else None, "bytes_into_root": int(moved),
+                       "gather_GBps": round(moved / max(t_gather, 1e-9) / 1e9, 1) if world > 1 else None, "byte_sums_ok": bool(sums_ok)}
     # replicas of one source image must agree on every rank
     for r in range(gathered.shape[0]):
         for k in range(K):
@@ -290,8 +347,25 @@ def main():
         st2, _ = batch.status()
         same = fd.plane_checksums(view)
         seq = {"value": round(args.batch * W * H / 1e6 / t_seq, 3), "unit": "Mpixels/s", "ms_per_step": round(t_seq * 1e3, 3),
-               "entropy_kernel_ms": round(d, 3), "identical_output": bool(torch.equal(same, checks)) and not st2.any()}
+               "entropy_kernel_ms": round(d, 3), "identical_output": bool(torch.equal(same, checks)) and not st2.any(),
+               "note": "the rate of files as the reference CLI writes them (no FGIX trailer): one wavefront per image"}
         ok = ok and seq["identical_output"]
+
+    # PCIe-inclusive rate: the boundary takes HOST buffers; one upload of the whole batch from 1024 separate host blobs
+    # (no replica shortcut) + one step.  Reported next to `value`, never as `value`.
+    h2d = None
+    if world == 1 and not args.no_h2d:
+        separate = [bytes(bytearray(b)) for b in blobs]
+        batch.set_group_parallel(not args.no_index)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        batch.upload(separate)
+        batch.sync()
+        t_h2d = time.perf_counter() - t0
+        h2d = {"upload_s": round(t_h2d, 3), "bytes": int(sum(len(b) for b in separate)),
+               "value_incl_h2d": round(args.batch * W * H / 1e6 / (t_h2d + ms_per_step / 1e3), 3), "unit": "Mpixels/s",
+               "note": "host parse of every stream + H2D copies from pageable memory + one step; not overlapped"}
+        del separate
 
     if rank == 0:
         S = sum(len(b) for b in blobs) / args.batch
@@ -320,14 +394,19 @@ def main():
                           "group_index": "ignored (--no-index): one wavefront per image" if args.no_index else
                                          "FGIX trailer behind each stream (csrc/index.cpp): one wavefront per channel group; the unmodified reference decodes the same files",
                           "parity_check": "decoded == source pixels for all images" if wl["lossless"] else "MSE vs source < 40 and all replicas identical (bit-exactness: tests -m gpu)",
-                          "gather": "all_gather of per-image output checksums", "input_gen_s": round(t_gen, 1), "upload_s": round(t_upload, 3)},
+                          "gather": "final gather of the packed pictures to rank 0 (chunked RCCL gather) + all_gather of per-image checksums", "input_gen_s": round(t_gen, 1), "upload_s": round(t_upload, 3)},
                "roofline": roofline}
         if seq is not None:
             res["one_wavefront_per_image"] = seq
+        if h2d is not None:
+            res["value_incl_h2d"] = h2d["value_incl_h2d"]
+            res["h2d"] = h2d
+        if gather_info is not None:
+            res["final_gather"] = gather_info
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline([b for _, b in inputs], W, H)
             res["speedup_vs_cpu_1thread"] = round(value / res["cpu_baseline"]["value"], 2)
-            if args.cpu_all_cores:
+            if not args.no_cpu_all_cores:
                 name = "synth_idx_" + wl["kind"] + "_%dx%dx%d_%dbit_seed%d.fuif"
                 paths = [os.path.join(args.cache, name % (W, H, C, BITS, seed)) for seed, _ in inputs]
                 if all(os.path.exists(p) for p in paths):

@@ -319,6 +319,15 @@ class Batch:
             return buf.view(">u2").astype(np.uint16).reshape(info.h, info.w, comps)
         return buf.reshape(info.h, info.w, comps)
 
+    def packed_bytes(self, components=0):
+        return int(lib().fuifgpu_plan_packed_bytes(self.plan._h, components))
+
+    def pack_out(self, dst_device_ptr, first_image=0, n_images=None, components=0, stream=None):
+        """interleaved clamped 8 / 16-bit samples of images [first, first+n) into DEVICE memory (n * packed_bytes bytes):
+        the payload of the final gather (dist.gather_packed) and of a PNM/PAM file; call after undo_transforms()"""
+        n = self.n_loaded - first_image if n_images is None else n_images
+        _check(lib().fuifgpu_batch_pack_out(self._h, first_image, n, components, dst_device_ptr, stream))
+
     def out_planes(self, image):
         slab = np.zeros(max(self.plan.info.out_elems, 1), np.int32)
         _check(lib().fuifgpu_batch_download_out(self._h, image, slab.ctypes.data, None))

@@ -94,14 +94,17 @@ constexpr int kPropPitch = 33;    // odd pitch: conflict-free column writes / ro
 // Pixels whose properties are prepared at once (lane = pixel).  The property rows are the largest LDS
 // item; a shorter chunk buys resident wavefronts (the real lever of this kernel: it is issue bound).
 #ifndef FUIF_CHUNK
-#define FUIF_CHUNK 64
+#define FUIF_CHUNK 32   // dense configuration; the wide one always prepares 64 pixels at a time
 #endif
-constexpr int kChunk = FUIF_CHUNK;
-static_assert(kChunk == 64 || kChunk == 32 || kChunk == 16, "chunk must divide the wavefront");
-// The dense configuration is built for 4 wavefronts per SIMD: 128 VGPRs (the compiler may spill a few
-// SGPR-to-VGPR homes; without the bound the scheduler code pushed it to 134 and the CU lost a quarter of its wavefronts)
+constexpr int kChunkDense = FUIF_CHUNK;
+static_assert(kChunkDense == 64 || kChunkDense == 32 || kChunkDense == 16, "chunk must divide the wavefront");
+// The dense configuration is built for 6 wavefronts per SIMD (80 VGPRs, 32-pixel chunks: 5.8 KB of LDS).  The kernel waits
+// for memory two thirds of the time even with 4 wavefronts per SIMD (a leaf, a supernode and a table line per symbol,
+// profiles/r2_sq_counters_*): measured on 1024 x 4K with the group index, 4 / 5 / 6 / 8 per SIMD = 10.9 / 9.6 / 9.5 /
+// 12.0 s (at 8 the 64-register budget spills in the pixel loop).  The wide configuration (LDS bound: one per SIMD)
+// ignores the bound.
 #ifndef FUIF_WAVES
-#define FUIF_WAVES 4
+#define FUIF_WAVES 6
 #endif
 #define FUIF_OCCUPANCY __attribute__((amdgpu_waves_per_eu(FUIF_WAVES, FUIF_WAVES)))
 
@@ -223,6 +226,16 @@ DEV int slog(int x) {  // encoding/context_predict.h:53-61, branch free: sign(x)
     return (r ^ m) - m;
 }
 DEV int iabs(int x) { return x < 0 ? -x : x; }
+// slog(d) > s  <=>  d > slog_threshold(s): slog is monotone, so a tree node that tests one of the four slog properties
+// that depend on the pixel to the left (local properties 3, 8, 9, 12) can test the raw difference instead, and the
+// per-pixel patch does not have to take a logarithm (s < -32 cannot occur: split values lie inside the property range)
+DEV int slog_threshold(int s) {
+    if (s >= 31) return 0x7FFFFFFF;
+    if (s >= 0) return (1 << s) - 1;
+    if (s <= -32) return (int)0x80000000;
+    return -(1 << (-s - 1));
+}
+DEV bool is_raw_slog_prop(int kloc) { return kloc == 3 || kloc == 8 || kloc == 9 || kloc == 12; }
 DEV int median3(int a, int b, int c) {  // util.h:9-23
     if (a < b) { if (b < c) return b; return a < c ? c : a; }
     if (a < c) return a;
@@ -442,10 +455,46 @@ DEV int fast_symbol(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
 #ifndef FUIF_EMU
 // The same symbol decoder as fast_symbol (the C++ above is the specification and what the CPU emulator runs), hand
 // written: hipcc turns the loops with their several exits into ~30 instructions and 4-5 branches per decision (flag
-// registers and copies for every exit); this is 13 per exponent bit and 21 per mantissa bit.  v125..v127 are scratch
+// registers and copies for every exit); this is 13 per exponent bit and 21 per mantissa bit.  three VGPRs at the top of the register budget are scratch
 // (clobbers).  Per decision: per-lane thresholds range - ((range * chance + 0x800) >> 12) as one 64-bit mad,
 // v_readlane of the lane of the chance in use, scalar compare with `low`; renormalisation out of line.
-#define FS_THR_PREP "v_mad_u64_u32 v[126:127], vcc, %[R], %[leafv], %[k800]\n\tv_alignbit_b32 v125, v127, v126, 12\n\tv_sub_u32 v125, %[R], v125\n\t"
+// scratch VGPRs = the last ones of the register budget of the build (FUIF_WAVES wavefronts per SIMD): the 64-bit
+// product, the 64-bit rounding constant 0x800 (loaded at the top of the block; 64-bit tuples must be even aligned on
+// gfx950, which an inline-asm "v" operand does not guarantee) and the thresholds
+#if FUIF_WAVES >= 8
+#define FS_VK "v[58:59]"
+#define FS_VK0 "v58"
+#define FS_VK1 "v59"
+#define FS_VBC "v[60:61]"
+#define FS_VB "v60"
+#define FS_VC "v61"
+#define FS_VA "v63"
+#elif FUIF_WAVES >= 6
+#define FS_VK "v[74:75]"
+#define FS_VK0 "v74"
+#define FS_VK1 "v75"
+#define FS_VBC "v[76:77]"
+#define FS_VB "v76"
+#define FS_VC "v77"
+#define FS_VA "v79"
+#elif FUIF_WAVES == 5
+#define FS_VK "v[90:91]"
+#define FS_VK0 "v90"
+#define FS_VK1 "v91"
+#define FS_VBC "v[92:93]"
+#define FS_VB "v92"
+#define FS_VC "v93"
+#define FS_VA "v95"
+#else
+#define FS_VK "v[122:123]"
+#define FS_VK0 "v122"
+#define FS_VK1 "v123"
+#define FS_VBC "v[124:125]"
+#define FS_VB "v124"
+#define FS_VC "v125"
+#define FS_VA "v127"
+#endif
+#define FS_THR_PREP "v_mad_u64_u32 " FS_VBC ", vcc, %[R], %[leafv], " FS_VK "\n\tv_alignbit_b32 " FS_VA ", " FS_VC ", " FS_VB ", 12\n\tv_sub_u32 " FS_VA ", %[R], " FS_VA "\n\t"
 // one or two bytes from the window registers into `low` (rac.h:70-81), then back to label `back`
 #define FS_RENORM(lbl, back) \
     lbl ":\n\t" \
@@ -456,17 +505,18 @@ DEV int fast_symbol(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
     "s_and_b32 %[t0], %[t0], 0xff\n\ts_lshl_b32 %[L], %[L], 8\n\ts_or_b32 %[L], %[L], %[t0]\n\ts_add_u32 %[widx], %[widx], 1\n\ts_lshl_b32 %[R], %[R], 8\n\t" \
     "s_branch " back "\n\t"
 #define FS_RN_CHECK(lbl, back) "s_cmp_le_u32 %[R], 0x10000\n\ts_cbranch_scc1 " lbl "\n" back ":\n\t"
-DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F, unsigned long long k800) {
+DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
     uint32_t R = r.range, Lo = r.low, widx = s.pos - s.win_base;
     uint32_t res, touched, bits, t0, t1, thr, e, amax, emax, sign, have, one, skipped;
     asm volatile(
+        "v_mov_b32 " FS_VK0 ", 0x800\n\tv_mov_b32 " FS_VK1 ", 0\n\t"
         // ---- zero?  (chance 0)
-        FS_THR_PREP "s_nop 0\n\tv_readlane_b32 %[thr], v125, 0\n\t"
+        FS_THR_PREP "s_nop 0\n\tv_readlane_b32 %[thr], " FS_VA ", 0\n\t"
         "s_cmp_ge_u32 %[L], %[thr]\n\ts_cbranch_scc1 70f\n\t"
         "s_mov_b32 %[R], %[thr]\n\t"
         FS_RN_CHECK("91f", "81")
         // ---- sign  (chance 1): 1 = positive
-        FS_THR_PREP "s_nop 0\n\tv_readlane_b32 %[thr], v125, 1\n\t"
+        FS_THR_PREP "s_nop 0\n\tv_readlane_b32 %[thr], " FS_VA ", 1\n\t"
         "s_sub_u32 %[t0], %[R], %[thr]\n\ts_cmp_ge_u32 %[L], %[thr]\n\t"
         "s_cselect_b32 %[R], %[t0], %[thr]\n\ts_cselect_b32 %[t1], %[thr], 0\n\ts_cselect_b32 %[sign], 2, 0\n\t"
         "s_cselect_b32 %[amax], %[amaxp], %[amaxn]\n\ts_cselect_b32 %[emax], %[emaxp], %[emaxn]\n\ts_sub_u32 %[L], %[L], %[t1]\n\t"
@@ -474,7 +524,7 @@ DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F, unsigne
         // ---- unary exponent  (chances 2 + e)
         "s_mov_b32 %[e], 0\n\ts_mov_b32 %[one], 0\n\ts_cmp_lg_u32 %[emax], 0\n\ts_cbranch_scc0 40f\n"
         "20:\n\t"
-        FS_THR_PREP "s_add_u32 %[t0], %[e], 2\n\tv_readlane_b32 %[thr], v125, %[t0]\n\t"
+        FS_THR_PREP "s_add_u32 %[t0], %[e], 2\n\tv_readlane_b32 %[thr], " FS_VA ", %[t0]\n\t"
         "s_cmp_ge_u32 %[L], %[thr]\n\ts_cbranch_scc1 25f\n\t"
         "s_mov_b32 %[R], %[thr]\n\t"
         FS_RN_CHECK("93f", "83")
@@ -489,7 +539,7 @@ DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F, unsigne
         "41:\n\t"
         "s_sub_u32 %[t1], %[t1], 1\n\ts_cbranch_scc1 60f\n\t"
         "s_lshl_b32 %[t0], 1, %[t1]\n\ts_or_b32 %[res], %[have], %[t0]\n\ts_cmp_gt_i32 %[res], %[amax]\n\ts_cbranch_scc1 45f\n\t"
-        FS_THR_PREP "s_add_u32 %[t0], %[t1], 16\n\tv_readlane_b32 %[thr], v125, %[t0]\n\t"
+        FS_THR_PREP "s_add_u32 %[t0], %[t1], 16\n\tv_readlane_b32 %[thr], " FS_VA ", %[t0]\n\t"
         "s_sub_u32 %[t0], %[R], %[thr]\n\ts_cmp_ge_u32 %[L], %[thr]\n\t"
         "s_cselect_b32 %[R], %[t0], %[thr]\n\ts_cselect_b32 %[t0], %[thr], 0\n\ts_cselect_b32 %[have], %[res], %[have]\n\ts_sub_u32 %[L], %[L], %[t0]\n\t"
         "s_cmp_le_u32 %[R], 0x10000\n\ts_cbranch_scc0 41b\n\t"
@@ -521,9 +571,9 @@ DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F, unsigne
         : [R] "+s"(R), [L] "+s"(Lo), [widx] "+s"(widx), [res] "=&s"(res), [touched] "=&s"(touched), [bits] "=&s"(bits), [t0] "=&s"(t0),
           [t1] "=&s"(t1), [thr] "=&s"(thr), [e] "=&s"(e), [amax] "=&s"(amax), [emax] "=&s"(emax), [sign] "=&s"(sign), [have] "=&s"(have),
           [one] "=&s"(one), [skipped] "=&s"(skipped)
-        : [leafv] "v"(L.leafv), [win] "v"(s.win), [k800] "v"(k800), [amaxp] "s"(F.amax_pos), [amaxn] "s"(F.amax_neg), [emaxp] "s"(F.emax_pos),
+        : [leafv] "v"(L.leafv), [win] "v"(s.win), [amaxp] "s"(F.amax_pos), [amaxn] "s"(F.amax_neg), [emaxp] "s"(F.emax_pos),
           [emaxn] "s"(F.emax_neg)
-        : "scc", "vcc", "v125", "v126", "v127");
+        : "scc", "vcc", FS_VA, FS_VB, FS_VC, FS_VK0, FS_VK1);
     r.range = R; r.low = Lo; s.pos = s.win_base + widx;
     L.touched = touched; L.bits = bits;
     return (int)res;
@@ -566,7 +616,8 @@ struct RefChan {  // one reference channel of the current group (context_predict
 template <int kLdsSuper>
 struct Shared {
     uint2 snodes[kLdsSuper * 64];        // breadth-first top of the supernode tree: lane i = {split_i, prop_i | exit_i << 8}
-    int32_t cprops[kChunk * kPropPitch]; // [pixel of the chunk][property]
+    static constexpr int kChunk = kLdsSuper == kLdsDense ? kChunkDense : 64;
+    int32_t cprops[(kChunk > 4 ? kChunk : 4) * kPropPitch]; // [pixel of the chunk][property]; the supernode build borrows 256 words
     uint16_t meta_ctx[3][32];            // three SimpleSymbolCoder contexts of the tree coder
     int32_t lo[kMaxProps], hi[kMaxProps];
     RefChan refs[kMaxRefs];
@@ -592,6 +643,7 @@ DEV void fill_plane(int32_t *plane, int64_t first, int64_t count, int v, int lan
 template <int kLdsSuper, bool kHandOff>
 __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParams P) {
     __shared__ Shared<kLdsSuper> sh;
+    constexpr int kChunk = Shared<kLdsSuper>::kChunk;
     const int lane = threadIdx.x;
 
     const uint16_t *tree_table = P.tables;          // cut 2, alpha 0xFFFFFFFF/19 (compound.h:262)
@@ -1165,7 +1217,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 else tgt = kLeafFlag | (uint32_t)n.child;
                 n_super += __popcll(__ballot(admit));
                 uint2 out;
-                out.x = (uint32_t)st_split[lane];
+                out.x = (uint32_t)(is_raw_slog_prop(st_prop[lane] - nrefprops) && st_split[lane] != 0x7FFFFFFF ? slog_threshold(st_split[lane]) : st_split[lane]);
                 out.y = ((uint32_t)st_prop[lane] & 0xFFu) | (tgt << 8);
                 snodes_g[(size_t)sn * 64 + lane] = out;
                 if (sn >= 1 && sn <= kLdsSuper) sh.snodes[(sn - 1) * 64 + lane] = out;   // the root (0) lives in registers: LDS holds 1..kLdsSuper
@@ -1227,7 +1279,6 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 FastSym fsym;
                 fsym.amax_pos = maxv - zero; fsym.amax_neg = zero - minv;
                 fsym.emax_pos = ilog2u((uint32_t)fsym.amax_pos); fsym.emax_neg = ilog2u((uint32_t)fsym.amax_neg);
-                const unsigned long long k800 = 0x800ull;   // rounding term of rac.h:50, as the 64-bit addend of the mad
                 const bool sym_fast = minv < zero && zero < maxv;   // both signs possible: symbol.h:160-165 codes zero and sign
                 auto rows = [&](auto pred0_tag) {
                     constexpr bool PRED0 = decltype(pred0_tag)::value;
@@ -1282,11 +1333,10 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                         //       8 slog(left-topleft)   9 slog(topleft-top)   12 slog(left-leftleft)
                         // In row 0 topleft IS left (context_predict.h:128), which moves the left term from 6,8 to 7,9.
                         const int kloc = lane - nrefprops;
+                        // (3, 8, 9, 12 stay raw differences: the supernodes hold slog_threshold(split) for them)
                         const bool f_abs = (kloc == 1);
-                        const bool f_slog = (kloc == 3) | (kloc == 8) | (kloc == 9) | (kloc == 12);
-                        const bool f_patch = f_abs | f_slog | (kloc == 6) | (kloc == 7);
-                        const bool f_l12 = (kloc == 12);
-                        const bool f_lcoef = (kloc == 1) | (kloc == 3) | (kloc == 12) | (y ? ((kloc == 6) | (kloc == 8)) : ((kloc == 7) | (kloc == 9)));
+                        const int c_left = ((kloc == 1) | (kloc == 3) | (kloc == 12) | (y ? ((kloc == 6) | (kloc == 8)) : ((kloc == 7) | (kloc == 9)))) ? 1 : 0;
+                        const int c_ll = (kloc == 12) ? -1 : 0;
                         for (int x0 = 0; x0 < w; x0 += kChunk) {
                             const int nx = min(kChunk, w - x0);
                             // ---- vector phase: lane j prepares pixel x0+j ------------------------
@@ -1315,7 +1365,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                 int32_t *q = cp + nrefprops;
                                 q[0] = iabs(vtop); q[2] = slog(vtop); q[4] = y; q[5] = x0 + lane;
                                 q[10] = slog(vtop - vtr); q[11] = slog(vtop - vtt);
-                                q[1] = 0; q[3] = 0;
+                                q[1] = 0; q[3] = 0; q[12] = 0;
                                 if (y) { q[6] = vtop - vtl; q[7] = vtl + vtr - vtop; q[8] = -vtl; q[9] = vtl - vtop; }
                                 else { q[6] = zero; q[7] = 0; q[8] = 0; q[9] = -zero; }
                             }
@@ -1328,10 +1378,9 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                 int pv = sh.cprops[j * kPropPitch + (lane & 31)];
                                 const int l = left;
                                 {
-                                    int d = pv + (f_lcoef ? l : 0);
-                                    d = f_l12 ? (l - leftleft) : d;
-                                    const int r = f_abs ? iabs(d) : (f_slog ? slog(d) : d);
-                                    pv = f_patch ? r : pv;
+                                    // samples of a compressed group have at most 16 significant bits (check_bit_depth): 24-bit multiplies
+                                    const int d = pv + __mul24(c_left, l) + __mul24(c_ll, leftleft);
+                                    pv = f_abs ? iabs(d) : d;
                                 }
                                 int guess = zero;
                                 if (!PRED0) {
@@ -1386,7 +1435,9 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                         int t = (int)(tgt & 0xFFFFu);
                                         Node n = nodes[t];
                                         while (n.property >= 0) {
-                                            t = rdlane(pv, rfl((int)n.property)) > rfl(n.splitval) ? (int)n.child : (int)n.child + 1;
+                                            const int np = rfl((int)n.property);
+                                            const int sv = is_raw_slog_prop(np - nrefprops) ? slog_threshold(rfl(n.splitval)) : rfl(n.splitval);
+                                            t = rdlane(pv, np) > sv ? (int)n.child : (int)n.child + 1;
                                             t = rfl(t);
                                             n = nodes[t];
                                         }
@@ -1409,7 +1460,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
 #ifdef FUIF_EMU
                                         diff = fast_symbol(rac, s, L, fsym);
 #else
-                                        diff = fast_symbol_hw(rac, s, L, fsym, k800);
+                                        diff = fast_symbol_hw(rac, s, L, fsym);
 #endif
                                     } else diff = leaf_symbol(rac, s, lane, L, mn, mx);
                                     PROF_LAP(4);

@@ -1,9 +1,12 @@
 """Multi-GPU glue of the FUIF decode path (one process per GPU, torch.distributed; RCCL on GPUs).
 
 Images are independent units: a batch shards across ranks with NO data-path collective
-(SURVEY.md §8e).  The only exchange is the final gather of per-image output checksums, plus the
-barrier / max-over-ranks timing of the bench contract.  Everything here works on CPU tensors with
-the gloo backend as well, which is how tests/test_dist_gloo.py covers the N>1 path without GPUs.
+(SURVEY.md §8e).  The only exchange is the FINAL GATHER: every rank's decoded pictures, packed on the
+GPU to the interleaved 8 / 16-bit samples a PNM/PAM file holds (k_pack_samples, 6.2 MB per 1920x1080
+RGB image instead of 24.9 MB of int32 planes), are collected on the root rank in chunks over RCCL
+(gather_packed), next to the small per-image checksums and the barrier / max-over-ranks timing of the
+bench contract.  Everything here works on CPU tensors with the gloo backend as well, which is how
+tests/test_dist_gloo.py covers the N>1 path without GPUs.
 """
 import os
 
@@ -63,6 +66,48 @@ def gather_checksums(local, dist):
     parts = [torch.zeros_like(local) for _ in range(dist.get_world_size())]
     dist.all_gather(parts, local)
     return torch.stack(parts)
+
+
+def gather_packed(local, dist, root=0, chunk_bytes=256 << 20, keep=True):
+    """Final gather: `local` is this rank's packed output, a 1-D uint8 tensor (any length, lengths may
+    differ between ranks: mixed geometries, uneven shards).  Returns on the root a list with every rank's bytes in rank
+    order (the root's own entry is `local` itself), elsewhere None.  The payload moves in chunks of at most chunk_bytes
+    per rank and step, so the root's receive buffers are bounded and a chunk of one peer is in flight on every xGMI link
+    at a time (RCCL gather = one send / recv pair per peer: the root's 7 links work in parallel).
+    keep=False: the root does not store what it receives (a consumer would write it out chunk by chunk) but returns
+    one int64 byte sum per rank instead -- for payloads that would not fit next to the root's own decode state."""
+    if dist is None:
+        return [local] if keep else [int(torch.sum(local, dtype=torch.int64).item())]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([local.numel()], dtype=torch.int64, device=local.device))
+    sizes = [int(t.item()) for t in sizes]
+    out = None
+    if rank == root:
+        if keep:
+            out = [local if r == root else torch.empty(sizes[r], dtype=torch.uint8, device=local.device) for r in range(world)]
+        else:
+            out = [0] * world
+            out[root] = int(torch.sum(local, dtype=torch.int64).item())
+    longest = max(sizes)
+    for off in range(0, longest, chunk_bytes):
+        # equal-sized slots per step (gather needs them): a rank past its end sends an empty tail padded in the slot
+        step = min(chunk_bytes, longest - off)
+        mine = torch.zeros(step, dtype=torch.uint8, device=local.device)
+        n_mine = max(0, min(step, local.numel() - off))
+        if n_mine:
+            mine[:n_mine] = local[off:off + n_mine]
+        slots = [torch.empty(step, dtype=torch.uint8, device=local.device) for _ in range(world)] if rank == root else None
+        dist.gather(mine, gather_list=slots, dst=root)
+        if rank == root:
+            for r in range(world):
+                n_r = max(0, min(step, sizes[r] - off))
+                if r != root and n_r:
+                    if keep:
+                        out[r][off:off + n_r] = slots[r][:n_r]
+                    else:
+                        out[r] += int(torch.sum(slots[r][:n_r], dtype=torch.int64).item())
+    return out
 
 
 def all_ok(ok, dist, device):

@@ -1,6 +1,8 @@
 """CPU, world_size 2 over gloo: the N>1 glue of the decode path (sharding, max-over-ranks timing,
-final checksum gather) without GPUs.  The decode itself has no CPU path, so each rank fabricates
-the planes its shard would produce (a pure function of the global image index)."""
+final gather of packed pictures and of checksums) without GPUs.  The decode itself has no CPU path: the
+checksum test fabricates the planes a shard would produce (a pure function of the global image index), the
+packed-gather test takes the pictures from the CPU oracle (two golden fixtures of different geometry) in
+the byte layout k_pack_samples writes on the GPU (tests/test_gpu_parity.py checks that layout there)."""
 import os
 import socket
 
@@ -78,3 +80,43 @@ def test_two_rank_gather_over_gloo():
             a, b = fd.shard_range(n_items, r, world)
             flat.extend(gathered[r][: b - a])
         assert np.array_equal(np.array(flat), expected)
+
+
+def _packed_payload(name):
+    """interleaved, clamped 8-bit samples of a golden fixture as the reference CLI would write them (export/write_pam.h:136-150)"""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle_py import Port
+    blob = open(os.path.join(ROOT, "tests", "golden", name + ".fuif"), "rb").read()
+    d = Port().decode(blob)
+    planes = np.stack([np.clip(c["data"], 0, 255) for c in d.channels[:3]], axis=-1).astype(np.uint8)
+    return planes.tobytes()
+
+
+def _gather_worker(rank, world, port, payloads, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist = fd.init(device=torch.device("cpu"))
+    local = torch.frombuffer(bytearray(payloads[rank]), dtype=torch.uint8)
+    got = fd.gather_packed(local, dist, root=0, chunk_bytes=100_000)   # several chunks, the last one ragged, rank 1 ends early
+    dist.barrier()
+    q.put((rank, None if got is None else [g.numpy().tobytes() for g in got]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_of_packed_pictures_of_two_geometries():
+    # rank 0: three 97x61 pictures (53 KB), rank 1: one 512x512 picture (786 KB): lengths differ, neither a chunk multiple
+    payloads = [_packed_payload("rgb8_97x61") * 3, _packed_payload("c1_rgb8_512x512")]
+    assert len(payloads[0]) == 3 * 97 * 61 * 3 and len(payloads[1]) == 512 * 512 * 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, payloads, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1] is None                        # only the root holds the gathered pictures
+    assert res[0] == payloads                    # byte for byte, in rank order
