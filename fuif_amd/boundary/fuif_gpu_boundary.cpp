@@ -12,9 +12,14 @@
 // The reference's own definitions of these three are kept in the link under the names
 // fuif_decode_file_cpu / fuif_decode_cpu / Image::undo_transforms_cpu (the Makefile compiles
 // encoding.cpp and image.cpp with -Dname=name_cpu) and are used for what is outside the GPU
-// scope: -i/--identify, animations (FUAF), streams with Palette/Match/Permute/Approximate
-// transforms, and undo_transforms(keep != 0).  Everything else (fuif.cpp, import/export code,
-// the encoder) is compiled and linked UNCHANGED.
+// scope: -i/--identify (header only), undo_transforms(keep != 0), and the streams the library
+// reports as FUIFGPU_E_UNSUPPORTED / FUIFGPU_ST_UNSUPPORTED (Permute; soft 2D matches).  Stills and
+// animations (FUAF), Squeeze / YCoCg / YCbCr / DCT / Quantize / Subsample / Palette / Approximate / 2D-match
+// chains all decode on the GPU.  With FUIFGPU_NO_CPU_FALLBACK=1 in the environment nothing is ever
+// routed to the reference's CPU decoder: an unsupported stream is an error (tests/test_boundary_cli.py
+// runs that way, so a planner regression cannot hide behind the fallback); FUIFGPU_VERBOSE=1 reports
+// on stderr which path decoded.  Everything else (fuif.cpp, import/export code, the encoder) is
+// compiled and linked UNCHANGED.
 //
 // Ownership: fuif_decode() fills `image` exactly like the reference (channel vector = coded
 // channels with geometry, ranges, q and samples narrowed to pixel_type; transform list with
@@ -25,6 +30,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <utility>
 #include <vector>
 
 #include "encoding/encoding.h"
@@ -44,15 +50,27 @@ namespace {
 struct Resident {
     fuifgpu_plan *plan = nullptr;
     fuifgpu_batch *batch = nullptr;
+    std::vector<uint8_t> bytes;          // the stream, for the CPU route if the inverse chain turns out to be unsupported
+    int preview = -1;                    // fuif_options::preview of the decode (fuif_options itself is not assignable: it holds an Image)
+    size_t n_channels = 0;               // identity of the Image this batch belongs to (the key is only an address)
+    const pixel_type *first_plane = nullptr;
     ~Resident() {
         if (batch) fuifgpu_batch_destroy(batch);
         if (plan) fuifgpu_plan_destroy(plan);
     }
 };
+// Never destroyed: static destructors run after the HIP runtime may be gone (hipFree / hipEventDestroy at exit);
+// the process is ending anyway.
 std::map<const Image *, std::unique_ptr<Resident>> &registry() {
-    static std::map<const Image *, std::unique_ptr<Resident>> r;
-    return r;
+    static auto *r = new std::map<const Image *, std::unique_ptr<Resident>>();
+    return *r;
 }
+bool env_flag(const char *name) { const char *e = getenv(name); return e && *e && strcmp(e, "0") != 0; }
+// den / num / loops of an animation header (encoding.cpp:611-622): the four varints after the magic, then these
+struct Cursor {
+    const std::vector<uint8_t> &b; size_t pos;
+    int varint() { int r = 0; for (int k = 0; k < 10 && pos < b.size(); k++) { int c = b[pos++]; if (c < 128) return r + c; r = (r + c - 128) << 7; } return -1; }
+};
 
 template <typename IO> std::vector<uint8_t> slurp(IO &io) {
     std::vector<uint8_t> b;
@@ -69,7 +87,6 @@ bool gpu_decode_bytes(const std::vector<uint8_t> &bytes, Image &image, const fui
     if (rc != FUIFGPU_OK) { e_printf("Corrupt file. Aborting. (%s)\n", fuifgpu_last_error()); return false; }
     fuifgpu_image_info info;
     fuifgpu_plan_info(res->plan, &info);
-    if (info.nb_frames > 1) { *unsupported = true; return false; }
     rc = fuifgpu_batch_create(res->plan, 1, bytes.size(), nullptr, nullptr, 1, &res->batch);
     if (rc != FUIFGPU_OK) { e_printf("fuifgpu: %s (%s)\n", fuifgpu_strerror(rc), fuifgpu_last_error()); return false; }
     const uint8_t *blobs[1] = {bytes.data()};
@@ -82,10 +99,21 @@ bool gpu_decode_bytes(const std::vector<uint8_t> &bytes, Image &image, const fui
     int32_t status = 0;
     uint32_t used = 0;
     fuifgpu_batch_status(res->batch, &status, &used);
+    if (status & FUIFGPU_ST_UNSUPPORTED) { *unsupported = true; return false; }
     if (status & FUIFGPU_ST_CORRUPT) { e_printf("Corruption detected.\n"); return false; }
 
     // Image(w,h,maxval,nb_channels,colormodel) + what meta_apply and the channel loop leave behind
     image = Image(info.w, info.h, info.maxval, info.nb_channels, info.colormodel);
+    if (info.nb_frames > 1 && bytes.size() > 4) {   // FUAF: filmstrip geometry + timing (encoding.cpp:611-622,641-645)
+        Cursor c{bytes, 4};
+        for (int k = 0; k < 4; k++) c.varint();
+        image.nb_frames = c.varint() + 2;
+        image.den = c.varint() + 1;
+        image.num.clear();
+        const int numerator = c.varint();
+        if (numerator > 0) { image.num.push_back(numerator); for (int i = 1; i < image.nb_frames; i++) image.num.push_back(c.varint()); }
+        image.loops = c.varint();
+    }
     std::vector<int32_t> slab((size_t)(info.coef_elems > 0 ? info.coef_elems : 1));
     fuifgpu_batch_download_coef(res->batch, 0, slab.data(), nullptr);
     std::vector<int32_t> meta((size_t)info.nb_coded_channels * 4);
@@ -118,13 +146,20 @@ bool gpu_decode_bytes(const std::vector<uint8_t> &bytes, Image &image, const fui
         for (int k = 0; k < np && k < (int)params.size(); k++) tr.parameters.push_back(params[k]);
         image.transform.push_back(tr);
     }
-    // Image::nb_meta_channels / nb_channels as the Palette meta steps leave them (transform/palette.h:87-88)
-    for (const Transform &tr : image.transform)
+    // Image::nb_meta_channels / nb_channels as the meta steps leave them (transform/palette.h:87-88, 2dmatch.h:191)
+    for (const Transform &tr : image.transform) {
         if (tr.ID == TRANSFORM_PALETTE && tr.parameters.size() == 3) {
             image.nb_meta_channels++;
             image.nb_channels -= tr.parameters[1] - tr.parameters[0];
         }
+        if (tr.ID == TRANSFORM_2DMATCH) image.nb_meta_channels++;
+    }
     image.error = false;
+    res->bytes = bytes;
+    res->preview = options.preview;
+    res->n_channels = image.channel.size();
+    res->first_plane = image.channel.empty() ? nullptr : image.channel[0].data.data();
+    if (env_flag("FUIFGPU_VERBOSE")) fprintf(stderr, "fuifgpu: %d coded channels entropy-decoded on the GPU\n", info.nb_coded_channels);
     registry()[&image] = std::move(res);
     return true;
 }
@@ -132,11 +167,17 @@ bool gpu_decode_bytes(const std::vector<uint8_t> &bytes, Image &image, const fui
 }  // namespace
 
 template <typename IO> bool fuif_decode(IO &io, Image &image, fuif_options options) {
+    registry().erase(&image);   // whatever was decoded into an Image at this address before is gone now
     if (options.identify) return fuif_decode_cpu(io, image, options);
     std::vector<uint8_t> bytes = slurp(io);
     bool unsupported = false;
     if (gpu_decode_bytes(bytes, image, options, &unsupported)) return true;
     if (!unsupported) return false;
+    if (env_flag("FUIFGPU_NO_CPU_FALLBACK")) {
+        e_printf("fuifgpu: this stream needs a feature outside the GPU path (%s) and FUIFGPU_NO_CPU_FALLBACK is set\n", fuifgpu_last_error());
+        return false;
+    }
+    if (env_flag("FUIFGPU_VERBOSE")) fprintf(stderr, "fuifgpu: outside the GPU path, decoding with the reference's CPU code\n");
     BlobReader again(bytes.data(), bytes.size());  // outside the GPU scope: the reference's own decoder
     return fuif_decode_cpu(again, image, options);
 }
@@ -157,6 +198,13 @@ bool fuif_decode_file(const char *filename, Image &image, fuif_options options) 
 void fuifgpu_boundary_undo_transforms(Image *self, int keep) __asm__("_ZN5Image15undo_transformsEi");
 void fuifgpu_boundary_undo_transforms(Image *self, int keep) {
     auto it = registry().find(self);
+    // the batch must belong to THIS image: same channel table as fuif_decode left it (an Image constructed later at the
+    // same address, or one whose channels were replaced, is not ours)
+    if (it != registry().end() && (it->second->n_channels != self->channel.size() ||
+                                   it->second->first_plane != (self->channel.empty() ? nullptr : self->channel[0].data.data()))) {
+        registry().erase(it);
+        it = registry().end();
+    }
     if (it == registry().end() || keep != 0) {
         if (it != registry().end()) registry().erase(it);
         self->undo_transforms(keep);  // macro-renamed: the reference's own CPU implementation
@@ -169,6 +217,34 @@ void fuifgpu_boundary_undo_transforms(Image *self, int keep) {
     if (rc == FUIFGPU_OK) rc = fuifgpu_batch_sync(res.batch, nullptr);
     if (rc != FUIFGPU_OK) {
         e_printf("Error while undoing transforms on the GPU: %s\n", fuifgpu_last_error());
+        self->error = true;
+        registry().erase(it);
+        return;
+    }
+    // the inverse kernels can still flag the image (soft 2D matches, forward references: k_match_init / k_inv_match_frames)
+    int32_t status = 0;
+    fuifgpu_batch_status(res.batch, &status, nullptr);
+    if (status & FUIFGPU_ST_UNSUPPORTED) {
+        if (env_flag("FUIFGPU_NO_CPU_FALLBACK")) {
+            e_printf("fuifgpu: the transform chain needs a feature outside the GPU path and FUIFGPU_NO_CPU_FALLBACK is set\n");
+            self->error = true;
+        } else {
+            // the planes on the host are still the coded ones: decode again with the reference's code and undo there
+            BlobReader again(res.bytes.data(), res.bytes.size());
+            Image redo;
+            fuif_options opt = default_fuif_options;
+            opt.preview = res.preview;
+            if (fuif_decode_cpu(again, redo, opt)) {
+                redo.undo_transforms(0);   // (macro-renamed: the CPU implementation)
+                self->channel.swap(redo.channel); self->transform.clear();
+                self->nb_channels = redo.nb_channels; self->nb_meta_channels = redo.nb_meta_channels; self->error = redo.error;
+            } else self->error = true;
+        }
+        registry().erase(self);
+        return;
+    }
+    if (status & FUIFGPU_ST_CORRUPT) {
+        e_printf("Corruption detected while undoing transforms.\n");
         self->error = true;
         registry().erase(it);
         return;

@@ -312,6 +312,7 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
         t.start = g[k].start;
         t.first_channel = k == 0 ? 0 : g[k].first_channel;
         t.last_channel = k + 1 < g.size() ? g[k + 1].first_channel - 1 : nch - 1;
+        t.end = k + 1 < g.size() ? g[k + 1].start : 0u;
         b->tiles.push_back(t);
     };
     // Dense launches with more tiles than wavefronts use the context scheduler (maniac_decode.h, sched == 1): tiles image by

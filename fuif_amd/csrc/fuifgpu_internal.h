@@ -64,6 +64,8 @@ struct Tile {
     uint32_t image;
     uint32_t start;                       // byte offset of the first group header of the tile
     int32_t first_channel, last_channel;  // coded channels [first,last] are decoded (or zero-filled) by this tile
+    uint32_t end;                         // where the index says the NEXT tile starts (0 = last tile / unknown): a tile that is
+                                          // decoded in full must stop exactly there, else the index does not belong to the stream
 };
 
 // --- inverse-transform schedule ---------------------------------------------------------------

@@ -34,6 +34,7 @@ bool get_varint(const uint8_t *p, size_t n, size_t &pos, uint64_t &out) {
     for (int k = 0; k < 10; k++) {
         if (pos >= n) return false;
         const uint8_t c = p[pos++];
+        if (r >> 57) return false;   // ten groups carry 70 bits: the value must fit 64
         r = (r << 7) | (c & 127);
         if (c < 128) { out = r; return true; }
     }
@@ -76,7 +77,8 @@ bool parse_index_trailer(const uint8_t *blob, size_t n, size_t data_start, int n
     for (uint64_t g = 0; g < count; g++) {
         uint64_t dc = 0, ds = 0;
         if (!get_varint(p, len, pos, dc) || !get_varint(p, len, pos, ds)) return false;
-        if (g && (dc == 0 || ds == 0)) return false;
+        if (g && (dc == 0 || ds == 0)) return false;              // strictly ascending channels and offsets
+        if (dc >= (uint64_t)nch || ds >= begin) return false;     // bounded before the sums: a 70-bit varint cannot wrap them
         c += dc; s += ds;
         if (c >= (uint64_t)nch || s >= begin) return false;
         groups.push_back(GroupEntry{(uint32_t)s, (int32_t)c});

@@ -1513,6 +1513,10 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
     }
     if (yielded) { st_yields++; __syncthreads(); continue; }   // the tile goes on later, on whichever wavefront picks it up
     if (s_limit_hit(s)) status |= ST_TRUNCATED;
+    // The group index is untrusted input (a stale or crafted trailer): a tile that was decoded in full must have stopped
+    // exactly where the next tile starts, as it does when the stream is decoded front to back; otherwise the picture is
+    // flagged instead of being silently different from what the reference (which ignores the trailer) decodes.
+    if (rflu(tile.end) != 0u && !(status & (ST_TRUNCATED | ST_CORRUPT)) && s.pos != rflu(tile.end)) status |= ST_CORRUPT;
     // planes the tile never reached read as zeros in the reference (empty Channel::data,
     // image/image.h:82-85; zero-filled residuals, transform/squeeze.h:379-383).  Every channel of
     // the tile ends up published as final, whatever path led here: nobody waits for ever.

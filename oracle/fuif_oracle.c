@@ -1497,3 +1497,72 @@ int fo_kat_read_bits(const uint8_t *buf, size_t n, int count, int32_t *out) {
     for (int i = 0; i < count; i++) out[i] = rac_read_bit(&rac);
     return 1;
 }
+
+/* ------------------------------------------------------------------------------------------- */
+/* single inverse transforms on raw planes: the checkers of the fuifgpu_inv_* / fuifgpu_idct8x8 / fuifgpu_upsample  */
+/* entry points (tests/test_gpu_transform_exports.py).  Each builds the little Image the reference's               */
+/* Transform::apply(image, true) (transform/transform.cpp:48-63) would be handed and runs the restatement above.   */
+static void kat_plane(fo_channel *c, const int32_t *data, int w, int h, int minval, int maxval) {
+    ch_init(c);
+    c->w = w; c->h = h; c->minval = minval; c->maxval = maxval; ch_setzero(c);
+    c->size = (size_t)w * h;
+    c->data = (int32_t *)malloc(sizeof(int32_t) * (c->size ? c->size : 1));
+    if (data) memcpy(c->data, data, sizeof(int32_t) * c->size);
+}
+static fo_image *kat_image(int nch, int maxval) {
+    fo_image *img = (fo_image *)calloc(1, sizeof(fo_image));
+    img->ch = (fo_channel *)calloc(nch, sizeof(fo_channel));
+    img->nch = nch; img->nb_channels = nch; img->real_nb_channels = nch; img->maxval = maxval; img->minval = 0; img->nb_frames = 1;
+    return img;
+}
+/* transform/squeeze.h:81-132 (horizontal) / :173-224 (vertical): out is (aw+rw) x ah resp. aw x (ah+rh) */
+int fo_kat_inv_squeeze(int horizontal, const int32_t *avg, int aw, int ah, const int32_t *res, int rw, int rh, int32_t *out) {
+    fo_image *img = kat_image(2, 255);
+    kat_plane(&img->ch[0], avg, aw, ah, -32768, 32767);
+    kat_plane(&img->ch[1], res, rw, rh, -32768, 32767);
+    img->ch[0].hshift = img->ch[0].vshift = img->ch[0].hcshift = img->ch[0].vcshift = 1;
+    if (horizontal) inv_hsqueeze(img, 0, 1); else inv_vsqueeze(img, 0, 1);
+    memcpy(out, img->ch[0].data, sizeof(int32_t) * (size_t)img->ch[0].w * img->ch[0].h);
+    fo_free(img);
+    return 1;
+}
+/* transform/ycocg.h:33-63 / transform/ycbcr.h:33-63, in place on three w x h planes */
+int fo_kat_inv_color(int ycbcr, int32_t *c0, int32_t *c1, int32_t *c2, int w, int h, int minval, int maxval) {
+    fo_image *img = kat_image(3, maxval);
+    img->minval = minval;
+    int32_t *p[3] = {c0, c1, c2};
+    for (int k = 0; k < 3; k++) kat_plane(&img->ch[k], p[k], w, h, -32768, 32767);
+    int ok = ycbcr ? inv_ycbcr(img) : inv_ycocg(img);
+    for (int k = 0; k < 3; k++) memcpy(p[k], img->ch[k].data, sizeof(int32_t) * (size_t)w * h);
+    fo_free(img);
+    return ok;
+}
+/* transform/dct.h:249-296 for one component: planes64 = the 64 coefficient planes in CHANNEL order (DC, then the AC
+ * planes as meta_dct lays them out: plane k holds zig-zag rank k), each bw x bh; out = 8bw x 8bh */
+int fo_kat_inv_dct(const int32_t *planes64, int bw, int bh, int maxval, int32_t *out) {
+    fo_image *img = kat_image(64, maxval);
+    for (int k = 0; k < 64; k++) kat_plane(&img->ch[k], planes64 + (size_t)k * bw * bh, bw, bh, -32768, 32767);
+    img->nb_channels = 1;
+    fo_transform t; t.id = 4; t.nparams = 0; t.params = NULL;
+    int ok = inv_dct(img, &t);
+    if (ok) memcpy(out, img->ch[0].data, sizeof(int32_t) * (size_t)bw * 8 * bh * 8);
+    free(t.params);
+    fo_free(img);
+    return ok;
+}
+void fo_kat_zigzag(int32_t *out64) { for (int i = 0; i < 64; i++) out64[i] = fo_zigzag[i]; }
+/* transform/subsample.h:73-127 for one plane that is smaller than the first (luma) plane; srh, srv in {1,2} */
+int fo_kat_upsample(const int32_t *in, int w, int h, int srh, int srv, int32_t *out) {
+    fo_image *img = kat_image(2, 255);
+    kat_plane(&img->ch[0], NULL, w * srh, h * srv, 0, 255);
+    memset(img->ch[0].data, 0, sizeof(int32_t) * img->ch[0].size);
+    kat_plane(&img->ch[1], in, w, h, -32768, 32767);
+    fo_transform t; t.id = 3; t.nparams = 4;
+    t.params = (int *)malloc(sizeof(int) * 4);
+    t.params[0] = 1; t.params[1] = 1; t.params[2] = srh; t.params[3] = srv;
+    int ok = inv_subsample(img, &t);
+    if (ok) memcpy(out, img->ch[1].data, sizeof(int32_t) * (size_t)w * srh * h * srv);
+    free(t.params);
+    fo_free(img);
+    return ok;
+}

@@ -71,6 +71,12 @@ int fo_kat_simple_symbols(const uint8_t *buf, size_t n, int count, int min, int 
 int fo_kat_uniform_symbols(const uint8_t *buf, size_t n, int count, int min, int len, int32_t *out, int *pos);
 int fo_kat_final_symbols(const uint8_t *buf, size_t n, int count, int zero_chance, int min, int max, int32_t *out, int *pos);
 int fo_kat_read_bits(const uint8_t *buf, size_t n, int count, int32_t *out);
+/* single inverse transforms on raw planes (checkers of the fuifgpu_inv_* / fuifgpu_idct8x8 / fuifgpu_upsample entry points) */
+int fo_kat_inv_squeeze(int horizontal, const int32_t *avg, int aw, int ah, const int32_t *res, int rw, int rh, int32_t *out);
+int fo_kat_inv_color(int ycbcr, int32_t *c0, int32_t *c1, int32_t *c2, int w, int h, int minval, int maxval);
+int fo_kat_inv_dct(const int32_t *planes64, int bw, int bh, int maxval, int32_t *out);
+void fo_kat_zigzag(int32_t *out64);
+int fo_kat_upsample(const int32_t *in, int w, int h, int srh, int srv, int32_t *out);
 
 #ifdef __cplusplus
 }

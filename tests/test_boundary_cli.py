@@ -14,10 +14,15 @@ from conftest import GOLDEN, ROOT
 CLI = os.path.join(ROOT, "fuif_amd", "boundary", "_build", "fuif_gpu")
 
 
-def run_cli(args):
+def run_cli(args, fallback=False):
     env = dict(os.environ)
     if os.path.exists("/opt/conda/lib/libjpeg.so.9"):
         env["LD_PRELOAD"] = "/opt/conda/lib/libjpeg.so.9"
+    # no silent CPU route: a stream the GPU planner rejects makes the CLI fail instead of quietly running the reference's
+    # decoder (which would keep these tests green without the GPU path); FUIFGPU_VERBOSE makes the path taken visible
+    env["FUIFGPU_VERBOSE"] = "1"
+    if not fallback:
+        env["FUIFGPU_NO_CPU_FALLBACK"] = "1"
     return subprocess.run([CLI] + args, env=env, capture_output=True, text=True, timeout=300)
 
 
@@ -53,6 +58,7 @@ def test_reference_cli_decodes_through_gpu(name, port, tmp_path):
     out = str(tmp_path / "out.pam")
     r = run_cli(["-d", src, out])
     assert r.returncode == 0, r.stdout + r.stderr
+    assert "entropy-decoded on the GPU" in r.stderr
     d = port.decode(open(src, "rb").read())
     w, h = d.info["w"], d.info["h"]
     planes = [c["data"][:h, :w] for c in d.channels]
@@ -72,3 +78,25 @@ def test_reference_cli_partial_decode_through_gpu(port, tmp_path):
     d = port.decode(open(src, "rb").read(), preview=2)
     planes = [c["data"] for c in d.channels]
     assert open(out, "rb").read().endswith(expected_pnm_payload(planes, 255))
+
+
+@pytest.mark.gpu
+def test_reference_cli_decodes_an_animation_through_gpu(ref, tmp_path):
+    """FUAF (3 frames, and 4 frames with the CLI's default 2D match against previous frames): the GPU path, not the CPU
+    route, and the same output file as the unmodified reference CLI"""
+    need_cli()
+    ref_cli = os.path.join(ROOT, "oracle", "_ref", "fuif")
+    if not os.path.exists(ref_cli):
+        pytest.skip("oracle/_ref/fuif not built")
+    env = dict(os.environ)
+    if os.path.exists("/opt/conda/lib/libjpeg.so.9"):
+        env["LD_PRELOAD"] = "/opt/conda/lib/libjpeg.so.9"
+    for name in ("anim3_48x32", "anim4_match_40x28"):
+        src = os.path.join(GOLDEN, name + ".fuif")
+        a, b = str(tmp_path / (name + "_gpu.pam")), str(tmp_path / (name + "_ref.pam"))
+        r = run_cli(["-d", src, a])
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "entropy-decoded on the GPU" in r.stderr
+        rb = subprocess.run([ref_cli, "-d", src, b], env=env, capture_output=True, text=True, timeout=300)
+        assert rb.returncode == 0, rb.stderr
+        assert open(a, "rb").read() == open(b, "rb").read(), name

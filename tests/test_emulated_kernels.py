@@ -47,7 +47,9 @@ SELECTED = [
     "tests/test_gpu_group_parallel.py::test_mixed_batch_with_more_tiles_than_wavefronts",
     "tests/test_gpu_group_parallel.py::test_jpeg_like_indexed",
     "tests/test_gpu_group_parallel.py::test_truncated_indexed_stream_falls_back_and_side_index_on_truncated_blob",
+    "tests/test_gpu_group_parallel.py::test_stale_index_is_flagged_not_silently_wrong",
     "tests/test_fuzz.py::test_gpu_agrees_with_oracle_on_corrupt_payload",
+    "tests/test_gpu_transform_exports.py",
 ]
 
 
@@ -107,9 +109,10 @@ def test_reference_cli_through_the_boundary_writes_the_reference_files(tmp_path)
     env = dict(os.environ)
     if os.path.exists("/opt/conda/lib/libjpeg.so.9"):
         env["LD_PRELOAD"] = "/opt/conda/lib/libjpeg.so.9"
-    env_gpu = dict(env, LD_LIBRARY_PATH=str(libdir), EMU_ALARM="600")
+    env_gpu = dict(env, LD_LIBRARY_PATH=str(libdir), EMU_ALARM="600", FUIFGPU_NO_CPU_FALLBACK="1")   # the GPU path or nothing
     names = ["rgb8_97x61", "pal_rgb_graphic_120x90", "pal_rgba_graphic_72x64", "pal_rgb_channelwise_96x72", "approx_quant_rgb8_40x30",
-             "approx_on_palette_gray12_24x50", "match_rgb_graphic_96x80", "gray8_nosqueeze_60x40", "jpeg420_256x192_q90", "rgba14_80x72"]
+             "approx_on_palette_gray12_24x50", "match_rgb_graphic_96x80", "gray8_nosqueeze_60x40", "jpeg420_256x192_q90", "rgba14_80x72",
+             "anim3_48x32", "anim4_match_40x28"]
     for name in names:
         src = os.path.join(ROOT, "tests", "golden", name + ".fuif")
         for extra in ([], ["-R", "2"]):

@@ -139,3 +139,22 @@ def test_truncated_indexed_stream_falls_back_and_side_index_on_truncated_blob(gp
     k = len(part) - 1
     first_cut_channel = part[k][0]
     assert all(np.array_equal(a, b) for a, b in list(zip(seq["pre"][0], par["pre"][0]))[:first_cut_channel])
+
+
+def test_stale_index_is_flagged_not_silently_wrong(gpulib, port):
+    """the trailer is untrusted: an index whose offsets are ascending and inside the stream but do not belong to it (here:
+    one group start moved by a byte) must not yield a different picture with status 0 -- the tile before the moved start
+    does not stop where the next one begins and the image is flagged corrupt (the reference ignores the trailer)"""
+    img = photographic(128, 96, 3, 8, seed=11)
+    blob = gpulib.encode_image(img, 8, tree_mode=1, index=True)
+    groups = gpulib.index_parse(blob)
+    good = _run(gpulib, [blob])
+    assert good["st"][0] == 0
+    k = len(groups) // 2
+    moved = list(groups)
+    moved[k] = (moved[k][0], moved[k][1] + 1)
+    stale = gpulib.index_append(blob, moved)
+    assert gpulib.index_parse(stale) == moved        # structurally a valid index
+    res = _run(gpulib, [stale, blob])
+    assert res["st"][0] & 2                          # corrupt
+    assert res["st"][1] == 0 and _same(res, good, 1, 0)   # the intact stream next to it in the batch is untouched

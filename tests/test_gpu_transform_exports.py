@@ -1,0 +1,191 @@
+"""GPU parity (-m gpu) of the single-transform entry points of the C-ABI (include/fuifgpu.h: fuifgpu_inv_hsqueeze,
+fuifgpu_inv_vsqueeze, fuifgpu_inv_ycocg, fuifgpu_inv_ycbcr, fuifgpu_idct8x8, fuifgpu_upsample) -- what
+Transform::apply(image, true) (transform/transform.cpp:48-63) dispatches to in the boundary layer.
+
+Each is run on raw device planes (random, incl. negative values, odd and tiny sizes, several planes per launch) and
+compared bit for bit with the oracle's restatement of the same reference function; the known answers of SURVEY.md
+Appendix E.4-E.6 (printed by the real reference) are pinned as well.  On a machine without a GPU the same tests run
+against the wavefront emulator build (tests/test_emulated_kernels.py), where "device" memory is host memory."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+EMULATED = "_emu" in os.environ.get("FUIF_AMD_LIB", "")
+
+
+class Dev:
+    """int32 planes in device memory (torch on the GPU box; plain host memory under the emulator)"""
+
+    def __init__(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.int32)
+        if EMULATED:
+            self.a = arr.copy()
+            self.ptr = self.a.ctypes.data
+        else:
+            import torch
+            self.t = torch.from_numpy(arr.copy()).cuda()
+            self.ptr = self.t.data_ptr()
+
+    def get(self):
+        if EMULATED:
+            return self.a.copy()
+        import torch
+        torch.cuda.synchronize()
+        return self.t.cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def olib():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle_py import Port
+    return Port().lib
+
+
+@pytest.fixture(scope="module")
+def glib(gpulib):
+    L = gpulib.lib()
+    if not EMULATED:
+        import torch
+        torch.zeros(1).cuda()          # one HIP context for torch and the library
+    return L
+
+
+def _sync():
+    if not EMULATED:
+        import torch
+        torch.cuda.synchronize()
+
+
+def ref_squeeze(olib, horizontal, avg, res):
+    ah, aw = avg.shape
+    rh, rw = res.shape
+    out = np.zeros((ah, aw + rw) if horizontal else (ah + rh, aw), np.int32)
+    assert olib.fo_kat_inv_squeeze(int(horizontal), avg.ctypes.data_as(C.c_void_p), aw, ah, res.ctypes.data_as(C.c_void_p), rw, rh,
+                                   out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+@pytest.mark.parametrize("w1,w2,h", [(4, 3, 1), (4, 4, 1), (1, 0, 5), (1, 1, 3), (33, 32, 7), (64, 64, 65), (129, 128, 130), (960, 960, 9)])
+def test_inv_hsqueeze_export(glib, olib, w1, w2, h):
+    rng = np.random.default_rng(w1 * 1000 + h)
+    n_planes = 3
+    avg = rng.integers(-3000, 3000, (n_planes, h, w1), dtype=np.int32)
+    res = rng.integers(-700, 700, (n_planes, h, max(w2, 1)), dtype=np.int32)[:, :, :w2].copy()
+    d_avg, d_res, d_out = Dev(avg), Dev(res if w2 else np.zeros(1, np.int32)), Dev(np.zeros((n_planes, h, w1 + w2), np.int32))
+    rc = glib.fuifgpu_inv_hsqueeze(d_avg.ptr, w1, d_res.ptr if w2 else None, w2, h, d_out.ptr, n_planes, h * w1, h * w2, h * (w1 + w2), None)
+    assert rc == 0
+    got = d_out.get().reshape(n_planes, h, w1 + w2)
+    for p in range(n_planes):
+        assert np.array_equal(got[p], ref_squeeze(olib, True, avg[p], res[p].reshape(h, w2)))
+
+
+@pytest.mark.parametrize("h1,h2,w", [(4, 3, 1), (4, 4, 2), (1, 0, 5), (1, 1, 3), (33, 32, 7), (65, 64, 300), (540, 540, 17)])
+def test_inv_vsqueeze_export(glib, olib, h1, h2, w):
+    rng = np.random.default_rng(h1 * 1000 + w)
+    n_planes = 2
+    avg = rng.integers(-3000, 3000, (n_planes, h1, w), dtype=np.int32)
+    res = rng.integers(-700, 700, (n_planes, max(h2, 1), w), dtype=np.int32)[:, :h2].copy()
+    d_avg, d_res, d_out = Dev(avg), Dev(res if h2 else np.zeros(1, np.int32)), Dev(np.zeros((n_planes, h1 + h2, w), np.int32))
+    rc = glib.fuifgpu_inv_vsqueeze(d_avg.ptr, h1, d_res.ptr if h2 else None, h2, w, d_out.ptr, n_planes, h1 * w, h2 * w, (h1 + h2) * w, None)
+    assert rc == 0
+    got = d_out.get().reshape(n_planes, h1 + h2, w)
+    for p in range(n_planes):
+        assert np.array_equal(got[p], ref_squeeze(olib, False, avg[p], res[p].reshape(h2, w)))
+
+
+def test_squeeze_known_answers(glib, olib):
+    """SURVEY.md Appendix E.4 (real reference): averages [100,104,90,91] + residuals [3,-2,5] -> 101 99 103 105 92 87 91,
+    as a row (horizontal) and as a column (vertical)"""
+    want = np.array([101, 99, 103, 105, 92, 87, 91], np.int32)
+    avg, res = np.array([[100, 104, 90, 91]], np.int32), np.array([[3, -2, 5]], np.int32)
+    d_avg, d_res, d_out = Dev(avg), Dev(res), Dev(np.zeros((1, 7), np.int32))
+    assert glib.fuifgpu_inv_hsqueeze(d_avg.ptr, 4, d_res.ptr, 3, 1, d_out.ptr, 1, 4, 3, 7, None) == 0
+    assert np.array_equal(d_out.get().ravel(), want)
+    d_avg, d_res, d_out = Dev(avg.T.copy()), Dev(res.T.copy()), Dev(np.zeros((7, 1), np.int32))
+    assert glib.fuifgpu_inv_vsqueeze(d_avg.ptr, 4, d_res.ptr, 3, 1, d_out.ptr, 1, 4, 3, 7, None) == 0
+    assert np.array_equal(d_out.get().ravel(), want)
+    assert np.array_equal(ref_squeeze(olib, True, avg, res).ravel(), want)
+
+
+@pytest.mark.parametrize("ycbcr", [0, 1])
+@pytest.mark.parametrize("w,h,maxval", [(1, 1, 255), (7, 5, 255), (130, 33, 255), (64, 64, 16383)])
+def test_inv_color_exports(glib, olib, ycbcr, w, h, maxval):
+    rng = np.random.default_rng(w + 7 * h + ycbcr)
+    lo, hi = (-maxval - 10, 2 * maxval) if not ycbcr else (-20, maxval + 20)
+    planes = [rng.integers(lo, hi, (h, w), dtype=np.int32) for _ in range(3)]
+    want = [p.copy() for p in planes]
+    assert olib.fo_kat_inv_color(ycbcr, *[p.ctypes.data_as(C.c_void_p) for p in want], w, h, 0, maxval)
+    devs = [Dev(p) for p in planes]
+    if ycbcr:
+        rc = glib.fuifgpu_inv_ycbcr(devs[0].ptr, devs[1].ptr, devs[2].ptr, w, h, w, w, w, 0, maxval, None)
+    else:
+        rc = glib.fuifgpu_inv_ycocg(devs[0].ptr, devs[1].ptr, devs[2].ptr, w, h, w, w, w, maxval, None)
+    assert rc == 0
+    for d, e in zip(devs, want):
+        assert np.array_equal(d.get().reshape(h, w), e)
+
+
+def test_ycocg_known_answers(glib):
+    """Appendix E.5: (Y,Co,Cg) -> (R,G,B) at maxval 255"""
+    src = np.array([[120, -30, 15], [0, 255, -255], [255, -255, 255], [77, 13, -8]], np.int32)
+    want = np.array([[98, 128, 128], [255, 0, 1], [0, 255, 255], [88, 73, 75]], np.int32)
+    devs = [Dev(src[:, k].copy()) for k in range(3)]
+    assert glib.fuifgpu_inv_ycocg(devs[0].ptr, devs[1].ptr, devs[2].ptr, 4, 1, 4, 4, 4, 255, None) == 0
+    got = np.stack([d.get() for d in devs], axis=1)
+    assert np.array_equal(got, want)
+
+
+def _zigzag(olib):
+    z = np.zeros(64, np.int32)
+    olib.fo_kat_zigzag(z.ctypes.data_as(C.c_void_p))
+    return z
+
+
+@pytest.mark.parametrize("bw,bh,maxval", [(1, 1, 255), (3, 2, 255), (17, 9, 255), (40, 23, 1023)])
+def test_idct_export(glib, olib, bw, bh, maxval):
+    rng = np.random.default_rng(bw * 64 + bh)
+    planes = rng.integers(-60, 60, (64, bh, bw), dtype=np.int32)
+    planes[0] = rng.integers(-4 * (maxval + 1), 4 * (maxval + 1), (bh, bw), dtype=np.int32)
+    want = np.zeros((bh * 8, bw * 8), np.int32)
+    assert olib.fo_kat_inv_dct(planes.ctypes.data_as(C.c_void_p), bw, bh, maxval, want.ctypes.data_as(C.c_void_p))
+    z = _zigzag(olib)
+    dev = Dev(planes)
+    # src64[i] = the plane feeding position i of the 8x8 block = channel z[i] (dct.h:286)
+    ptrs = (C.c_void_p * 64)(*[dev.ptr + int(z[i]) * bh * bw * 4 for i in range(64)])
+    d_out = Dev(np.zeros((bh * 8, bw * 8), np.int32))
+    assert glib.fuifgpu_idct8x8(ptrs, bw, bh, d_out.ptr, maxval, None) == 0
+    assert np.array_equal(d_out.get().reshape(bh * 8, bw * 8), want)
+
+
+def test_idct_known_answer(glib, olib):
+    """Appendix E.6: block with b[0]=919 (DC incl. offset), b[1]=24, b[8]=-18, b[9]=7, b[18]=-5, b[63]=2 ->
+    row 0 = 117 116 116 114 112 109 106 105, row 7 = 119 120 120 120 118 117 115 114"""
+    maxval = 255
+    blk = np.zeros(64, np.int32)
+    blk[[1, 8, 9, 18, 63]] = [24, -18, 7, -5, 2]
+    blk[0] = 919 - (maxval + 1) * 4            # the entry point adds the DC offset (maxval+1)*4 itself (dct.h:281,285)
+    dev = Dev(blk)                             # 64 planes of one sample each, in block-position order
+    ptrs = (C.c_void_p * 64)(*[dev.ptr + i * 4 for i in range(64)])
+    d_out = Dev(np.zeros((8, 8), np.int32))
+    assert glib.fuifgpu_idct8x8(ptrs, 1, 1, d_out.ptr, maxval, None) == 0
+    got = d_out.get().reshape(8, 8)
+    assert got[0].tolist() == [117, 116, 116, 114, 112, 109, 106, 105]
+    assert got[7].tolist() == [119, 120, 120, 120, 118, 117, 115, 114]
+
+
+@pytest.mark.parametrize("w,h,srh,srv", [(1, 1, 2, 2), (5, 3, 2, 2), (64, 17, 2, 1), (33, 40, 1, 2), (240, 135, 2, 2)])
+def test_upsample_export(glib, olib, w, h, srh, srv):
+    rng = np.random.default_rng(w * 3 + h + srh)
+    src = rng.integers(-50, 300, (h, w), dtype=np.int32)
+    want = np.zeros((h * srv, w * srh), np.int32)
+    assert olib.fo_kat_upsample(src.ctypes.data_as(C.c_void_p), w, h, srh, srv, want.ctypes.data_as(C.c_void_p))
+    d_in, d_out = Dev(src), Dev(np.zeros((h * srv, w * srh), np.int32))
+    assert glib.fuifgpu_upsample(d_in.ptr, w, h, srh, srv, d_out.ptr, None) == 0
+    assert np.array_equal(d_out.get().reshape(h * srv, w * srh), want)

@@ -83,3 +83,29 @@ def test_bad_indices_are_refused(gpulib, port):
     assert gpulib.index_parse(good[:-1] + b"Y") == []
     bad_len = good[:-8] + (10 ** 6).to_bytes(4, "little") + b"FGIX"
     assert gpulib.index_parse(bad_len) == []
+
+
+def test_trailer_varints_cannot_wrap(gpulib, port):
+    """a channel or offset delta wider than 64 bits (ten 7-bit groups) must not wrap the running sums back into range"""
+    blob = load("rgb8_97x61.fuif")
+    g = port.decode(blob).groups
+    good = gpulib.index_append(blob, g[:3])
+    n = len(good)
+    plen = int.from_bytes(good[n - 8:n - 4], "little")
+    stream = good[: n - 8 - plen]
+
+    def trailer(entries):
+        def vi(v):
+            out = [v & 127]; v >>= 7
+            while v:
+                out.append(128 | (v & 127)); v >>= 7
+            return bytes(reversed(out))
+        payload = vi(1) + vi(len(entries)) + b"".join(vi(c) + vi(s) for c, s in entries)
+        return payload + len(payload).to_bytes(4, "little") + b"FGIX"
+
+    d0 = (g[0][0], g[0][1])
+    ok = stream + trailer([d0, (g[1][0] - g[0][0], g[1][1] - g[0][1])])
+    assert gpulib.index_parse(ok) == g[:2]
+    big = (1 << 64) + (g[1][1] - g[0][1])            # 2^64 + a valid delta: wraps to the valid delta in a uint64 sum
+    assert gpulib.index_parse(stream + trailer([d0, (g[1][0] - g[0][0], big)])) == []
+    assert gpulib.index_parse(stream + trailer([d0, ((1 << 64) + 1, g[1][1] - g[0][1])])) == []
