@@ -80,6 +80,7 @@ ABI_SYMBOLS = [
     "fuifgpu_inv_ycocg", "fuifgpu_inv_ycbcr", "fuifgpu_idct8x8", "fuifgpu_upsample", "fuifgpu_encode_image", "fuifgpu_encode_channels", "fuifgpu_free_blob",
     "fuifgpu_index_parse", "fuifgpu_index_append", "fuifgpu_batch_group_index", "fuifgpu_batch_set_group_parallel",
     "fuifgpu_plan_packed_bytes", "fuifgpu_batch_pack_out", "fuifgpu_batch_download_packed",
+    "fuifgpu_dev_alloc", "fuifgpu_dev_free", "fuifgpu_dev_upload", "fuifgpu_dev_download",
 ]
 
 

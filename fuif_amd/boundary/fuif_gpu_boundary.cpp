@@ -267,3 +267,115 @@ void fuifgpu_boundary_undo_transforms(Image *self, int keep) {
     self->transform.clear();
     registry().erase(self);
 }
+
+
+// =====================================================================================================
+// Transform::apply(image, inverse) -- transform/transform.cpp:48-63.  The reference's own definition is kept in the
+// link as Transform::apply_cpu (the Makefile compiles transform.cpp with -Dapply=apply_cpu, and this file too, so the
+// class declares it under that name here); the symbol Transform::apply is bound to the function below.  The INVERSE of
+// Squeeze, YCoCg and YCbCr runs on the MI355X through the single-transform entry points of the C-ABI: this is the path
+// of Image::undo_transforms(keep != 0) (fuif.cpp:220,230, image.cpp:94-115 calls t.apply(*this, true) per transform),
+// while a plain undo_transforms() replays the whole chain on the planes that are still resident (above).  Everything
+// else -- forward transforms, the other inverses, an image a kernel precondition does not hold for -- goes to apply_cpu.
+namespace {
+struct DevPlane {
+    int32_t *d = nullptr;
+    size_t n = 0;
+    ~DevPlane() { fuifgpu_dev_free(d); }
+    bool put(const Channel &ch) {   // pixel_type -> int32, H2D
+        n = (size_t)ch.w * ch.h;
+        if (ch.data.size() < n) return false;
+        std::vector<int32_t> wide(n);
+        for (size_t i = 0; i < n; i++) wide[i] = ch.data[i];
+        d = (int32_t *)fuifgpu_dev_alloc(n * 4);
+        return d && fuifgpu_dev_upload(d, wide.data(), n * 4) == FUIFGPU_OK;
+    }
+    bool alloc(size_t count) { n = count; d = (int32_t *)fuifgpu_dev_alloc(n * 4); return d != nullptr; }
+    bool get(Channel &ch) const {   // D2H, int32 -> pixel_type
+        std::vector<int32_t> wide(n);
+        if (fuifgpu_dev_download(wide.data(), d, n * 4) != FUIFGPU_OK) return false;
+        ch.data.resize(n);
+        for (size_t i = 0; i < n; i++) ch.data[i] = (pixel_type)wide[i];
+        return true;
+    }
+};
+
+// transform/ycocg.h:33-63 / transform/ycbcr.h:33-63 (same preconditions, checked by the caller's CPU twin otherwise)
+bool gpu_inv_color(Image &img, bool ycbcr) {
+    const int m = ycbcr ? 0 : img.nb_meta_channels;
+    if ((int)img.channel.size() < m + 3 || (!ycbcr && img.nb_channels < 3)) return false;
+    Channel &c0 = img.channel[m], &c1 = img.channel[m + 1], &c2 = img.channel[m + 2];
+    const int w = c0.w, h = c0.h;
+    if (w < 1 || h < 1 || c1.w < w || c1.h < h || c2.w < w || c2.h < h) return false;
+    DevPlane p0, p1, p2;
+    if (!p0.put(c0) || !p1.put(c1) || !p2.put(c2)) return false;
+    const int rc = ycbcr ? fuifgpu_inv_ycbcr(p0.d, p1.d, p2.d, w, h, c0.w, c1.w, c2.w, img.minval, img.maxval, nullptr)
+                         : fuifgpu_inv_ycocg(p0.d, p1.d, p2.d, w, h, c0.w, c1.w, c2.w, img.maxval, nullptr);
+    return rc == FUIFGPU_OK && p0.get(c0) && p1.get(c1) && p2.get(c2);
+}
+
+// transform/squeeze.h:363-388, inverse branch, with explicit parameters (after a decode they always are: meta_apply
+// expands the defaults in place, squeeze.h:323-326)
+bool gpu_inv_squeeze(Image &img, const std::vector<int> &par) {
+    if (par.empty() || par.size() % 3) return false;
+    // dry run of the channel bookkeeping: every step must be one the kernels take (sizes as forward squeeze leaves them)
+    {
+        std::vector<std::pair<int, int>> dims;
+        for (const Channel &c : img.channel) dims.emplace_back(c.w, c.h);
+        for (int i = (int)par.size() - 3; i >= 0; i -= 3) {
+            const bool horizontal = par[i] & 1, in_place = !(par[i] & 2);
+            const int beginc = par[i + 1], endc = par[i + 2];
+            const int offset = in_place ? endc + 1 : img.nb_meta_channels + img.nb_channels;
+            if (beginc < 0 || endc < beginc || offset + (endc - beginc) >= (int)dims.size()) return false;
+            for (int c = beginc; c <= endc; c++) {
+                const auto a = dims[c], r = dims[offset + c - beginc];
+                if (a.first < 1 || a.second < 1) return false;
+                if (horizontal) { if (r.second != a.second || a.first - r.first < 0 || a.first - r.first > 1) return false; dims[c].first += r.first; }
+                else { if (r.first != a.first || a.second - r.second < 0 || a.second - r.second > 1) return false; dims[c].second += r.second; }
+            }
+            dims.erase(dims.begin() + offset, dims.begin() + offset + (endc - beginc + 1));
+        }
+    }
+    for (int i = (int)par.size() - 3; i >= 0; i -= 3) {
+        const bool horizontal = par[i] & 1, in_place = !(par[i] & 2);
+        const int beginc = par[i + 1], endc = par[i + 2];
+        const int offset = in_place ? endc + 1 : img.nb_meta_channels + img.nb_channels;
+        for (int c = beginc; c <= endc; c++) {
+            Channel &chin = img.channel[c];
+            Channel &res = img.channel[offset + c - beginc];
+            if (res.data.size() == 0) res.resize();   // zero-filled residuals of a partial decode (squeeze.h:379-383)
+            DevPlane a, r, o;
+            if (!a.put(chin) || (res.w * res.h > 0 && !r.put(res))) return false;
+            int rc;
+            Channel out = horizontal ? Channel(chin.w + res.w, chin.h, chin.minval, chin.maxval, chin.q, chin.hshift - 1, chin.vshift, chin.hcshift - 1, chin.vcshift)
+                                     : Channel(chin.w, chin.h + res.h, chin.minval, chin.maxval, chin.q, chin.hshift, chin.vshift - 1, chin.hcshift, chin.vcshift - 1);
+            out.component = chin.component;
+            if (!o.alloc((size_t)out.w * out.h)) return false;
+            if (horizontal) rc = fuifgpu_inv_hsqueeze(a.d, chin.w, r.d, res.w, chin.h, o.d, 1, 0, 0, 0, nullptr);
+            else rc = fuifgpu_inv_vsqueeze(a.d, chin.h, r.d, res.h, chin.w, o.d, 1, 0, 0, 0, nullptr);
+            if (rc != FUIFGPU_OK || !o.get(out)) return false;
+            img.channel[c] = out;
+        }
+        img.channel.erase(img.channel.begin() + offset, img.channel.begin() + offset + (endc - beginc + 1));
+    }
+    return true;
+}
+}  // namespace
+
+bool fuifgpu_boundary_transform_apply(Transform *self, Image &input, bool inverse) __asm__("_ZN9Transform5applyER5Imageb");
+bool fuifgpu_boundary_transform_apply(Transform *self, Image &input, bool inverse) {
+    if (inverse && !env_flag("FUIFGPU_CPU_TRANSFORMS")) {
+        bool done = false;
+        switch (self->ID) {
+            case TRANSFORM_YCoCg: done = gpu_inv_color(input, false); break;
+            case TRANSFORM_YCbCr: done = gpu_inv_color(input, true); break;
+            case TRANSFORM_SQUEEZE: done = gpu_inv_squeeze(input, self->parameters); break;
+            default: break;
+        }
+        if (done) {
+            if (env_flag("FUIFGPU_VERBOSE")) fprintf(stderr, "fuifgpu: inverse %s on the GPU (Transform::apply)\n", self->name());
+            return true;
+        }
+    }
+    return self->apply(input, inverse);   // macro-renamed: Transform::apply_cpu, the reference's own dispatcher
+}

@@ -626,6 +626,24 @@ int fuifgpu_batch_sched_stats(fuifgpu_batch *b, uint64_t *out8) {
     return FUIFGPU_OK;
 }
 
+// ---- device memory for callers that are not HIP programs themselves (the C++ boundary layer is compiled with g++) ---
+void *fuifgpu_dev_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { g_last_error = "hipMalloc failed (no HIP device or out of memory): libfuifgpu has no CPU fallback"; return nullptr; }
+    return p;
+}
+void fuifgpu_dev_free(void *p) { if (p) hipFree(p); }
+int fuifgpu_dev_upload(void *dst_device, const void *src_host, size_t bytes) {
+    if ((!dst_device || !src_host) && bytes) return FUIFGPU_E_ARG;
+    if (bytes) HIPCHK(hipMemcpy(dst_device, src_host, bytes, hipMemcpyHostToDevice));
+    return FUIFGPU_OK;
+}
+int fuifgpu_dev_download(void *dst_host, const void *src_device, size_t bytes) {
+    if ((!dst_host || !src_device) && bytes) return FUIFGPU_E_ARG;
+    if (bytes) HIPCHK(hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost));   // synchronises with the null stream's kernels
+    return FUIFGPU_OK;
+}
+
 // ---- single-transform entry points -----------------------------------------------------------
 static Op raw_op(int kind) {
     Op op{};

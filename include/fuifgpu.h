@@ -158,9 +158,16 @@ int fuifgpu_batch_group_index(fuifgpu_batch *batch, int image, int32_t *first_ch
 /* enable = 0: ignore trailers from the next upload on (A/B measurements; default 1) */
 int fuifgpu_batch_set_group_parallel(fuifgpu_batch *batch, int enable);
 
+/* ---- device memory for hosts that are not HIP programs (the boundary layer is plain g++ code) ------------- */
+void *fuifgpu_dev_alloc(size_t bytes);                       /* NULL on failure (fuifgpu_last_error) */
+void fuifgpu_dev_free(void *device_ptr);
+int fuifgpu_dev_upload(void *dst_device, const void *src_host, size_t bytes);
+int fuifgpu_dev_download(void *dst_host, const void *src_device, size_t bytes);   /* waits for the null stream */
+
 /* ---- single-transform entry points on raw device planes (row-major int32) ------------------
- * These are what Transform::apply(image, true) (transform/transform.cpp:48-63) dispatches to;
- * the C++ boundary layer (fuif_amd/csrc/boundary) and the unit parity tests call them. */
+ * These are what Transform::apply(image, true) (transform/transform.cpp:48-63) dispatches to in the C++ boundary
+ * layer (fuif_amd/boundary/fuif_gpu_boundary.cpp binds Transform::apply for Squeeze, YCoCg and YCbCr inverses to them:
+ * the path of Image::undo_transforms(keep != 0)); tests/test_gpu_transform_exports.py checks each against the oracle. */
 /* transform/squeeze.h:81-132 inv_hsqueeze: avg w1 x h + residual w2 x h -> out (w1+w2) x h */
 int fuifgpu_inv_hsqueeze(const int32_t *avg, int w1, const int32_t *res, int w2, int h, int32_t *out, int n_planes,
                          int64_t avg_stride, int64_t res_stride, int64_t out_stride, void *stream);

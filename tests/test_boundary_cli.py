@@ -100,3 +100,24 @@ def test_reference_cli_decodes_an_animation_through_gpu(ref, tmp_path):
         rb = subprocess.run([ref_cli, "-d", src, b], env=env, capture_output=True, text=True, timeout=300)
         assert rb.returncode == 0, rb.stderr
         assert open(a, "rb").read() == open(b, "rb").read(), name
+
+
+@pytest.mark.gpu
+def test_reference_cli_yuv_output_uses_the_per_transform_binding(tmp_path):
+    """`fuif -d x.fuif out.yuv` = Image::undo_transforms(2): Transform::apply(image, true) transform by transform; the
+    Squeeze inverse must come from the GPU entry points and the file must equal the unmodified reference CLI's"""
+    need_cli()
+    ref_cli = os.path.join(ROOT, "oracle", "_ref", "fuif")
+    if not os.path.exists(ref_cli):
+        pytest.skip("oracle/_ref/fuif not built")
+    env = dict(os.environ)
+    if os.path.exists("/opt/conda/lib/libjpeg.so.9"):
+        env["LD_PRELOAD"] = "/opt/conda/lib/libjpeg.so.9"
+    src = os.path.join(GOLDEN, "jpeg420_256x192_q90.fuif")
+    a, b = str(tmp_path / "gpu.yuv"), str(tmp_path / "ref.yuv")
+    r = run_cli(["-d", src, a])
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "inverse Squeeze on the GPU (Transform::apply)" in r.stderr
+    rb = subprocess.run([ref_cli, "-d", src, b], env=env, capture_output=True, text=True, timeout=300)
+    assert rb.returncode == 0
+    assert open(a, "rb").read() == open(b, "rb").read()
