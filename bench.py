@@ -175,6 +175,98 @@ def pmc_traffic(batch, mode):
     return None if best is None else int(best["traffic_bytes_per_launch"])
 
 
+def run_streamed(args, wl, inputs, blobs, dev, dist, rank, world, W, H, C, BITS, K, t_gen):
+    """--chunk: the batch goes through one chunk-sized Batch (coefficient, output, tmp slabs for `chunk` images), chunk after
+    chunk; a step = one pass over the WHOLE batch.  Upload of a chunk = K distinct streams over PCIe + device-side replicas,
+    inside the timed region (it is part of running a batch that does not fit).  Every image of the first pass is compared
+    with the generator's pixels (lossless workloads)."""
+    import torch
+    import fuif_amd
+    from fuif_amd import dist as fd
+    from fuif_amd.synth import photographic
+    chunk = args.chunk
+    plan = fuif_amd.Plan(blobs[0])
+    info = plan.info
+    out = torch.empty(chunk * info.out_elems, dtype=torch.int32, device=dev)
+    cap = max(sum(len(b) for b in blobs[c0:c0 + chunk]) for c0 in range(0, args.batch, chunk))
+    batch = fuif_amd.Batch(plan, chunk, cap, out_ptr=out.data_ptr())
+    batch.set_group_parallel(not args.no_index)
+    outs = plan.output_channels
+    srcs = None
+    if wl["lossless"]:
+        srcs = [torch.from_numpy(photographic(W, H, C, BITS, seed=inputs[k][0])).to(dev) for k in range(K)]
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_pass(check):
+        ok, dec, tr, tiles = True, 0.0, 0.0, 0
+        for c0 in range(0, args.batch, chunk):
+            sub = blobs[c0:c0 + chunk]
+            batch.upload(sub)
+            batch.decode()
+            batch.undo_transforms()
+            batch.sync()
+            d, t = batch.timing()
+            dec += d; tr += t
+            if check:
+                st, _ = batch.status()
+                ok = ok and not st.any()
+                view = out.view(chunk, info.out_elems)
+                if srcs is not None:
+                    for i in range(len(sub)):
+                        for c, oc in enumerate(outs):
+                            got = view[i, oc["offset"]: oc["offset"] + oc["w"] * oc["h"]].view(oc["h"], oc["w"])
+                            ok = ok and bool(torch.equal(got, srcs[(c0 + i) % K][c]))
+        return ok, dec, tr
+
+    ok = True
+    checked = False
+    for _ in range(args.warmup):
+        o, _, _ = one_pass(not checked)
+        ok, checked = ok and o, True
+    fence()
+    dec_ms, tr_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, d, t = one_pass(False)
+        dec_ms.append(d); tr_ms.append(t)
+    fence()
+    elapsed = fd.max_over_ranks(time.perf_counter() - t0, dist, dev)
+    if not checked:
+        o, _, _ = one_pass(True)
+        ok = ok and o
+    ok = fd.all_ok(ok, dist, dev)
+    if rank == 0:
+        S = sum(len(b) for b in blobs) / args.batch
+        alg = args.batch * (S + 4.0 * info.coef_elems)
+        d_avg = float(np.mean(dec_ms)) / 1e3
+        value = world * args.batch * W * H * args.steps / 1e6 / elapsed
+        res = {"metric": "Mpixels/s decode (%s)" % args.workload, "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "int32", "data": "synthetic",
+               "config": {"workload": wl["desc"] % (args.batch, W, H), "images_per_gpu": args.batch, "chunk": chunk, "distinct_images": K,
+                          "bytes_per_stream": int(S), "channels": C, "bits": BITS, "parity_roundtrip_ok": ok,
+                          "parity_check": "decoded == source pixels for every image of one full pass" if wl["lossless"] else "status only",
+                          "streaming": "one chunk-sized set of slabs, %d chunks per step, uploads inside the timed region" % (-(-args.batch // chunk)),
+                          "input_gen_s": round(t_gen, 1)},
+               "roofline": {"bound": "hbm", "kernel": "k_maniac_decode", "achieved": round(alg / d_avg / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(alg / d_avg / 1e9 / HBM_PEAK_GBS, 6), "traffic": None, "kernel_ms": round(d_avg * 1e3, 3),
+                            "algorithmic_bytes_per_launch": int(alg), "note": "kernel_ms / bytes are per step = the sum over the step's chunk launches",
+                            "transforms_ms": round(float(np.mean(tr_ms)), 3)}}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline([b for _, b in inputs], W, H)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("PARITY FAILURE: decoded planes differ from the source pixels")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,6 +283,9 @@ def main():
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive measurement (one upload of the whole batch from distinct host buffers)")
     ap.add_argument("--no-index", action="store_true", help="ignore the streams' group index: one wavefront per image for the timed steps")
     ap.add_argument("--no-seq-compare", action="store_true", help="skip the extra one-wavefront-per-image step reported next to the headline")
+    ap.add_argument("--chunk", type=int, default=0,
+                    help="images resident at a time (0 = the whole batch): the batch is streamed through ONE chunk-sized set of coefficient / "
+                         "output slabs, chunk after chunk -- how C4 (256 x 8192x8192x4: 275 GB of coefficients alone) runs on one GPU")
     ap.add_argument("--cache", default=os.environ.get("FUIF_BENCH_CACHE", "/tmp/fuif_bench_cache"))
     args = ap.parse_args()
 
@@ -226,6 +321,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = fd.init(device=dev)
+
+    if args.chunk and args.chunk < args.batch:
+        return run_streamed(args, wl, inputs, blobs, dev, dist, rank, world, W, H, C, BITS, K, t_gen)
 
     plan = fuif_amd.Plan(blobs[0])
     info = plan.info

@@ -83,3 +83,37 @@ def test_jpeg_like_dct_path_matches_oracle(gpulib, port, w, h, c, sub):
         assert len(planes) == len(d_post.channels)
         for g, e in zip(planes, d_post.channels):
             assert np.array_equal(g, e["data"])
+
+
+def test_c4_full_size_image_matches_oracle(gpulib, port):
+    """BASELINE config C4 at its real geometry: ONE 8192x8192, 4-channel, 14-bit, Squeeze-only lossless stream (268 M
+    symbols, 2.1 GB of planes) through the C-ABI with the group index, every coded plane and every output plane against the
+    CPU oracle.  Takes minutes (the oracle alone ~2) and ~12 GB of host memory, so it only runs when FUIF_TEST_C4_FULL=1;
+    profiles/r2_c4_full_size.txt records the round-2 run.  The same shape at 1024x768 is part of the routine suite above."""
+    import os
+    if not os.environ.get("FUIF_TEST_C4_FULL"):
+        pytest.skip("set FUIF_TEST_C4_FULL=1 (minutes of CPU for the writer and the oracle)")
+    w = h = 8192
+    img = photographic(w, h, 4, 14, seed=8192)
+    blob = gpulib.encode_image(img, 14, ycocg=False, tree_mode=1, index=True)
+    plan = gpulib.Plan(blob)
+    batch = gpulib.Batch(plan, 1, len(blob))
+    try:
+        batch.upload([blob])
+        batch.decode()
+        batch.sync()
+        st, used = batch.status()
+        assert st[0] == 0
+        pre = batch.coef_planes(0)
+        batch.undo_transforms()
+        batch.sync()
+        post = batch.out_planes(0)
+    finally:
+        batch.close()
+    d_pre, d_post = port.decode_both(blob)
+    for g, e in zip(pre, d_pre.channels):
+        assert np.array_equal(g, e["data"])
+    for g, e in zip(post, d_post.channels):
+        assert np.array_equal(g, e["data"])
+    for k in range(4):
+        assert np.array_equal(post[k], img[k])
