@@ -125,11 +125,12 @@ def host_description():
     return {"model": model, "hardware_threads": threads or (os.cpu_count() or 1), "physical_cores": len(cores) or None}
 
 
-def cpu_baseline_all_cores(paths, w, h, seconds=12.0):
+def cpu_baseline_all_cores(paths, w, h, seconds=6.0):
     """the same reference decoder on every host core at once, one process per image; separate
     processes started with subprocess (this process already holds HIP / RCCL state: no fork)"""
     import subprocess
-    cores = os.cpu_count() or 1
+    host = host_description()
+    cores = host["physical_cores"] or os.cpu_count() or 1     # one process per physical core (SMT siblings only add contention here)
     worker = os.path.join(ROOT, "oracle", "cpu_worker.py")
     start_at = time.time() + 6.0 + cores * 0.01          # let every worker load before the clock starts
     procs = [subprocess.Popen([sys.executable, worker, str(seconds), str(start_at), str(i)] + paths, stdout=subprocess.PIPE, text=True)
@@ -156,7 +157,8 @@ def cpu_baseline_all_cores(paths, w, h, seconds=12.0):
         return None
     from oracle_py import Ref
     return {"value": round(images * w * h / 1e6 / wall, 2), "unit": "Mpixels/s", "cores": cores, "kind": "reference" if Ref.available() else "port",
-            "sample": "%d full decodes of the bench's %dx%d streams by %d concurrent processes in %.1f s" % (images, w, h, cores, wall)}
+            "sample": "%d full decodes of the bench's %dx%d streams by %d concurrent processes (one per physical core) in %.1f s" % (images, w, h, cores, wall),
+            "host": host}
 
 
 def pmc_traffic(batch, mode):
@@ -173,6 +175,135 @@ def pmc_traffic(batch, mode):
         if d.get("kernel") == "k_maniac_decode" and d.get("batch") == batch and d.get("mode", "images") == mode:
             best = d
     return None if best is None else int(best["traffic_bytes_per_launch"])
+
+
+def run_c5(args):
+    """--workload c5 = BASELINE config 5: `--batch` (default 8192) mixed images, 1920x1080 8-bit RGB, alternately YCoCg+Squeeze
+    lossless and JPEG-transcode-like (YCbCr + 4:2:0 + DCT + Quantize), sharded over the ranks (STRONG scaling: the total is
+    fixed, rank r takes fuif_amd.dist.shard_range).  A rank groups its streams by plan signature (two groups), runs each group
+    through its own Batch in chunks of at most --chunk images (default 1024), and packs every decoded picture on the GPU into
+    one device buffer of interleaved 8-bit samples (k_pack_samples).  A step = decode + inverse transforms + packing of the
+    rank's whole shard.  After the timed steps the packed pictures are gathered on rank 0 over RCCL in chunks
+    (dist.gather_packed); the gather is timed separately."""
+    import torch
+    import fuif_amd
+    from fuif_amd import dist as fd
+    from fuif_amd.synth import photographic
+    W, H = (args.width, args.height) if (args.width, args.height) != (3840, 2160) else (1920, 1080)
+    total = args.batch if args.batch != 1024 else 8192
+    K = max(1, args.distinct // 2)
+    rank = int(os.environ.get("RANK", "0"))
+    t0 = time.time()
+    sq = make_inputs(K, W, H, 3, 8, 3000, args.cache, "squeeze")      # the same K distinct images of each kind on every rank
+    dc = make_inputs(K, W, H, 3, 8, 4000, args.cache, "dct420")
+    t_gen = time.time() - t0
+    rank, local_rank, world = fd.env_world()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the FUIF decode path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = fd.init(device=dev)
+    lo, hi = fd.shard_range(total, rank, world)
+    mine = list(range(lo, hi))
+    kinds = {"squeeze": [g for g in mine if g % 2 == 0], "dct420": [g for g in mine if g % 2 == 1]}
+    src = {"squeeze": sq, "dct420": dc}
+    chunk = args.chunk or 1024
+    groups = {}
+    for kind, idx in kinds.items():
+        if not idx:
+            continue
+        blobs = [src[kind][(g // 2) % K][1] for g in idx]
+        plan = fuif_amd.Plan(blobs[0])
+        n = min(chunk, len(idx))
+        batch = fuif_amd.Batch(plan, n, max(sum(len(b) for b in blobs[c0:c0 + n]) for c0 in range(0, len(idx), n)))
+        batch.set_group_parallel(not args.no_index)
+        groups[kind] = dict(idx=idx, blobs=blobs, plan=plan, batch=batch, n=n, pb=batch.packed_bytes())
+    pb = next(iter(groups.values()))["pb"]
+    assert all(g["pb"] == pb for g in groups.values())
+    packed = torch.empty(len(mine) * pb, dtype=torch.uint8, device=dev)
+    slot = {g: i for i, g in enumerate(mine)}     # picture of global image g sits at slot[g] * pb
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        dec = tr = 0.0
+        ok = True
+        for kind, g in groups.items():
+            for c0 in range(0, len(g["idx"]), g["n"]):
+                sub = g["blobs"][c0:c0 + g["n"]]
+                g["batch"].upload(sub)
+                g["batch"].decode()
+                g["batch"].undo_transforms()
+                # consecutive images of one kind are 2 apart in the global numbering: pack one by one into their slots
+                for i in range(len(sub)):
+                    g["batch"].pack_out(packed.data_ptr() + slot[g["idx"][c0 + i]] * pb, i, 1)
+                g["batch"].sync()
+                d, t = g["batch"].timing()
+                dec += d; tr += t
+                st, _ = g["batch"].status()
+                ok = ok and not st.any()
+        return ok, dec, tr
+
+    ok = True
+    for _ in range(args.warmup):
+        o, _, _ = step()
+        ok = ok and o
+    fence()
+    dec_ms, tr_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        o, d, t = step()
+        ok = ok and o
+        dec_ms.append(d); tr_ms.append(t)
+    fence()
+    elapsed = fd.max_over_ranks(time.perf_counter() - t0, dist, dev)
+    # parity at size: the lossless half must be the generator's pixels; replicas of one source must be identical pictures
+    pics = packed.view(len(mine), H, W, 3)
+    for k in range(K):
+        ref_px = torch.from_numpy(np.moveaxis(photographic(W, H, 3, 8, seed=sq[k][0]), 0, -1).astype(np.uint8)).to(dev)
+        for g in kinds["squeeze"]:
+            if (g // 2) % K == k:
+                ok = ok and bool(torch.equal(pics[slot[g]], ref_px))
+        first = None
+        for g in kinds["dct420"]:
+            if (g // 2) % K == k:
+                if first is None:
+                    first = pics[slot[g]]
+                else:
+                    ok = ok and bool(torch.equal(pics[slot[g]], first))
+    # final gather: every rank's packed pictures to rank 0, chunked, byte sums checked
+    mine_sum = torch.sum(packed, dtype=torch.int64).reshape(1)
+    fence(); t0 = time.perf_counter()
+    got = fd.gather_packed(packed, dist, root=0, keep=False)
+    fence(); t_gather = time.perf_counter() - t0
+    if dist is not None:
+        every = [torch.zeros_like(mine_sum) for _ in range(world)]
+        dist.all_gather(every, mine_sum)
+        if rank == 0:
+            ok = ok and got == [int(e.item()) for e in every]
+    ok = fd.all_ok(ok, dist, dev)
+    if rank == 0:
+        value = total * W * H * args.steps / 1e6 / elapsed
+        moved = (total - len(mine)) * pb
+        res = {"metric": "Mpixels/s decode (c5: mixed Squeeze/DCT 1920x1080)", "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+               "config": {"workload": "C5: batch of %d %dx%d mixed Squeeze/DCT images sharded across %d GPU(s)" % (total, W, H, world),
+                          "images_total": total, "images_this_rank": len(mine), "chunk": chunk, "distinct_images_per_kind": K,
+                          "parity_roundtrip_ok": ok, "parity_check": "lossless half == source pixels; DCT replicas identical; status 0; gathered byte sums",
+                          "entropy_kernel_ms": round(float(np.mean(dec_ms)), 3), "transform_ms": round(float(np.mean(tr_ms)), 3), "input_gen_s": round(t_gen, 1)},
+               "final_gather": {"payload": "packed 8-bit RGB pictures, %d bytes each" % pb, "bytes_into_root": int(moved),
+                                "gather_ms": round(t_gather * 1e3, 3), "gather_GBps": round(moved / max(t_gather, 1e-9) / 1e9, 1) if world > 1 else None}}
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("PARITY FAILURE (c5)")
 
 
 def run_streamed(args, wl, inputs, blobs, dev, dist, rank, world, W, H, C, BITS, K, t_gen):
@@ -276,7 +407,8 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--distinct", type=int, default=16, help="K distinct images replicated to the batch (SURVEY.md §8(d): 16)")
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2", help="c2 = BASELINE headline config (default)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["c5"], default="c2",
+                    help="c2 = BASELINE headline config (default); c5 = 8192 mixed 1920x1080 images sharded over the ranks (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-all-cores", action="store_true",
                     help="skip the all-host-cores leg of the CPU baseline (one reference process per hardware thread, ~30 s)")
@@ -291,6 +423,9 @@ def main():
 
     import fuif_amd
     rank = int(os.environ.get("RANK", "0"))
+    if args.workload == "c5":
+        fuif_amd.lib()
+        return run_c5(args)
     # the HIP library is built by __graft_entry__.build() and travels in-tree; only a missing library is
     # built here, by local rank 0 alone (N ranks must not run hipcc on the same output file)
     lib_path = os.path.join(ROOT, "fuif_amd", "libfuifgpu.so")
@@ -478,8 +613,10 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(args.batch, "images" if args.no_index else "groups") if args.workload == "c2" else None,
                     "kernel_ms": round(d_avg * 1e3, 3), "algorithmic_bytes_per_launch": int(alg_kernel),
                     "tiles_per_launch": n_tiles,
-                    "note": "serial range decoders, one wavefront per channel group (4 per SIMD): bound by instruction issue on the "
-                            "per-symbol dependency chain and by the length of the largest group, not by HBM (DESIGN.md 4.1)",
+                    "note": "serial range decoders, one wavefront per channel group, 6 per SIMD, suspended while they wait for other groups' rows: "
+                            "bound by the latency of three dependent memory round trips per symbol (supernode, leaf, transition table) and by "
+                            "instruction issue, not by HBM bandwidth (DESIGN.md 4.1, profiles/r2_sq_counters_*); traffic = PMC bytes of the "
+                            "committed profile of this configuration (profiles/r*_pmc_traffic.json), calibrated on the kernel's access pattern",
                     "transforms": {"ms": round(t_avg * 1e3, 3), "achieved": round(args.batch * 4.0 * (N + P) / t_avg / 1e9, 1),
                                    "unit": "GB/s", "algorithmic_bytes": int(args.batch * 4.0 * (N + P))},
                     "path_bytes_per_image": int(S + 8.0 * N + 4.0 * P)}

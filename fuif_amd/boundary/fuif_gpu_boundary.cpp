@@ -13,8 +13,9 @@
 // fuif_decode_file_cpu / fuif_decode_cpu / Image::undo_transforms_cpu (the Makefile compiles
 // encoding.cpp and image.cpp with -Dname=name_cpu) and are used for what is outside the GPU
 // scope: -i/--identify (header only), undo_transforms(keep != 0), and the streams the library
-// reports as FUIFGPU_E_UNSUPPORTED / FUIFGPU_ST_UNSUPPORTED (Permute; soft 2D matches).  Stills and
-// animations (FUAF), Squeeze / YCoCg / YCbCr / DCT / Quantize / Subsample / Palette / Approximate / 2D-match
+// reports as FUIFGPU_E_UNSUPPORTED / FUIFGPU_ST_UNSUPPORTED (a data-driven Permute over channels of different geometry; soft 2D
+// matches).  Stills and
+// animations (FUAF), Squeeze / YCoCg / YCbCr / DCT / Quantize / Subsample / Palette / Approximate / 2D-match / Permute
 // chains all decode on the GPU.  With FUIFGPU_NO_CPU_FALLBACK=1 in the environment nothing is ever
 // routed to the reference's CPU decoder: an unsupported stream is an error (tests/test_boundary_cli.py
 // runs that way, so a planner regression cannot hide behind the fallback); FUIFGPU_VERBOSE=1 reports

@@ -304,6 +304,19 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
     for (auto &g : groups) deepest = std::max(deepest, g.size());
     b->dense = (int64_t)total_tiles > b->max_waves[0] ? 1 : 0;
     b->n_waves = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)total_tiles, b->max_waves[b->dense]));
+    // an image whose every tile holds exactly one non-empty channel (one single-channel group per tile) may have its tiles suspended
+    std::vector<char> suspendable(groups.size(), 0);
+    for (size_t gi = 0; gi < groups.size(); gi++) {
+        const std::vector<GroupEntry> &g = groups[gi];
+        bool ok = g.size() > 1;
+        for (size_t k = 0; k < g.size() && ok; k++) {
+            const int first = k == 0 ? 0 : g[k].first_channel, last = k + 1 < g.size() ? g[k + 1].first_channel - 1 : nch - 1;
+            int nonempty = 0;
+            for (int c = first; c <= last; c++) nonempty += (int64_t)b->plan.coded[c].w * b->plan.coded[c].h > 0 ? 1 : 0;
+            ok = nonempty <= 1;
+        }
+        suspendable[gi] = ok ? 1 : 0;
+    }
     auto push_tile = [&](int i, size_t k) {
         const std::vector<GroupEntry> &g = groups[group_of[i]];
         if (k >= g.size()) return;
@@ -313,6 +326,7 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
         t.first_channel = k == 0 ? 0 : g[k].first_channel;
         t.last_channel = k + 1 < g.size() ? g[k + 1].first_channel - 1 : nch - 1;
         t.end = k + 1 < g.size() ? g[k + 1].start : 0u;
+        t.flags = suspendable[group_of[i]] ? kTileSuspendable : 0u;
         b->tiles.push_back(t);
     };
     // Dense launches with more tiles than wavefronts use the context scheduler (maniac_decode.h, sched == 1): tiles image by

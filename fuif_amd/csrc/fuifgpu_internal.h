@@ -66,7 +66,12 @@ struct Tile {
     int32_t first_channel, last_channel;  // coded channels [first,last] are decoded (or zero-filled) by this tile
     uint32_t end;                         // where the index says the NEXT tile starts (0 = last tile / unknown): a tile that is
                                           // decoded in full must stop exactly there, else the index does not belong to the stream
+    uint32_t flags;                       // bit 0: every tile of this image is one single-channel group, so every tile that can wait for
+                                          // another tile's rows can be SUSPENDED (context scheduler).  Otherwise none of the image's
+                                          // tiles is: a suspended tile needs a free wavefront to go on, and tiles that wait by
+                                          // spinning could hold all of them (round 1's invariant -- a taken tile runs -- per image)
 };
+constexpr uint32_t kTileSuspendable = 1u;
 
 // --- inverse-transform schedule ---------------------------------------------------------------
 enum : int { BUF_COEF = 0, BUF_OUT = 1, BUF_TMP = 2 };
@@ -85,7 +90,8 @@ enum : int {
     // 2D match with free offsets (2dmatch.h:136-146), exact matches only: source map by pointer jumping
     OP_MATCH_INIT = 13,   // dst[0] = linear index every sample copies from (itself / -1 = before the first sample); src[0] match plane, p0 softmatch
     OP_MATCH_JUMP = 14,   // dst[0][p] = src[0][src[0][p]]: one doubling step; src[1] match plane (mode check)
-    OP_MATCH_APPLY = 15   // listed planes[p] = planes[src[0][p]] in place; src[1] match plane (mode check)
+    OP_MATCH_APPLY = 15,  // listed planes[p] = planes[src[0][p]] in place; src[1] match plane (mode check)
+    OP_PERMUTE = 16       // dst[0] = listed plane number perm[p0], perm = the samples of the 1-row meta plane src[0] (p1 = its length): transform/permute.h:31-54
 };
 struct Op {
     int32_t kind;

@@ -1128,11 +1128,12 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         // are the ones that stay in LDS.
         const int nleaves = (tree_size + 1) / 2;
         n_super = 1;
-        // A group that may be suspended: the tile's single, last, one-channel group, with references to wait for and a
-        // tree the context areas are sized for.  Its supernodes and leaves are built in a context area of its image's
-        // queue; without a free one the tile simply runs to completion on this wavefront like every other tile.
+        // A group that may be suspended: a tile of an image ALL of whose tiles are single one-channel groups (Tile::flags),
+        // with references to wait for.  Its supernodes and leaves are built in a context area of its image's queue.
+        // (Without a free area -- the arenas are sized generously -- the tile runs to completion on this wavefront and
+        // spins when it has to wait, like the tiles of images that are not suspendable at all.)
         int max_super_here = P.max_super;
-        if (sched && kHandOff && beginc == endc && endc == last_c && nrefs > 0 && tree_size > 1) {
+        if (sched && kHandOff && (rflu(tile.flags) & kTileSuspendable) && beginc == endc && endc == last_c && nrefs > 0) {
             // (7n+5)/12 supernodes are enough for n inner nodes (capi.hip), so nothing falls to the node-by-node walk
             const uint32_t inner = (uint32_t)(tree_size - 1) / 2u;
             const uint32_t sn_cap = (7u * inner + 5u) / 12u + 1u;

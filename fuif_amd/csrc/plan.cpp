@@ -159,6 +159,8 @@ struct Builder {
     std::vector<PlaneInfo> planes;
     std::vector<ProtoOp> ops;
     int nb_meta = 0;  // Image::nb_meta_channels (palettes live in front of the channel list)
+    bool permute_is_last = false;   // the transform list ends with a parameter-less Permute (encoding.cpp:712)
+    std::vector<int> permute_labels;   // component labels of the channels a parameter-less Permute covers, in natural order
     int nbc = 0;      // Image::nb_channels: shrinks/grows with Palette (palette.h:88,66)
 
     explicit Builder(Plan &p) : plan(p), nbc(p.nb_channels) {}
@@ -303,6 +305,38 @@ struct Builder {
         LiveChannel mch{};
         mch.plane = -1; mch.w = live[begin_c].w; mch.h = live[begin_c].h; mch.component = -1; mch.ctor_data = true;
         live.insert(live.begin(), mch);
+        return true;
+    }
+
+    // transform/permute.h:56-84.  With parameters the permutation is static: only the channel table moves.  Without, it is
+    // the content of a 1-row meta-channel in front of the list -- stream DATA, while this planner is geometry only; so the
+    // permuted channels must all have the same geometry (then neither the decode-time inv_permute_meta of
+    // encoding.cpp:576-596,712 nor the inverse changes the channel table, and the inverse is a per-image plane gather).
+    bool meta_permute(const std::vector<int> &params) {
+        const int nb = (int)live.size() - nb_meta;
+        if (params.empty()) {
+            if (nb < 1) return fail(FUIFGPU_E_CORRUPT, "Permute on an image without channels");
+            for (int i = 1; i < nb; i++) {
+                const LiveChannel &a = live[nb_meta], &c = live[nb_meta + i];
+                if (a.w != c.w || a.h != c.h || a.hshift != c.hshift || a.vshift != c.vshift || a.hcshift != c.hcshift || a.vcshift != c.vcshift)
+                    return fail(FUIFGPU_E_UNSUPPORTED, "Permute from a meta-channel over channels of different geometry (the channel table would depend on stream data)");
+            }
+            permute_labels.clear();
+            for (int i = 0; i < nb; i++) permute_labels.push_back(live[nb_meta + i].component);
+            nb_meta++;
+            LiveChannel pch{};
+            pch.plane = -1; pch.w = nb; pch.h = 1; pch.hshift = -1; pch.component = -1; pch.ctor_data = true;
+            live.insert(live.begin(), pch);
+            return true;
+        }
+        if ((int)params.size() > nb) return fail(FUIFGPU_E_CORRUPT, "Incorrect number of parameters in Permute transform");
+        const std::vector<LiveChannel> in = live;
+        for (size_t i = 0; i < params.size(); i++) {
+            const int c = params[i];
+            if (c < 0 || c >= (int)params.size()) return fail(FUIFGPU_E_CORRUPT, "Invalid permutation: a channel is lost");
+            for (size_t j = 0; j < i; j++) if (params[i] == params[j]) return fail(FUIFGPU_E_CORRUPT, "Invalid permutation: two channels map to one");
+            live[nb_meta + c] = in[nb_meta + i];
+        }
         return true;
     }
 
@@ -484,6 +518,50 @@ struct Builder {
         return true;
     }
 
+    // transform/permute.h:31-54
+    bool inv_permute(const std::vector<int> &params) {
+        if (!params.empty()) {
+            if (nb_meta + (int)params.size() > (int)live.size()) return fail(FUIFGPU_E_CORRUPT, "Permute: channels missing");
+            const std::vector<LiveChannel> tmp = live;
+            for (size_t i = 0; i < params.size(); i++) live[nb_meta + i] = tmp[nb_meta + params[i]];
+            return true;
+        }
+        if (nb_meta < 1) return fail(FUIFGPU_E_CORRUPT, "Permute without its meta-channel");
+        const LiveChannel perm = live[0];
+        const int nb = perm.w;
+        if (nb_meta + nb > (int)live.size()) return fail(FUIFGPU_E_CORRUPT, "Permute: channels missing");
+        std::vector<int> cand(nb), outp(nb);
+        for (int k = 0; k < nb; k++) {
+            cand[k] = live[nb_meta + k].plane;
+            if (live[nb_meta + k].w != live[nb_meta].w || live[nb_meta + k].h != live[nb_meta].h)
+                return fail(FUIFGPU_E_UNSUPPORTED, "Permute from a meta-channel over planes of different size");
+        }
+        for (int i = 0; i < nb; i++) {
+            ProtoOp op;
+            op.kind = OP_PERMUTE;
+            const int idx = (int)ops.size();
+            op.src[0] = perm.plane;
+            op.list = cand;
+            op.p0 = i; op.p1 = nb;
+            op.dst[0] = new_plane(live[nb_meta].w, live[nb_meta].h, -1, idx);
+            touch(perm.plane, idx);
+            for (int pl : cand) touch(pl, idx);
+            ops.push_back(op);
+            outp[i] = op.dst[0];
+        }
+        // The reference moves whole Channel objects, so the component LABEL of output i is the one coded position perm[i]
+        // carried: stream data again.  When Permute is the last transform the decode-time metadata permutation
+        // (encoding.cpp:576-596) has put the labels in coded order first and the two cancel: labels end up natural.
+        // Otherwise the label is not knowable from the header: reported as -1.
+        for (int i = 0; i < nb; i++) {
+            live[nb_meta + i].plane = outp[i];
+            live[nb_meta + i].component = permute_is_last && i < (int)permute_labels.size() ? permute_labels[i] : -1;
+        }
+        nb_meta--;
+        live.erase(live.begin());
+        return true;
+    }
+
     // transform/approximate.h:32-60
     bool inv_approximate(const std::vector<int> &params) {
         int beginc = params[0], endc = params[1];
@@ -638,7 +716,7 @@ struct Builder {
             bool range_ok = (lk == OP_YCBCR) || (lk == OP_YCOCG && plan.minval == 0);
             if (range_ok) continue;
             if (lw >= 0 && planes[pl].birth == lw &&
-                (lk == OP_HSQUEEZE || lk == OP_VSQUEEZE || lk == OP_IDCT || lk == OP_UPSAMPLE || lk == OP_COPY_CLAMP || lk == OP_PALETTE)) {
+                (lk == OP_HSQUEEZE || lk == OP_VSQUEEZE || lk == OP_IDCT || lk == OP_UPSAMPLE || lk == OP_COPY_CLAMP || lk == OP_PALETTE || lk == OP_PERMUTE)) {
                 clamp_fused[lw] = 1;
             } else {
                 ProtoOp op;
@@ -788,6 +866,7 @@ int parse_and_plan(const uint8_t *blob, size_t n, Plan &plan) {
             case TR_PALETTE: ok = b.meta_palette(t.params); break;
             case TR_APPROXIMATE: ok = b.meta_approximate(t.params); break;
             case TR_2DMATCH: ok = b.meta_match(t.params); break;
+            case TR_PERMUTE: ok = b.meta_permute(t.params); break;
             default:
                 plan.error = FUIFGPU_E_UNSUPPORTED;
                 plan.message = "transform id " + std::to_string(t.id) + " is outside the MI355X hot-path scope";
@@ -798,6 +877,13 @@ int parse_and_plan(const uint8_t *blob, size_t n, Plan &plan) {
     }
     if (io.eof) { plan.error = FUIFGPU_E_CORRUPT; plan.message = "truncated header"; return plan.error; }
     plan.data_start = io.pos;
+
+    // A parameter-less Permute at the END of the list: right after its meta-channel the reference puts the metadata of the
+    // channels still to be decoded in coded order (encoding.cpp:576-596,712).  Their geometry is identical (meta_permute
+    // checked), so only the component labels of the CODED table become stream data: reported as -1.
+    b.permute_is_last = !plan.transforms.empty() && plan.transforms.back().id == TR_PERMUTE && plan.transforms.back().params.empty();
+    if (b.permute_is_last)
+        for (size_t i = 0; i < b.permute_labels.size() && b.nb_meta + i < b.live.size(); i++) b.live[b.nb_meta + i].component = -1;
 
     // coded channel table + coefficient slab layout
     int64_t off = 0;
@@ -835,6 +921,7 @@ int parse_and_plan(const uint8_t *blob, size_t n, Plan &plan) {
             case TR_PALETTE: ok = b.inv_palette(t.params); break;
             case TR_APPROXIMATE: ok = b.inv_approximate(t.params); break;
             case TR_2DMATCH: ok = b.inv_match(t.params); break;
+            case TR_PERMUTE: ok = b.inv_permute(t.params); break;
             default: ok = false; break;
         }
         if (!ok) return plan.error ? plan.error : (plan.error = FUIFGPU_E_CORRUPT);

@@ -14,6 +14,7 @@
 //   k_upsample       transform/subsample.h:90-115  "fancy" 2x chroma upsampling
 //   k_clamp / k_copy_clamp   image/image.cpp:107-113
 //   k_inv_palette    transform/palette.h:57-64     gather through the decoded palette meta-channel
+//   k_permute_plane  transform/permute.h:31-54     plane gather by a permutation that is stream data (meta-channel form)
 //   k_inv_approx     transform/approximate.h:44-57 quotient * q + remainder, in place
 //   k_inv_match_frames  transform/2dmatch.h:147-171  copy / add the co-located sample of an earlier frame
 //   k_pack_samples   export/write_pam.h:136-150    interleaved 8/16-bit samples of the final planes (what a PNM/PAM holds)
@@ -218,6 +219,24 @@ __global__ __launch_bounds__(256) void k_inv_palette(Bases b, PlaneRef pidx, Pla
         const int v = colours > 0 ? pal[clampi(idx[i], 0, colours - 1)] : 0;   // an empty palette reads Channel::zero (image.h:82)
         d[i] = clamp ? clampi(v, lo, hi) : v;
     }
+}
+
+// transform/permute.h:31-54 with the permutation in a meta-channel: output plane i is a copy of candidate plane perm[i],
+// perm = the decoded samples of the 1-row meta plane -- per image.  A value that is no channel number (the reference would
+// index outside its channel vector) flags the image corrupt and copies nothing.
+__global__ __launch_bounds__(256) void k_permute_plane(Bases b, PlaneRef pperm, const PlaneRef *cand, int nb, int which, PlaneRef po, int clamp, int lo,
+                                                       int hi, int32_t *status, int img_first) {
+    const int c = plane_ptr(b, pperm, blockIdx.z)[which];
+    bool bad = c < 0 || c >= nb;
+    for (int j = 0; j < which && !bad; j++) bad = plane_ptr(b, pperm, blockIdx.z)[j] == c;
+    if (bad) {
+        if (status && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&status[img_first + blockIdx.z], (int32_t)ST_CORRUPT);
+        return;
+    }
+    const int32_t *s = plane_ptr(b, cand[c], blockIdx.z);
+    int32_t *d = plane_ptr(b, po, blockIdx.z);
+    const int64_t n = (int64_t)po.w * po.h;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = clamp ? clampi(s[i], lo, hi) : s[i];
 }
 
 // transform/approximate.h:44-57: ch = ch*q + remainder.  A remainder channel the stream never reached has no
@@ -516,6 +535,11 @@ void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMe
             if ((int64_t)op.dst[0].w * op.dst[0].h <= 0) break;
             hipLaunchKernelGGL(k_inv_palette, grid1d((int64_t)op.dst[0].w * op.dst[0].h, 256, n_images), dim3(256), 0, stream, b, op.src[0],
                                op.src[1], op.dst[0], op.p0, op.p1, op.clamp_out, op.lo, op.hi);
+            break;
+        case OP_PERMUTE:
+            if ((int64_t)op.dst[0].w * op.dst[0].h <= 0 || op.pad < 1) break;
+            hipLaunchKernelGGL(k_permute_plane, grid1d((int64_t)op.dst[0].w * op.dst[0].h, 256, n_images), dim3(256), 0, stream, b, op.src[0],
+                               dev_list + op.idct_first, op.pad, op.p0, op.dst[0], op.clamp_out, op.lo, op.hi, status, img_first);
             break;
         case OP_MATCH:
             if (!meta || op.src[0].w <= 0) break;

@@ -8,7 +8,7 @@
  * tests/test_golden.py compares it with fixtures produced by the unmodified reference CLI.
  *
  * Scope: transforms YCbCr(0) YCoCg(1) ChromaSubsample(3) DCT(4) Quantize(5)
- * Squeeze(7).  Palette/2DMatch/Permute/Approximate streams are reported as unsupported.
+ * Squeeze(7), Palette(6), 2DMatch(8), Permute(9), Approximate(10).
  */
 #include "fuif_oracle.h"
 
@@ -523,6 +523,47 @@ static int meta_match(fo_image *img, fo_transform *t) {
     return 1;
 }
 
+/* transform/permute.h:56-84.  Two forms: the permutation as transform parameters (only channel METADATA moves here:
+ * channel[m+c] = old channel[m+i]), or -- without parameters -- as the samples of a 1-row meta-channel inserted in front */
+static int meta_permute(fo_image *img, const fo_transform *t) {
+    int nb = img->nch - img->nb_meta_channels;
+    if (t->nparams == 0) {
+        img->nb_meta_channels++;
+        fo_channel pch; ch_ctor(&pch, nb, 1, 0, nb - 1);
+        pch.hshift = -1;
+        img_insert_channel(img, 0, &pch);
+        return 1;
+    }
+    if (t->nparams > nb) return 0;
+    fo_channel *in = (fo_channel *)malloc(sizeof(fo_channel) * img->nch);
+    memcpy(in, img->ch, sizeof(fo_channel) * img->nch);
+    for (int i = 0; i < t->nparams; i++) {
+        int c = t->params[i];
+        if (c < 0 || c >= t->nparams) { free(in); return 0; }
+        for (int j = 0; j < i; j++) if (t->params[i] == t->params[j]) { free(in); return 0; }
+        img->ch[img->nb_meta_channels + c] = in[img->nb_meta_channels + i];
+    }
+    free(in);
+    return 1;
+}
+/* encoding/encoding.cpp:576-596: right after the permutation meta-channel has been decoded, when Permute is the LAST transform
+ * of the list and has no parameters, the metadata of the channels still to be decoded is put in coded order */
+static int inv_permute_meta(fo_image *img) {
+    const fo_channel *p = &img->ch[0];
+    int nb = p->w;
+    fo_channel *in = (fo_channel *)malloc(sizeof(fo_channel) * img->nch);
+    memcpy(in, img->ch, sizeof(fo_channel) * img->nch);
+    for (int i = 0; i < nb; i++) {
+        int c = ch_value(p, 0, i);
+        int bad = (c < 0 || c >= nb || img->nb_meta_channels + c >= img->nch);
+        for (int j = 0; j < i && !bad; j++) if (ch_value(p, 0, j) == c) bad = 1;
+        if (bad) { memcpy(img->ch, in, sizeof(fo_channel) * img->nch); free(in); img->error = 1; return 0; }
+        img->ch[img->nb_meta_channels + c] = in[img->nb_meta_channels + i];
+    }
+    free(in);
+    return 1;
+}
+
 /* transform/transform.h:85-102 */
 static int tr_has_parameters(int id) {
     switch (id) { case 3: case 6: case 7: case 4: case 8: case 9: case 10: return 1; default: return 0; }
@@ -537,7 +578,8 @@ static int meta_apply(fo_image *img, fo_transform *t) {
         case TR_PALETTE: return meta_palette(img, t);
         case TR_APPROXIMATE: return meta_approximate(img, t);
         case TR_2DMATCH: return meta_match(img, t);
-        default: return -1;   /* permute (9): not on the path this oracle restates */
+        case 9: return meta_permute(img, t);
+        default: return -1;
     }
 }
 
@@ -965,7 +1007,10 @@ fo_image *fo_decode(const uint8_t *blob, size_t n, int preview, int io_kind, int
                 img->group_channel = (int32_t *)realloc(img->group_channel, sizeof(int32_t) * img->groups_cap);
             }
             img->group_start[img->ngroups] = (uint32_t)io_tell(&io); img->group_channel[img->ngroups] = i; img->ngroups++;
+            const int was_first = (i == 0);
             if (!decode_channel_group(&io, img, &i, btl)) { img->bytes_consumed = io_tell(&io); return img; }
+            /* encoding.cpp:712 */
+            if (was_first && img->ntr > 0 && img->tr[img->ntr - 1].id == 9 && img->tr[img->ntr - 1].nparams == 0) inv_permute_meta(img);
         } else break;
     }
     img->bytes_consumed = io_tell(&io);
@@ -1401,8 +1446,30 @@ static int inv_match(fo_image *img, fo_transform *t) {
     return 1;
 }
 
+/* transform/permute.h:31-54: channel[m+i] = old channel[m+c_i], c from the parameters or from the meta-channel (then dropped) */
+static int inv_permute(fo_image *img, const fo_transform *t) {
+    const int use_channel = (t->nparams == 0);
+    if (use_channel && (img->nb_meta_channels < 1 || img->nch < 1)) return 0;
+    const int n = use_channel ? img->ch[0].w : t->nparams;
+    const int m = img->nb_meta_channels;
+    if (m + n > img->nch) return 0;
+    fo_channel *tmp = (fo_channel *)malloc(sizeof(fo_channel) * img->nch);
+    memcpy(tmp, img->ch, sizeof(fo_channel) * img->nch);
+    char *used = (char *)calloc(n ? n : 1, 1);
+    for (int i = 0; i < n; i++) {
+        int c = use_channel ? ch_value(&img->ch[0], 0, i) : t->params[i];
+        if (c < 0 || c >= n || used[c]) { memcpy(img->ch, tmp, sizeof(fo_channel) * img->nch); free(tmp); free(used); return 0; }  /* the reference indexes blindly */
+        used[c] = 1;
+        img->ch[m + i] = tmp[m + c];
+    }
+    free(tmp); free(used);
+    if (use_channel) { img->nb_meta_channels--; img_erase_channels(img, 0, 1); }
+    return 1;
+}
+
 static int tr_apply_inverse(fo_image *img, fo_transform *t) {
     switch (t->id) {
+        case 9: return inv_permute(img, t);
         case TR_YCBCR: return inv_ycbcr(img);
         case TR_SUBSAMPLE: return inv_subsample(img, t);
         case TR_DCT: return inv_dct(img, t);

@@ -93,6 +93,7 @@ void fuifref_transform_info(void *h, int t, int32_t *out, int cap) {
 // opts[4] max_properties (CLI default 12)
 // opts[5] compress (1 default; 0 = -U uncompressed groups)
 // opts[6] predictor override for all channels (-1 = CLI defaults)
+// opts[7], opts[8..11]: Permute (see below); callers pass at least 12 ints
 // returns malloc'd blob in *out (caller frees with fuifref_free_blob), size as return value; 0 on failure
 size_t fuifref_encode(int w, int h, int nch, int maxval, const int32_t *planes, const int32_t *opts, uint8_t **out) {
     *out = nullptr;
@@ -106,6 +107,18 @@ size_t fuifref_encode(int w, int h, int nch, int maxval, const int32_t *planes, 
     options.compress = opts[5] != 0;
 
     img.recompute_minmax();
+    // Permute (transform/permute.h): the CLI never applies it (fuif.cpp:362-368 is commented out), so fixtures come from here.
+    // opts[7]: 0 none; 1 explicit form (the permutation is a transform parameter: leading -1, permute.h:86-89);
+    //          2 channel form (the permutation is the content of a 1-row meta-channel, permute.h:58-63; the forward step
+    //            leaves the permutation in Transform::parameters as well, which a decoder would take for the explicit form --
+    //            they are cleared here so that the stream says "read it from the meta-channel");  opts[8..8+nch) = permutation
+    if (opts[7] == 1 || opts[7] == 2) {
+        Transform perm(TRANSFORM_PERMUTE);
+        if (opts[7] == 1) perm.parameters.push_back(-1);
+        for (int c = 0; c < nch; c++) perm.parameters.push_back(opts[8 + c]);
+        if (!img.do_transform(perm)) return 0;
+        if (opts[7] == 2) img.transform.back().parameters.clear();
+    }
     // fuif.cpp:380-393 (no palette here: photographic inputs)
     if (opts[0] < 0) img.do_transform(Transform(TRANSFORM_YCoCg));
     // fuif.cpp:449-455

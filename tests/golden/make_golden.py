@@ -53,6 +53,8 @@ SPECS = [
     ("rgb8_96x96_nosqueeze", dict(w=96, h=96, channels=3, bits=8, seed=9), ["-R", "0"]),
     ("rgb8_tall_40x200", dict(w=40, h=200, channels=3, bits=8, seed=10), []),
     ("rgb8_smooth_256x256", dict(w=256, h=256, channels=3, bits=8, seed=11, sigma=0.0), []),
+    # (the reference ENCODER is not deterministic on this one: its bytes differ from run to run -- every version is a valid
+    # stream that decodes to the same planes; the committed file is one of them and the manifest pins what IT decodes to)
     # no Squeeze: the planes are the Image constructor's (already hold w*h zeros), and the channel range excludes 0 --
     # the rows a truncated stream never reaches stay 0, not Channel::zero (encoding.cpp:368, image.h:64-65,73-75)
     ("gray8_nosqueeze_60x40", dict(w=60, h=40, channels=1, bits=8, seed=14), ["-R", "0"]),
@@ -88,10 +90,22 @@ ANIM_SPECS = [
     # default flags for an animation: 2D match against the previous frames (fuif.cpp:440-448, 2dmatch.h:147-171)
     ("anim4_match_40x28", dict(w=40, h=28, channels=3, bits=8, seed=710, static=True), dict(frames=4, match=True)),
 ]
+# Permute (transform/permute.h): the CLI never applies it (fuif.cpp:362-368 is commented out), so these go through the
+# reference's own library calls -- Image::do_transform(Transform(TRANSFORM_PERMUTE)), fuif_prepare_encode, fuif_encode -- in
+# oracle/ref_driver.cpp (fuifref_encode).  "explicit": the permutation is a transform parameter; "channel": it is the content
+# of a 1-row meta-channel; with colorspace/squeeze off Permute is the LAST transform, which also exercises the decode-time
+# metadata permutation of encoding.cpp:576-596,712.
+PERMUTE_SPECS = [
+    ("permute_explicit_rgb8_48x40", dict(w=48, h=40, channels=3, bits=8, seed=81), dict(permute=1, permutation=(2, 0, 1))),
+    ("permute_channel_rgb8_48x40", dict(w=48, h=40, channels=3, bits=8, seed=82), dict(permute=2, permutation=(2, 0, 1))),
+    ("permute_channel_last_rgb8_44x36", dict(w=44, h=36, channels=3, bits=8, seed=83), dict(permute=2, permutation=(1, 2, 0), colorspace=0, squeeze=0)),
+    ("permute_explicit_rgba14_40x36", dict(w=40, h=36, channels=4, bits=14, seed=84), dict(permute=1, permutation=(3, 1, 0, 2))),
+    ("permute_channel_rgba14_40x36", dict(w=40, h=36, channels=4, bits=14, seed=85), dict(permute=2, permutation=(2, 3, 1, 0), colorspace=0)),
+]
 PREVIEWS = {"c1_rgb8_512x512": [0, 1, 2, 3, 4], "rgb8_97x61": [0, 2, 4], "jpeg420_256x192_q90": [0, 1, 2, 3, 4],
             "pal_rgb_graphic_120x90": [1, 3], "approx_rgb8_96x80_A3": [2], "approx_quant_rgb8_40x30": [3], "match_rgb_graphic_96x80": [3]}
 TRUNCATE_EXTRA = {"approx_on_palette_gray12_24x50": [0.8], "match_rgb_graphic_96x80": [0.6]}
-TRUNCATE = {"rgb8_97x61": [0.2, 0.55, 0.93], "rgb8_128x128_I0": [0.5], "jpeg420_256x192_q90": [0.4], "rgb8_64x64_U": [0.6],
+TRUNCATE = {"permute_channel_rgb8_48x40": [0.5], "permute_explicit_rgb8_48x40": [0.6], "rgb8_97x61": [0.2, 0.55, 0.93], "rgb8_128x128_I0": [0.5], "jpeg420_256x192_q90": [0.4], "rgb8_64x64_U": [0.6],
             "pal_rgba_graphic_72x64": [0.5], "pal_rgb_sparse_128x96": [0.7],
             "gray8_nosqueeze_60x40": [0.6], "rgb8_96x96_nosqueeze": [0.45]}
 
@@ -100,7 +114,7 @@ def main():
     ref = Ref()
     manifest = {"generator": "tests/golden/make_golden.py", "reference": "cloudinary/fuif @ /root/reference (unmodified)", "fixtures": []}
     tmp = tempfile.mkdtemp()
-    for name, gen, flags in SPECS + GRAPHIC_SPECS + [(n, g, j) for n, g, j in JPEG_SPECS] + ANIM_SPECS:
+    for name, gen, flags in SPECS + GRAPHIC_SPECS + [(n, g, j) for n, g, j in JPEG_SPECS] + ANIM_SPECS + PERMUTE_SPECS:
         gen = dict(gen)
         static = gen.pop("static", False)
         if "colors" in gen:
@@ -113,7 +127,12 @@ def main():
                 img = img // poster * poster   # more than 256 colours, sparse per-channel histograms
         maxval = (1 << gen["bits"]) - 1
         out = os.path.join(HERE, name + ".fuif")
-        if isinstance(flags, dict) and "frames" in flags:
+        if isinstance(flags, dict) and "permute" in flags:
+            blob = ref.encode(img, maxval=maxval, **flags)
+            with open(out, "wb") as f:
+                f.write(blob)
+            src, cli_flags = None, []
+        elif isinstance(flags, dict) and "frames" in flags:
             base = photographic(**gen)
             for i in range(flags["frames"]):
                 g2 = dict(gen); g2["seed"] = gen["seed"] + i
@@ -135,12 +154,13 @@ def main():
             src = os.path.join(tmp, name + (".pam" if gen["channels"] in (2, 4) else ".ppm" if gen["channels"] == 3 else ".pgm"))
             write_pnm(src, img, maxval)
             cli_flags = flags
-        r = run_ref_cli(cli_flags + [src, out])
-        if r.returncode != 0 or not os.path.exists(out):
-            raise SystemExit("reference CLI failed for %s: %s %s" % (name, r.stdout[-400:], r.stderr[-400:]))
+        if src is not None:
+            r = run_ref_cli(cli_flags + [src, out])
+            if r.returncode != 0 or not os.path.exists(out):
+                raise SystemExit("reference CLI failed for %s: %s %s" % (name, r.stdout[-400:], r.stderr[-400:]))
         blob = open(out, "rb").read()
         entry = {"name": name, "file": name + ".fuif", "bytes": len(blob), "file_sha256": hashlib.sha256(blob).hexdigest(),
-                 "source": gen, "cli_flags": cli_flags if not isinstance(flags, dict) else ["<jpeg/anim>", json.dumps(flags)] + cli_flags, "cases": []}
+                 "source": gen, "cli_flags": cli_flags if not isinstance(flags, dict) else (["<library: oracle/ref_driver.cpp fuifref_encode>", json.dumps(flags)] if "permute" in flags else ["<jpeg/anim>", json.dumps(flags)] + cli_flags), "cases": []}
         cases = [("full", -1, len(blob))]
         cases += [("preview%d" % k, k, len(blob)) for k in PREVIEWS.get(name, [])]
         cases += [("trunc%02d" % int(f * 100), -1, int(len(blob) * f)) for f in TRUNCATE.get(name, []) + TRUNCATE_EXTRA.get(name, [])]
@@ -149,7 +169,7 @@ def main():
             entry["cases"].append({"case": cname, "preview": preview, "nbytes": nbytes, "ok": bool(pre.ok),
                                    "info": pre.info, "transforms": pre.transforms, "pre": describe(pre), "post": describe(post)})
         # lossless fixtures must reproduce the source pixels
-        if not isinstance(flags, dict) and "-Q" not in flags:
+        if (not isinstance(flags, dict) and "-Q" not in flags) or (isinstance(flags, dict) and "permute" in flags):
             full = entry["cases"][0]
             _, post = ref.decode_both(blob)
             assert all(np.array_equal(post.channels[c]["data"], img[c]) for c in range(gen["channels"])), name

@@ -30,12 +30,21 @@ def test_plan_matches_reference_geometry(gpulib, manifest):
         assert [[t[0], t[1]] for t in p.transforms] == [[t[0], t[1]] for t in c["transforms"]], e["name"]
         coded = p.coded_channels
         assert len(coded) == len(c["pre"]), e["name"]
-        for a, b in zip(coded, c["pre"]):
-            assert tuple(a[k] for k in keys) == tuple(b[k] for k in keys), e["name"]
+        # ... and one that IS the last transform permutes the labels of the CODED table at decode time (encoding.cpp:576-596)
+        coded_labels = bool(c["transforms"]) and c["transforms"][-1][0] == 9 and not c["transforms"][-1][1]
+        for i, (a, b) in enumerate(zip(coded, c["pre"])):
+            want = tuple(b[k] for k in keys)
+            if coded_labels and i >= 1:
+                want = want[:-1] + (-1,)
+            assert tuple(a[k] for k in keys) == want, e["name"]
         outs = p.output_channels
         assert len(outs) == len(c["post"]), e["name"]
+        # a Permute whose permutation is stream data (no parameters) and that is not the last transform leaves component
+        # LABELS that depend on that data (permute.h:48 moves whole Channel objects): the geometry-only plan reports -1
+        data_labels = any(t[0] == 9 and not t[1] for t in c["transforms"][:-1])
         for a, b in zip(outs, c["post"]):
-            assert (a["w"], a["h"], a["component"]) == (b["w"], b["h"], b["component"]), e["name"]
+            assert (a["w"], a["h"]) == (b["w"], b["h"]), e["name"]
+            assert a["component"] == (b["component"] if not (data_labels and b["component"] >= 0) else -1), e["name"]
         # slabs: planes do not overlap and stay inside the slab
         spans = sorted((ch["offset"], ch["offset"] + ch["w"] * ch["h"]) for ch in coded if ch["w"] * ch["h"])
         assert all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))
