@@ -66,7 +66,7 @@ class ChannelDesc(C.Structure):
 
 class EncodeOptions(C.Structure):
     _fields_ = [("ycocg", C.c_int32), ("squeeze", C.c_int32), ("max_properties", C.c_int32), ("tree_mode", C.c_int32),
-                ("max_tree_nodes", C.c_int32), ("emit_index", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("max_tree_nodes", C.c_int32), ("emit_index", C.c_int32), ("split_bits", C.c_int32), ("reserved", C.c_int32)]
 
 
 # every symbol include/fuifgpu.h declares (tests check that the library exports all of them)
@@ -353,12 +353,19 @@ def decode_batch(blobs, preview=-1, undo=True):
         batch.close()
 
 
-def encode_image(planes, bit_depth=8, ycocg=True, squeeze=True, max_properties=12, tree_mode=1, max_tree_nodes=4095, index=False):
+# learned trees: 0 = the writer's default rule (description length of the extra leaf), > 0 = flat bits a split must save.
+# The test suite sets 16 (bushy trees on small pictures: coverage of the context-tree walk).
+DEFAULT_SPLIT_BITS = 0
+
+
+def encode_image(planes, bit_depth=8, ycocg=True, squeeze=True, max_properties=12, tree_mode=1, max_tree_nodes=4095, index=False,
+                 split_bits=None):
     """(C,H,W) int32 planes -> lossless .fuif bytes (host C++ writer, csrc/writer.cpp).
     index=True appends the group index trailer (csrc/index.cpp) that unlocks one-wavefront-per-group decoding."""
+    split_bits = DEFAULT_SPLIT_BITS if split_bits is None else split_bits
     planes = np.ascontiguousarray(planes, dtype=np.int32)
     c, h, w = planes.shape
-    opt = EncodeOptions(int(ycocg), int(squeeze), max_properties, tree_mode, max_tree_nodes, int(index), (C.c_int32 * 2)(0, 0))
+    opt = EncodeOptions(int(ycocg), int(squeeze), max_properties, tree_mode, max_tree_nodes, int(index), int(split_bits), 0)
     out = C.c_void_p()
     n = C.c_size_t(0)
     _check(lib().fuifgpu_encode_image(planes.ctypes.data, w, h, c, bit_depth, C.byref(opt), C.byref(out), C.byref(n)))

@@ -317,6 +317,8 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
         }
         suspendable[gi] = ok ? 1 : 0;
     }
+    int64_t image_samples = 0;
+    for (int c = 0; c < nch; c++) image_samples += (int64_t)b->plan.coded[c].w * b->plan.coded[c].h;
     auto push_tile = [&](int i, size_t k) {
         const std::vector<GroupEntry> &g = groups[group_of[i]];
         if (k >= g.size()) return;
@@ -327,6 +329,13 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
         t.last_channel = k + 1 < g.size() ? g[k + 1].first_channel - 1 : nch - 1;
         t.end = k + 1 < g.size() ? g[k + 1].start : 0u;
         t.flags = suspendable[group_of[i]] ? kTileSuspendable : 0u;
+        // size class = floor(log2(samples of the image / samples of the tile)): the few tiles that hold most of an image are its
+        // critical path (one range coder each), the kernel runs them at a higher wavefront priority
+        int64_t mine = 0;
+        for (int c = (int)t.first_channel; c <= (int)t.last_channel; c++) mine += (int64_t)b->plan.coded[c].w * b->plan.coded[c].h;
+        uint32_t cls = 15;
+        if (mine > 0) { cls = 0; while (cls < 15 && (mine << (cls + 1)) <= image_samples) cls++; }
+        t.flags |= cls << kTileSizeClassShift;
         b->tiles.push_back(t);
     };
     // Dense launches with more tiles than wavefronts use the context scheduler (maniac_decode.h, sched == 1): tiles image by
@@ -348,10 +357,24 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
         const int Q = b->n_queues;
         layout.resize((size_t)Q + 1 + n_images + n_images + 1);
         uint32_t *qib = layout.data(), *qim = qib + Q + 1, *itb = qim + n_images;
+        // Images are dealt to the queues longest stream first, back and forth (0..Q-1, Q-1..0, ...): every queue gets the same
+        // number of images and a similar number of bytes.  Dealing them in caller order put the copies of one picture on
+        // one CU (a batch of K pictures replicated, K dividing Q), and the CUs holding the longest pictures finished 1.3 s
+        // after the median one (profiles/r2_priority_and_balance.txt); the stream length is the best predictor of the
+        // decoding time the host has.
+        std::vector<int> by_size(n_images);
+        for (int i = 0; i < n_images; i++) by_size[i] = i;
+        std::stable_sort(by_size.begin(), by_size.end(), [&](int x, int y) { return sizes[x] > sizes[y]; });
+        std::vector<std::vector<uint32_t>> dealt(Q);
+        for (int k = 0; k < n_images; k++) {
+            const int round = k / Q, at = k % Q;
+            dealt[(round & 1) ? Q - 1 - at : at].push_back((uint32_t)by_size[k]);
+        }
         uint32_t pos = 0;
         for (int q = 0; q < Q; q++) {
             qib[q] = pos;
-            for (int i = q; i < n_images; i += Q) qim[pos++] = (uint32_t)i;
+            std::sort(dealt[q].begin(), dealt[q].end());   // caller order inside a queue
+            for (uint32_t i : dealt[q]) qim[pos++] = i;
         }
         qib[Q] = pos;
         for (int i = 0; i < n_images; i++) {
@@ -445,6 +468,8 @@ int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
         P.q_head = w; P.done_total = w + 1; P.sched_stats = reinterpret_cast<unsigned long long *>(w + 2); w += 18;
         P.yield_slack = 8;
         if (const char *e = getenv("FUIFGPU_YIELD_SLACK")) P.yield_slack = (uint32_t)std::max(0, atoi(e));
+        P.prio_base = kDefaultPrioBase;   // size classes <= base run at wavefront priority 3, base+1 at 2, base+2 at 1; negative: all 0
+        if (const char *e = getenv("FUIFGPU_PRIO_BASE")) P.prio_base = atoi(e);
         P.simd_claim = w; w += 2 * 4096 + 1;
         P.img_next = w; w += b->n_loaded;
         P.img_done = w; w += b->n_loaded;

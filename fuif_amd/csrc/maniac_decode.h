@@ -49,6 +49,7 @@ struct DecodeParams {
     //              wavefront's scratch) and gives the wavefront back instead of spinning; a wavefront of the same CU
     //              resumes it later.
     int32_t sched;
+    int32_t prio_base;           // tiles of size class <= prio_base run at wavefront priority 3, +1 at 2, +2 at 1 (negative: off)
     uint32_t yield_slack;        // a suspended tile is runnable again once the rows it waits for are this many rows ahead (or final)
     int32_t n_queues;
     uint32_t *q_head;            // sched 0: [1] head of the single list; zeroed before the launch

@@ -469,6 +469,14 @@ DEV int fast_symbol(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
 #define FS_VB "v60"
 #define FS_VC "v61"
 #define FS_VA "v63"
+#elif FUIF_WAVES == 7
+#define FS_VK "v[66:67]"
+#define FS_VK0 "v66"
+#define FS_VK1 "v67"
+#define FS_VBC "v[68:69]"
+#define FS_VB "v68"
+#define FS_VC "v69"
+#define FS_VA "v71"
 #elif FUIF_WAVES >= 6
 #define FS_VK "v[74:75]"
 #define FS_VK0 "v74"
@@ -777,6 +785,9 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
     for (;;) {
     uint32_t tix = kNoWork;
     bool resumed = false;
+#ifndef FUIF_EMU
+    __builtin_amdgcn_s_setprio(0);   // looking for work never competes with decoding
+#endif
     if (!sched) {
         if (lane == 0) { const uint32_t k = atomicAdd(&P.q_head[0], 1u); if (k < (uint32_t)P.n_tiles) tix = k; }
         tix = rflu(tix);
@@ -814,6 +825,18 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
     }
     const Tile tile = P.tiles[tix];
     const unsigned long long tile_t0 = realtime();
+#ifndef FUIF_EMU
+    {
+        // the few tiles that hold most of an image are its critical path: they get the issue slots first (s_setprio),
+        // the many short tiles fill what is left (size class: Tile::flags, host side)
+        const int cls = (int)((rflu(tile.flags) >> kTileSizeClassShift) & 15u), over = cls - P.prio_base;
+        const int prio = P.prio_base < 0 ? 0 : over <= 0 ? 3 : over >= 3 ? 0 : 3 - over;
+        if (prio == 3) __builtin_amdgcn_s_setprio(3);
+        if (prio == 2) __builtin_amdgcn_s_setprio(2);
+        if (prio == 1) __builtin_amdgcn_s_setprio(1);
+        if (prio == 0) __builtin_amdgcn_s_setprio(0);
+    }
+#endif
     unsigned long long waited = 0;
     const int img = rfl((int)tile.image);
     const int first_c = rfl(tile.first_channel), last_c = rfl(tile.last_channel);

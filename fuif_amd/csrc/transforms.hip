@@ -20,6 +20,9 @@
 //   k_pack_samples   export/write_pam.h:136-150    interleaved 8/16-bit samples of the final planes (what a PNM/PAM holds)
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "fuifgpu_internal.h"
 #include "transforms.h"
 
@@ -144,6 +147,55 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze(Bases b, PlaneRef pa, Plane
     if ((wo & 1) && lane < rows) {  // squeeze.h:129
         const int v = a[(int64_t)myrow * w1 + w1 - 1];
         o[(int64_t)myrow * wo + wo - 1] = clamp ? clampi(v, lo, hi) : v;
+    }
+}
+
+// The same transform without LDS: one lane per row, 4 pairs per step as 16-byte loads and two 16-byte stores.  A lane
+// walks its own row, so one load instruction touches 64 rows; the 128-byte lines it opens are finished by the lane's next
+// loads and come from L1/L2 by then.  No LDS and ~40 VGPRs: the CU holds 8 wavefronts per SIMD (the staged kernel above:
+// 33 KB of LDS per wavefront = 4 wavefronts per CU, its three phases separated by barriers).
+struct __attribute__((packed, aligned(4))) Int4U { int32_t v[4]; };
+__global__ __launch_bounds__(256) void k_inv_hsqueeze_rows(Bases b, PlaneRef pa, PlaneRef pr, PlaneRef po, int clamp, int lo, int hi) {
+    const int y = blockIdx.x * 256 + threadIdx.x;
+    const int w1 = pa.w, w2 = pr.w, h = pa.h, wo = w1 + w2;
+    if (y >= h) return;
+    const int32_t *a = plane_ptr(b, pa, blockIdx.z) + (int64_t)y * w1;
+    const int32_t *r = plane_ptr(b, pr, blockIdx.z) + (int64_t)y * w2;
+    int32_t *o = plane_ptr(b, po, blockIdx.z) + (int64_t)y * wo;
+    int avg = a[0];
+    int left = avg;   // first pair: tendency(avg, avg, next), squeeze.h:89
+    int x = 0;
+    for (; x + 4 < w1 && x + 4 <= w2; x += 4) {   // avg[x+1 .. x+4] all exist
+        const Int4U rv = *reinterpret_cast<const Int4U *>(r + x);
+        const Int4U nv = *reinterpret_cast<const Int4U *>(a + x + 1);
+        Int4U o0, o1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int next_avg = nv.v[k];
+            const int diff = rv.v[k] + smooth_tendency(left, avg, next_avg);
+            int A, B;
+            unsqueeze_pair(avg, diff, A, B);
+            left = B;
+            avg = next_avg;
+            if (clamp) { A = clampi(A, lo, hi); B = clampi(B, lo, hi); }
+            if (k < 2) { o0.v[2 * k] = A; o0.v[2 * k + 1] = B; } else { o1.v[2 * k - 4] = A; o1.v[2 * k - 3] = B; }
+        }
+        *reinterpret_cast<Int4U *>(o + 2 * x) = o0;
+        *reinterpret_cast<Int4U *>(o + 2 * x + 4) = o1;
+    }
+    for (; x < w2; x++) {
+        const int next_avg = x + 1 < w1 ? a[x + 1] : avg;   // squeeze.h:100
+        const int diff = r[x] + smooth_tendency(left, avg, next_avg);
+        int A, B;
+        unsqueeze_pair(avg, diff, A, B);
+        o[2 * x] = clamp ? clampi(A, lo, hi) : A;
+        o[2 * x + 1] = clamp ? clampi(B, lo, hi) : B;
+        left = B;
+        avg = next_avg;
+    }
+    if (wo & 1) {  // squeeze.h:129
+        const int v = a[w1 - 1];
+        o[wo - 1] = clamp ? clampi(v, lo, hi) : v;
     }
 }
 
@@ -500,8 +552,13 @@ void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMe
         case OP_HSQUEEZE: {
             const int h = op.src[0].h;
             if (h <= 0 || op.dst[0].w <= 0) break;
-            hipLaunchKernelGGL(k_inv_hsqueeze, dim3((h + HS_ROWS - 1) / HS_ROWS, 1, n_images), dim3(64), 0, stream, b, op.src[0], op.src[1],
-                               op.dst[0], op.clamp_out, op.lo, op.hi);
+            static const bool staged = [] { const char *e = getenv("FUIFGPU_HSQ"); return e && !strcmp(e, "lds"); }();   // A/B switch
+            if (staged)
+                hipLaunchKernelGGL(k_inv_hsqueeze, dim3((h + HS_ROWS - 1) / HS_ROWS, 1, n_images), dim3(64), 0, stream, b, op.src[0], op.src[1],
+                                   op.dst[0], op.clamp_out, op.lo, op.hi);
+            else
+                hipLaunchKernelGGL(k_inv_hsqueeze_rows, dim3((h + 255) / 256, 1, n_images), dim3(256), 0, stream, b, op.src[0], op.src[1],
+                                   op.dst[0], op.clamp_out, op.lo, op.hi);
             break;
         }
         case OP_YCOCG:

@@ -196,7 +196,9 @@ typedef struct {
     int32_t tree_mode;      /* 0 none, 1 learned */
     int32_t max_tree_nodes; /* cap for learned trees (<= 65535) */
     int32_t emit_index;     /* 1: append the group index trailer (see fuifgpu_index_*) */
-    int32_t reserved[2];
+    int32_t split_bits;     /* learned trees: > 0 = a split must save this many bits (flat); 0 = the default rule, the description
+                               length of the extra leaf ((k/2) log2 pixels), which follows the reference encoder's tree sizes */
+    int32_t reserved;
 } fuifgpu_encode_options;
 int fuifgpu_encode_image(const int32_t *planes, int w, int h, int nch, int bit_depth, const fuifgpu_encode_options *opt,
                          uint8_t **blob_out, size_t *size_out);

@@ -732,6 +732,44 @@ static void leafsim_access(int id, int *prev) {
     *prev = id;
     for (int k = 0; k < 4; k++) { int slot = id % g_ls_sizes[k]; if (g_ls_tags[k][slot] == id) g_ls_hit[k]++; else g_ls_tags[k][slot] = id; }
 }
+/* supernode locality: which 6-level subtree (below the root one) each walk round enters; static = the first K in
+ * breadth-first order stay resident (what the kernel does), lru = K most recently used */
+#define SN_POL 5
+static const int g_sn_k[SN_POL] = {2, 3, 4, 7, 12};
+static uint64_t g_sn_rounds, g_sn_static[SN_POL], g_sn_lru[SN_POL];
+static int g_sn_lru_tags[SN_POL][16];
+static void snsim_reset(void) { for (int k = 0; k < SN_POL; k++) for (int i = 0; i < 16; i++) g_sn_lru_tags[k][i] = -1; }
+static void snsim_access(int id) {   /* id = breadth-first rank of the supernode, 1.. */
+    g_sn_rounds++;
+    for (int k = 0; k < SN_POL; k++) {
+        if (id <= g_sn_k[k]) g_sn_static[k]++;
+        int *t = g_sn_lru_tags[k], n = g_sn_k[k], at = -1;
+        for (int i = 0; i < n; i++) if (t[i] == id) { at = i; break; }
+        if (at >= 0) g_sn_lru[k]++; else at = n - 1;
+        for (int i = at; i > 0; i--) t[i] = t[i - 1];
+        t[0] = id;
+    }
+}
+void fo_snsim_report(uint64_t *out) { out[0] = g_sn_rounds; for (int k = 0; k < SN_POL; k++) { out[1 + k] = g_sn_static[k]; out[1 + SN_POL + k] = g_sn_lru[k]; } }
+/* breadth-first rank of every node that roots a supernode (depth multiple of 6, inner node) */
+static void sn_number(const fo_node *n, int size, int *rank) {
+    int *queue = (int *)malloc(sizeof(int) * (size + 1)), qh = 0, qt = 0, next = 0;
+    for (int i = 0; i < size; i++) rank[i] = -1;
+    queue[qt++] = 0;
+    while (qh < qt) {
+        const int r = queue[qh++];
+        rank[r] = next++;
+        /* the inner nodes 6 levels below r, left to right */
+        int level[64], cnt = 1; level[0] = r;
+        for (int d = 0; d < 6; d++) {
+            int nl[64], nc = 0;
+            for (int i = 0; i < cnt; i++) if (n[level[i]].property != -1) { nl[nc++] = n[level[i]].childID; nl[nc++] = n[level[i]].childID + 1; }
+            cnt = nc; for (int i = 0; i < nc; i++) level[i] = nl[i];
+        }
+        for (int i = 0; i < cnt; i++) if (n[level[i]].property != -1) queue[qt++] = level[i];
+    }
+    free(queue);
+}
 void fo_leafsim_report(uint64_t *out6) { out6[0] = g_ls_access; out6[1] = g_ls_same; for (int k = 0; k < 4; k++) out6[2 + k] = g_ls_hit[k]; }
 static void dfs_number(const fo_node *n, int pos, int *ids, int *next) {
     if (n[pos].property == -1) { ids[n[pos].childID] = (*next)++; return; }
@@ -847,7 +885,9 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
     if (g_stats > 0) memset(&g_st, 0, sizeof(g_st));
     const uint64_t st_dec0 = rac.decisions;
     int *ls_ids = NULL, ls_prev = -1;
-    if (g_leafsim) { ls_ids = (int *)malloc(sizeof(int) * nleaves); int nx = 0; dfs_number(tree.n, 0, ls_ids, &nx); leafsim_reset(); }
+    int *sn_rank = NULL;
+    if (g_leafsim) { ls_ids = (int *)malloc(sizeof(int) * nleaves); int nx = 0; dfs_number(tree.n, 0, ls_ids, &nx); leafsim_reset();
+                     sn_rank = (int *)malloc(sizeof(int) * tree.size); sn_number(tree.n, tree.size, sn_rank); snsim_reset(); }
     const int nref = nprops - FO_NB_NONREF;
 
     for (int i = beginc; i <= endc; i++) {
@@ -885,6 +925,7 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
                                 const int kl = tree.n[pos].property - nref;  /* local properties that read `left` */
                                 if (kl == 1 || kl == 3 || kl == 12 || (y ? (kl == 6 || kl == 8) : (kl == 7 || kl == 9))) pre = depth;
                             }
+                            if (g_leafsim && depth && depth % 6 == 0) snsim_access(sn_rank[pos]);
                             depth++;
                             if (props[tree.n[pos].property] > tree.n[pos].splitval) pos = tree.n[pos].childID;
                             else pos = tree.n[pos].childID + 1;
@@ -919,7 +960,7 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
         fprintf(stderr, "\n");
     }
     img->stat_rac_decisions += rac.decisions;
-    free(ls_ids);
+    free(ls_ids); free(sn_rank);
     free(leaves);
     free(tree.n);
     *beginc_io = endc;

@@ -14,6 +14,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The writer's default rule for learned trees (description length of the extra leaf) leaves small pictures with
+    # single-leaf trees.  The tests want the opposite: deep trees on small pictures, so that the context-tree walk, the
+    # supernode levels and the leaf switches are exercised at sizes the oracle finishes in seconds.
+    import fuif_amd
+    fuif_amd.DEFAULT_SPLIT_BITS = 16
 
 
 def plane_hash(a):
