@@ -5,8 +5,7 @@
 // of images: grid.z = image, address = base[buf] + z*stride[buf] + plane offset.
 //
 //   k_inv_vsqueeze   transform/squeeze.h:173-224   one lane per column, serial down the rows
-//   k_inv_hsqueeze   transform/squeeze.h:81-132    one lane per row (the recurrence runs along x),
-//                                                  tiles staged through LDS so HBM sees full rows
+//   k_inv_hsqueeze_rows  transform/squeeze.h:81-132  one lane per row (the recurrence runs along x), a cache line per step
 //   k_inv_ycocg      transform/ycocg.h:49-61       elementwise on three planes (+ clamp)
 //   k_inv_ycbcr      transform/ycbcr.h:49-60       float operands, double arithmetic, no FMA
 //   k_dequant        transform/quantize.h:32-49    elementwise * Channel::q (per image, per plane)
@@ -87,74 +86,15 @@ __global__ __launch_bounds__(256) void k_inv_vsqueeze(Bases b, PlaneRef pa, Plan
 
 // ---------------------------------------------------------------------------------------------
 // horizontal unsqueeze: avg (w1 x h) + residual (w2 x h) -> out ((w1+w2) x h), w1-w2 in {0,1}.
-// One wave per 64 rows; the row recurrence (left = previous B) is serial along x, so lanes own
-// rows.  Chunks of 32 pairs are staged through LDS: HBM sees contiguous 128/256-byte row segments,
-// LDS is read with an odd pitch (conflict free for one-row-per-lane access).
-constexpr int HS_ROWS = 64, HS_PAIRS = 32;
-__global__ __launch_bounds__(64) void k_inv_hsqueeze(Bases b, PlaneRef pa, PlaneRef pr, PlaneRef po, int clamp, int lo, int hi) {
-    __shared__ int s_avg[HS_ROWS * (HS_PAIRS + 1)];
-    __shared__ int s_res[HS_ROWS * (HS_PAIRS + 1)];
-    __shared__ int s_out[HS_ROWS * (2 * HS_PAIRS + 1)];
-    const int lane = threadIdx.x;
-    const int w1 = pa.w, w2 = pr.w, h = pa.h, wo = w1 + w2;
-    const int y0 = blockIdx.x * HS_ROWS;
-    const int32_t *a = plane_ptr(b, pa, blockIdx.z);
-    const int32_t *r = plane_ptr(b, pr, blockIdx.z);
-    int32_t *o = plane_ptr(b, po, blockIdx.z);
-    const int rows = min(HS_ROWS, h - y0);
-    const int myrow = y0 + lane;
-    int left = 0;       // previous B of my row
-    int avg_carry = 0;  // avg[x] for the first pair of the next chunk
-    if (lane < rows) avg_carry = a[(int64_t)myrow * w1];
-    for (int x0 = 0; x0 < w2; x0 += HS_PAIRS) {
-        const int np = min(HS_PAIRS, w2 - x0);
-        // cooperative loads: 2 rows x 32 columns per iteration
-        for (int it = 0; it < HS_ROWS / 2; it++) {
-            const int rr = it * 2 + (lane >> 5), cc = lane & 31;
-            if (rr < rows) {
-                const int64_t rowoff = (int64_t)(y0 + rr);
-                if (cc < np) s_res[rr * (HS_PAIRS + 1) + cc] = r[rowoff * w2 + x0 + cc];
-                // next averages: avg[x0+1 .. x0+np] (clamped to the row end: squeeze.h:100)
-                const int ax = x0 + 1 + cc;
-                if (cc < np) s_avg[rr * (HS_PAIRS + 1) + cc] = a[rowoff * w1 + (ax < w1 ? ax : w1 - 1)];
-            }
-        }
-        __syncthreads();
-        if (lane < rows) {
-            int avg = avg_carry;
-            for (int k = 0; k < np; k++) {
-                const int x = x0 + k;
-                int next_avg = s_avg[lane * (HS_PAIRS + 1) + k];
-                if (x + 1 >= w1) next_avg = avg;
-                const int B0 = (x == 0) ? avg : left;  // first pair: tendency(avg,avg,next) squeeze.h:89
-                const int diff = s_res[lane * (HS_PAIRS + 1) + k] + smooth_tendency(B0, avg, next_avg);
-                int A, B;
-                unsqueeze_pair(avg, diff, A, B);
-                s_out[lane * (2 * HS_PAIRS + 1) + 2 * k] = clamp ? clampi(A, lo, hi) : A;
-                s_out[lane * (2 * HS_PAIRS + 1) + 2 * k + 1] = clamp ? clampi(B, lo, hi) : B;
-                left = B;
-                avg = next_avg;
-            }
-            avg_carry = avg;
-        }
-        __syncthreads();
-        // cooperative stores: one 256-byte row segment per iteration
-        for (int rr = 0; rr < rows; rr++) {
-            if (lane < 2 * np) o[(int64_t)(y0 + rr) * wo + 2 * x0 + lane] = s_out[rr * (2 * HS_PAIRS + 1) + lane];
-        }
-        __syncthreads();
-    }
-    if ((wo & 1) && lane < rows) {  // squeeze.h:129
-        const int v = a[(int64_t)myrow * w1 + w1 - 1];
-        o[(int64_t)myrow * wo + wo - 1] = clamp ? clampi(v, lo, hi) : v;
-    }
-}
-
-// The same transform without LDS: one lane per row, 4 pairs per step as 16-byte loads and two 16-byte stores.  A lane
-// walks its own row, so one load instruction touches 64 rows; the 128-byte lines it opens are finished by the lane's next
-// loads and come from L1/L2 by then.  No LDS and ~40 VGPRs: the CU holds 8 wavefronts per SIMD (the staged kernel above:
-// 33 KB of LDS per wavefront = 4 wavefronts per CU, its three phases separated by barriers).
+// The row recurrence (left = previous B) is serial along x, so lanes own rows: one lane per row, HS_STEP pairs per step.
+// A lane walks its own row, so one load instruction touches 64 rows and 64 cache lines; all loads of a step are issued
+// before the first use, so every 128-byte line a lane opens is fetched from L2 once and finished from L1 while it is
+// still there.  No LDS, no barriers.  Measured on 256 x 4K (profiles/r2_priority_and_balance.txt, r2_transforms.txt): the
+// round-1 kernel (64 rows x 32 pairs staged through 33 KB of LDS, 4 wavefronts per CU, three phases between barriers)
+// 87.6 ms for the whole inverse schedule; this kernel with 4 pairs per step 68.0 ms (every line re-fetched up to 8
+// times); with 32 pairs per step 49.3 ms.
 struct __attribute__((packed, aligned(4))) Int4U { int32_t v[4]; };
+constexpr int HS_STEP = 32;   // pairs per step = one 128-byte line of each input row, two of the output row
 __global__ __launch_bounds__(256) void k_inv_hsqueeze_rows(Bases b, PlaneRef pa, PlaneRef pr, PlaneRef po, int clamp, int lo, int hi) {
     const int y = blockIdx.x * 256 + threadIdx.x;
     const int w1 = pa.w, w2 = pr.w, h = pa.h, wo = w1 + w2;
@@ -165,23 +105,30 @@ __global__ __launch_bounds__(256) void k_inv_hsqueeze_rows(Bases b, PlaneRef pa,
     int avg = a[0];
     int left = avg;   // first pair: tendency(avg, avg, next), squeeze.h:89
     int x = 0;
-    for (; x + 4 < w1 && x + 4 <= w2; x += 4) {   // avg[x+1 .. x+4] all exist
-        const Int4U rv = *reinterpret_cast<const Int4U *>(r + x);
-        const Int4U nv = *reinterpret_cast<const Int4U *>(a + x + 1);
-        Int4U o0, o1;
+    for (; x + HS_STEP < w1 && x + HS_STEP <= w2; x += HS_STEP) {   // avg[x+1 .. x+HS_STEP] all exist
+        Int4U rv[HS_STEP / 4], nv[HS_STEP / 4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int next_avg = nv.v[k];
-            const int diff = rv.v[k] + smooth_tendency(left, avg, next_avg);
-            int A, B;
-            unsqueeze_pair(avg, diff, A, B);
-            left = B;
-            avg = next_avg;
-            if (clamp) { A = clampi(A, lo, hi); B = clampi(B, lo, hi); }
-            if (k < 2) { o0.v[2 * k] = A; o0.v[2 * k + 1] = B; } else { o1.v[2 * k - 4] = A; o1.v[2 * k - 3] = B; }
+        for (int q = 0; q < HS_STEP / 4; q++) {
+            rv[q] = *reinterpret_cast<const Int4U *>(r + x + 4 * q);
+            nv[q] = *reinterpret_cast<const Int4U *>(a + x + 1 + 4 * q);
         }
-        *reinterpret_cast<Int4U *>(o + 2 * x) = o0;
-        *reinterpret_cast<Int4U *>(o + 2 * x + 4) = o1;
+#pragma unroll
+        for (int q = 0; q < HS_STEP / 4; q++) {
+            Int4U o0, o1;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int next_avg = nv[q].v[k];
+                const int diff = rv[q].v[k] + smooth_tendency(left, avg, next_avg);
+                int A, B;
+                unsqueeze_pair(avg, diff, A, B);
+                left = B;
+                avg = next_avg;
+                if (clamp) { A = clampi(A, lo, hi); B = clampi(B, lo, hi); }
+                if (k < 2) { o0.v[2 * k] = A; o0.v[2 * k + 1] = B; } else { o1.v[2 * k - 4] = A; o1.v[2 * k - 3] = B; }
+            }
+            *reinterpret_cast<Int4U *>(o + 2 * (x + 4 * q)) = o0;
+            *reinterpret_cast<Int4U *>(o + 2 * (x + 4 * q) + 4) = o1;
+        }
     }
     for (; x < w2; x++) {
         const int next_avg = x + 1 < w1 ? a[x + 1] : avg;   // squeeze.h:100
@@ -552,13 +499,8 @@ void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMe
         case OP_HSQUEEZE: {
             const int h = op.src[0].h;
             if (h <= 0 || op.dst[0].w <= 0) break;
-            static const bool staged = [] { const char *e = getenv("FUIFGPU_HSQ"); return e && !strcmp(e, "lds"); }();   // A/B switch
-            if (staged)
-                hipLaunchKernelGGL(k_inv_hsqueeze, dim3((h + HS_ROWS - 1) / HS_ROWS, 1, n_images), dim3(64), 0, stream, b, op.src[0], op.src[1],
-                                   op.dst[0], op.clamp_out, op.lo, op.hi);
-            else
-                hipLaunchKernelGGL(k_inv_hsqueeze_rows, dim3((h + 255) / 256, 1, n_images), dim3(256), 0, stream, b, op.src[0], op.src[1],
-                                   op.dst[0], op.clamp_out, op.lo, op.hi);
+            hipLaunchKernelGGL(k_inv_hsqueeze_rows, dim3((h + 255) / 256, 1, n_images), dim3(256), 0, stream, b, op.src[0], op.src[1],
+                               op.dst[0], op.clamp_out, op.lo, op.hi);
             break;
         }
         case OP_YCOCG:

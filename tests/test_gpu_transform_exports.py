@@ -72,7 +72,9 @@ def ref_squeeze(olib, horizontal, avg, res):
     return out
 
 
-@pytest.mark.parametrize("w1,w2,h", [(4, 3, 1), (4, 4, 1), (1, 0, 5), (1, 1, 3), (33, 32, 7), (64, 64, 65), (129, 128, 130), (960, 960, 9)])
+# (k_inv_hsqueeze_rows takes 32 pairs per step while 32 more averages exist: widths on both sides of every boundary of that loop)
+@pytest.mark.parametrize("w1,w2,h", [(4, 3, 1), (4, 4, 1), (1, 0, 5), (1, 1, 3), (33, 32, 7), (64, 64, 65), (129, 128, 130), (960, 960, 9),
+                                     (32, 32, 3), (32, 31, 2), (34, 33, 5), (65, 64, 257), (65, 65, 4), (96, 96, 2), (97, 96, 300), (161, 160, 1)])
 def test_inv_hsqueeze_export(glib, olib, w1, w2, h):
     rng = np.random.default_rng(w1 * 1000 + h)
     n_planes = 3
