@@ -31,6 +31,25 @@ def test_writer_learns_real_trees(gpulib, port):
     assert d.stats["tree_steps"] / d.stats["symbols"] > 0.5  # slow track with non-trivial trees
 
 
+def test_split_rule_default_follows_the_reference_encoder(gpulib, port, ref):
+    """The default rule for learned trees (description length of the extra leaf, `split_bits` 0) is tuned on what the
+    reference encoder does with the same picture: trees that cost the decoder about as many steps per symbol, and a
+    file no larger than with the flat 16-bit bar this suite uses elsewhere for coverage (conftest.py)."""
+    img = photographic(768, 512, 3, 8, seed=31)
+    flat = gpulib.encode_image(img, 8, tree_mode=1, split_bits=16)
+    dflt = gpulib.encode_image(img, 8, tree_mode=1, split_bits=0)
+    theirs = ref.encode(img, 255)
+    steps = {}
+    for name, blob in (("flat", flat), ("default", dflt), ("reference", theirs)):
+        d = port.decode(blob)
+        assert all(np.array_equal(d.channels[i]["data"], img[i]) for i in range(3)), name
+        steps[name] = d.stats["tree_steps"] / d.stats["symbols"]
+    assert steps["default"] < steps["flat"]
+    assert len(dflt) <= len(flat)
+    assert steps["default"] <= steps["reference"] * 1.25   # not deeper than the reference's own trees (it was 1.4x at 4K)
+    assert len(dflt) <= len(theirs) * 1.01
+
+
 @pytest.mark.parametrize("w,h,c,bits,seed", CASES[:3])
 def test_writer_accepted_by_real_reference(gpulib, ref, tmp_path, w, h, c, bits, seed):
     from oracle_py import ref_cli, run_ref_cli
