@@ -750,6 +750,8 @@ static void snsim_access(int id) {   /* id = breadth-first rank of the supernode
         t[0] = id;
     }
 }
+static uint64_t g_depth_hist[32];
+void fo_depth_hist(uint64_t *out32) { for (int i = 0; i < 32; i++) out32[i] = g_depth_hist[i]; }
 void fo_snsim_report(uint64_t *out) { out[0] = g_sn_rounds; for (int k = 0; k < SN_POL; k++) { out[1 + k] = g_sn_static[k]; out[1 + SN_POL + k] = g_sn_lru[k]; } }
 /* breadth-first rank of every node that roots a supernode (depth multiple of 6, inner node) */
 static void sn_number(const fo_node *n, int size, int *rank) {
@@ -936,7 +938,7 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
                             if ((int)tree.n[pos].childID == st_prev_leaf) g_st.same_leaf++;
                             st_prev_leaf = tree.n[pos].childID;
                         }
-                        if (g_leafsim) leafsim_access(ls_ids[tree.n[pos].childID], &ls_prev);
+                        if (g_leafsim) { leafsim_access(ls_ids[tree.n[pos].childID], &ls_prev); g_depth_hist[depth > 31 ? 31 : depth]++; }
                         diff = read_symbol(&rac, leaves + (size_t)tree.n[pos].childID * CH_N, g_table_pixel, mn, mx);
                     }
                     c->data[(size_t)y * c->w + x] = diff + guess;

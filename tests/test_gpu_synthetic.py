@@ -43,6 +43,25 @@ def test_writer_streams_match_oracle(gpulib, port, w, h, c, bits, ycocg):
         assert np.array_equal(post[0][k], img[k])      # lossless round trip
 
 
+@pytest.mark.parametrize("index", [False, True])
+def test_deep_trees_walk_through_chained_supernodes(gpulib, port, index):
+    """trees of depth up to 14 on a small picture (a split only has to save 2 bits): walks go through three supernode
+    levels, most second- and third-level supernodes come from memory, not LDS (small enough for the wavefront emulator
+    of tests/test_emulated_kernels.py)"""
+    img = photographic(320, 256, 3, 8, seed=5)
+    blob = gpulib.encode_image(img, 8, tree_mode=1, split_bits=2, index=index)
+    d_pre, d_post = port.decode_both(blob)
+    stats = port.decode(blob, want_data=False).stats
+    assert stats["tree_steps"] / stats["symbols"] > 8
+    pre, post, st, used = gpu_decode(gpulib, [blob, blob])
+    assert not st.any()
+    for planes in pre:
+        for g, e in zip(planes, d_pre.channels):
+            assert np.array_equal(g, e["data"])
+    for k in range(3):
+        assert np.array_equal(post[1][k], img[k])
+
+
 def test_batch_of_distinct_images(gpulib):
     imgs = [photographic(800, 600, 3, 8, seed=5000 + i) for i in range(6)]
     blobs = [gpulib.encode_image(im, 8, tree_mode=1) for im in imgs]
