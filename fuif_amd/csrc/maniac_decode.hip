@@ -887,6 +887,9 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         leaves = reinterpret_cast<uint16_t *>(cb + (size_t)ctx_leaves_units * 256u);
     }
     PROF_DECL;
+#ifdef FUIF_PROF
+    const unsigned long long prof_seg0 = __builtin_readcyclecounter();   // slot 7: cycles of the whole run segment (pick-up to suspension / end)
+#endif
     // progress word of channel c: 1 = ChannelMeta valid, 1 + r = rows [0,r) final, 1 + h = plane final
     auto publish = [&](int c, uint32_t v) {
         if (kHandOff) { drain_stores(); if (lane == 0) st_agent(progress + c, v); }
@@ -1541,6 +1544,10 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         __syncthreads();
         ci = endc;
     }
+#ifdef FUIF_PROF
+    if (yielded) prof_acc[7] += __builtin_readcyclecounter() - prof_seg0;
+    if (yielded && lane == 0 && P.prof) for (int k = 0; k < 8; k++) atomicAdd(&P.prof[(size_t)img * 8 + k], prof_acc[k]);   // (a suspended tile's laps count too)
+#endif
     if (yielded) { st_yields++; __syncthreads(); continue; }   // the tile goes on later, on whichever wavefront picks it up
     if (s_limit_hit(s)) status |= ST_TRUNCATED;
     // The group index is untrusted input (a stale or crafted trailer): a tile that was decoded in full must have stopped
@@ -1576,6 +1583,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         tl[3] = (waited & 0xFFFFFFFFFFFFull) | ((unsigned long long)simd_key << 48);
     }
 #ifdef FUIF_PROF
+    prof_acc[7] += __builtin_readcyclecounter() - prof_seg0;
     if (lane == 0 && P.prof) for (int k = 0; k < 8; k++) atomicAdd(&P.prof[(size_t)img * 8 + k], prof_acc[k]);
 #endif
     __syncthreads();

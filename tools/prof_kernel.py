@@ -32,3 +32,7 @@ for k in range(7):
     c = prof[:, k].mean()
     print("  %-16s %8.1f cycles/symbol  %5.1f %%" % (names[k], c / nsym, 100 * c / tot))
 print("  %-16s %8.1f cycles/symbol (instrumented)" % ("total", tot / nsym))
+seg = prof[:, 7].mean()
+ss = batch.sched_stats()
+print("  run segments (pick-up to suspension / end): %.1f cycles/symbol; scheduler busy %.0f wavefront-seconds -> cycle counter at %.2f GHz" % (
+    seg / nsym, float(ss[6]) / 1e8, (prof[:, 7].sum() / (float(ss[6]) / 1e8) / 1e9) if ss[6] else 0.0))
