@@ -455,6 +455,43 @@ __global__ __launch_bounds__(256) void k_upsample(Bases b, PlaneRef pi, PlaneRef
     plane_ptr(b, po, blockIdx.z)[(int64_t)Y * po.w + X] = clamp ? clampi(v, lo, hi) : v;
 }
 
+// The 4:2:0 case (both factors 2) with one lane per INPUT sample, which owns the 2x2 outputs above it: 9 loads (its 3x3
+// neighbourhood, shared with the neighbouring lanes through L1) for 4 samples instead of 4 loads for 1, a quarter of the
+// lanes and blocks, 8-byte stores.  Same arithmetic as k_upsample (subsample.h:90-115).  C3, 1024 x 4K: k_upsample was the
+// slowest inverse transform of the JPEG-transcode schedule (61.8 ms per step, 1.4 TB/s; profiles/r2_c3_kernel_stats.csv).
+struct __attribute__((packed, aligned(4))) Int2U { int32_t v[2]; };
+__global__ __launch_bounds__(256) void k_upsample_2x2(Bases b, PlaneRef pi, PlaneRef po, int clamp, int lo, int hi) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int ow = pi.w, oh = pi.h;
+    if (x >= ow || 2 * x >= po.w || 2 * y >= po.h) return;
+    const int32_t *in = plane_ptr(b, pi, blockIdx.z);
+    const int xm = x ? x - 1 : 0, xp = x + 1 < ow ? x + 1 : x;
+    const int ym = y ? y - 1 : 0, yp = y + 1 < oh ? y + 1 : y;
+    // the horizontally upsampled row yy at columns 2x (even) and 2x + 1 (odd)
+    auto hrow = [&](int yy, int &he, int &ho) {
+        const int32_t *r = in + (int64_t)yy * ow;
+        const int c = r[x];
+        he = (3 * c + r[xm] + 1) >> 2;
+        ho = (3 * c + r[xp] + 2) >> 2;
+    };
+    int me, mo, ce, co, pe, po2;
+    hrow(ym, me, mo); hrow(y, ce, co); hrow(yp, pe, po2);
+    int v00 = (3 * ce + me + 1) >> 2, v01 = (3 * co + mo + 1) >> 2;     // row 2y: with the row above
+    int v10 = (3 * ce + pe + 2) >> 2, v11 = (3 * co + po2 + 2) >> 2;    // row 2y + 1: with the row below
+    if (clamp) { v00 = clampi(v00, lo, hi); v01 = clampi(v01, lo, hi); v10 = clampi(v10, lo, hi); v11 = clampi(v11, lo, hi); }
+    int32_t *o = plane_ptr(b, po, blockIdx.z) + (int64_t)(2 * y) * po.w + 2 * x;
+    const bool two_cols = 2 * x + 1 < po.w, two_rows = 2 * y + 1 < po.h;
+    if (two_cols) {
+        Int2U a; a.v[0] = v00; a.v[1] = v01;
+        *reinterpret_cast<Int2U *>(o) = a;
+        if (two_rows) { Int2U c2; c2.v[0] = v10; c2.v[1] = v11; *reinterpret_cast<Int2U *>(o + po.w) = c2; }
+    } else {
+        o[0] = v00;
+        if (two_rows) o[po.w] = v10;
+    }
+}
+
 // export/write_pam.h:136-150 (the RGB / gray / +alpha path): for every pixel of the w x h image the first
 // `components` channels, CLAMP(v, minval, maxval), one byte per sample or two bytes big-endian.  Planes may be
 // wider than the image (DCT-padded): the row pitch is the plane's own width.  A quarter of the bytes of the
@@ -522,8 +559,12 @@ void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMe
                                op.p0, op.p1, op.hi, op.clamp_out, op.lo, op.hi);
             break;
         case OP_UPSAMPLE:
-            hipLaunchKernelGGL(k_upsample, dim3((op.dst[0].w + 255) / 256, op.dst[0].h, n_images), dim3(256), 0, stream, b, op.src[0], op.dst[0],
-                               op.p0, op.p1, op.clamp_out, op.lo, op.hi);
+            if (op.p0 == 2 && op.p1 == 2)
+                hipLaunchKernelGGL(k_upsample_2x2, dim3((op.src[0].w + 255) / 256, op.src[0].h, n_images), dim3(256), 0, stream, b, op.src[0], op.dst[0],
+                                   op.clamp_out, op.lo, op.hi);
+            else
+                hipLaunchKernelGGL(k_upsample, dim3((op.dst[0].w + 255) / 256, op.dst[0].h, n_images), dim3(256), 0, stream, b, op.src[0], op.dst[0],
+                                   op.p0, op.p1, op.clamp_out, op.lo, op.hi);
             break;
         case OP_COPY_CLAMP:
         case OP_CLAMP:
