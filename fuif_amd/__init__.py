@@ -66,7 +66,7 @@ class ChannelDesc(C.Structure):
 
 class EncodeOptions(C.Structure):
     _fields_ = [("ycocg", C.c_int32), ("squeeze", C.c_int32), ("max_properties", C.c_int32), ("tree_mode", C.c_int32),
-                ("max_tree_nodes", C.c_int32), ("emit_index", C.c_int32), ("split_bits", C.c_int32), ("reserved", C.c_int32)]
+                ("max_tree_nodes", C.c_int32), ("emit_index", C.c_int32), ("split_bits", C.c_int32), ("gpu_forward", C.c_int32)]
 
 
 # every symbol include/fuifgpu.h declares (tests check that the library exports all of them)
@@ -77,7 +77,7 @@ ABI_SYMBOLS = [
     "fuifgpu_batch_decode", "fuifgpu_batch_undo_transforms", "fuifgpu_batch_sync", "fuifgpu_batch_status",
     "fuifgpu_batch_channel_meta", "fuifgpu_batch_coef_ptr", "fuifgpu_batch_out_ptr", "fuifgpu_batch_download_coef",
     "fuifgpu_batch_download_out", "fuifgpu_batch_last_timing", "fuifgpu_batch_profile", "fuifgpu_batch_tile_log", "fuifgpu_batch_sched_stats", "fuifgpu_inv_hsqueeze", "fuifgpu_inv_vsqueeze",
-    "fuifgpu_inv_ycocg", "fuifgpu_inv_ycbcr", "fuifgpu_idct8x8", "fuifgpu_upsample", "fuifgpu_encode_image", "fuifgpu_encode_channels", "fuifgpu_free_blob",
+    "fuifgpu_inv_ycocg", "fuifgpu_inv_ycbcr", "fuifgpu_idct8x8", "fuifgpu_upsample", "fuifgpu_fwd_ycocg", "fuifgpu_fwd_hsqueeze", "fuifgpu_fwd_vsqueeze", "fuifgpu_encode_image", "fuifgpu_encode_channels", "fuifgpu_free_blob",
     "fuifgpu_index_parse", "fuifgpu_index_append", "fuifgpu_batch_group_index", "fuifgpu_batch_set_group_parallel",
     "fuifgpu_plan_packed_bytes", "fuifgpu_batch_pack_out", "fuifgpu_batch_download_packed",
     "fuifgpu_dev_alloc", "fuifgpu_dev_free", "fuifgpu_dev_upload", "fuifgpu_dev_download",
@@ -147,6 +147,9 @@ def lib():
     L.fuifgpu_inv_ycbcr.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.fuifgpu_idct8x8.argtypes = [C.POINTER(vp), C.c_int, C.c_int, vp, C.c_int, vp]
     L.fuifgpu_upsample.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.fuifgpu_fwd_ycocg.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
+    L.fuifgpu_fwd_hsqueeze.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
+    L.fuifgpu_fwd_vsqueeze.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.fuifgpu_encode_image.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(EncodeOptions), C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.fuifgpu_free_blob.argtypes = [vp]; L.fuifgpu_free_blob.restype = None
     L.fuifgpu_index_parse.argtypes = [C.c_char_p, C.c_size_t, vp, vp, C.c_int, C.POINTER(C.c_int)]
@@ -359,13 +362,14 @@ DEFAULT_SPLIT_BITS = 0
 
 
 def encode_image(planes, bit_depth=8, ycocg=True, squeeze=True, max_properties=12, tree_mode=1, max_tree_nodes=4095, index=False,
-                 split_bits=None):
+                 split_bits=None, gpu_forward=False):
     """(C,H,W) int32 planes -> lossless .fuif bytes (host C++ writer, csrc/writer.cpp).
-    index=True appends the group index trailer (csrc/index.cpp) that unlocks one-wavefront-per-group decoding."""
+    index=True appends the group index trailer (csrc/index.cpp) that unlocks one-wavefront-per-group decoding.
+    gpu_forward=True runs the forward YCoCg and Squeeze on the GPU (fuifgpu_fwd_*): same bytes."""
     split_bits = DEFAULT_SPLIT_BITS if split_bits is None else split_bits
     planes = np.ascontiguousarray(planes, dtype=np.int32)
     c, h, w = planes.shape
-    opt = EncodeOptions(int(ycocg), int(squeeze), max_properties, tree_mode, max_tree_nodes, int(index), int(split_bits), 0)
+    opt = EncodeOptions(int(ycocg), int(squeeze), max_properties, tree_mode, max_tree_nodes, int(index), int(split_bits), int(gpu_forward))
     out = C.c_void_p()
     n = C.c_size_t(0)
     _check(lib().fuifgpu_encode_image(planes.ctypes.data, w, h, c, bit_depth, C.byref(opt), C.byref(out), C.byref(n)))

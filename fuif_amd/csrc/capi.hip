@@ -765,6 +765,24 @@ int fuifgpu_idct8x8(const int32_t *const *src64, int bw, int bh, int32_t *out, i
     if (e != hipSuccess) return hip_fail(e, "idct8x8");
     return FUIFGPU_OK;
 }
+int fuifgpu_fwd_ycocg(int32_t *c0, int32_t *c1, int32_t *c2, int w, int h, void *stream) {
+    if (!c0 || !c1 || !c2 || w < 1 || h < 1) return FUIFGPU_E_ARG;
+    launch_fwd_ycocg(c0, c1, c2, (int64_t)w * h, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return FUIFGPU_OK;
+}
+int fuifgpu_fwd_hsqueeze(const int32_t *in, int w, int h, int32_t *avg, int32_t *res, void *stream) {
+    if (!in || !avg || (w > 1 && !res) || w < 1 || h < 1) return FUIFGPU_E_ARG;
+    launch_fwd_squeeze(true, in, w, h, avg, res, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return FUIFGPU_OK;
+}
+int fuifgpu_fwd_vsqueeze(const int32_t *in, int w, int h, int32_t *avg, int32_t *res, void *stream) {
+    if (!in || !avg || (h > 1 && !res) || w < 1 || h < 1) return FUIFGPU_E_ARG;
+    launch_fwd_squeeze(false, in, w, h, avg, res, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return FUIFGPU_OK;
+}
 int fuifgpu_upsample(const int32_t *in, int w, int h, int srh, int srv, int32_t *out, void *stream) {
     if (!in || !out || w < 1 || h < 1 || srh < 1 || srh > 2 || srv < 1 || srv > 2) return FUIFGPU_E_ARG;
     Bases b;

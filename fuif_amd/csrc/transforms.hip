@@ -492,6 +492,57 @@ __global__ __launch_bounds__(256) void k_upsample_2x2(Bases b, PlaneRef pi, Plan
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Forward YCoCg and Squeeze (the encoder-side subset that is data parallel).  Unlike their inverses
+// they have no recurrence -- the residual of a pair reads ORIGINAL neighbours -- so it is one lane per pair.
+// transform/ycocg.h:65-95, in place on three contiguous planes of n samples
+__global__ __launch_bounds__(256) void k_fwd_ycocg(int32_t *c0, int32_t *c1, int32_t *c2, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int R = c0[i], G = c1[i], B = c2[i];
+    c0[i] = (((R + B) >> 1) + G) >> 1;
+    c1[i] = R - B;
+    c2[i] = G - ((R + B) >> 1);
+}
+// transform/squeeze.h:135-170: in (w x h) -> avg ((w+1)/2 x h) + residual (w/2 x h)
+__global__ __launch_bounds__(256) void k_fwd_hsqueeze(const int32_t *in, int w, int h, int32_t *avg, int32_t *res) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    const int w1 = (w + 1) / 2, w2 = w - w1;
+    if (x >= w1 || y >= h) return;
+    const int32_t *row = in + (int64_t)y * w;
+    if (x >= w2) { avg[(int64_t)y * w1 + x] = row[2 * x]; return; }   // the odd last column is its own average
+    const int A = row[2 * x], B = row[2 * x + 1];
+    const int a = (A + B + (A > B)) >> 1;
+    avg[(int64_t)y * w1 + x] = a;
+    int next = a;
+    if (x + 1 < w2) { const int C = row[2 * x + 2], D = row[2 * x + 3]; next = (C + D + (C > D)) >> 1; }
+    else if (w & 1) next = row[2 * x + 2];
+    const int left = x > 0 ? row[2 * x - 1] : a;
+    res[(int64_t)y * w2 + x] = (A - B) - smooth_tendency(left, a, next);
+}
+// transform/squeeze.h:227-263: in (w x h) -> avg (w x (h+1)/2) + residual (w x h/2)
+__global__ __launch_bounds__(256) void k_fwd_vsqueeze(const int32_t *in, int w, int h, int32_t *avg, int32_t *res) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    const int h1 = (h + 1) / 2, h2 = h - h1;
+    if (x >= w || y >= h1) return;
+    if (y >= h2) { avg[(int64_t)y * w + x] = in[(int64_t)(2 * y) * w + x]; return; }   // the odd last row
+    const int A = in[(int64_t)(2 * y) * w + x], B = in[(int64_t)(2 * y + 1) * w + x];
+    const int a = (A + B + (A > B)) >> 1;
+    avg[(int64_t)y * w + x] = a;
+    int next = a;
+    if (y + 1 < h2) { const int C = in[(int64_t)(2 * y + 2) * w + x], D = in[(int64_t)(2 * y + 3) * w + x]; next = (C + D + (C > D)) >> 1; }
+    else if (h & 1) next = in[(int64_t)(2 * y + 2) * w + x];
+    const int top = y > 0 ? in[(int64_t)(2 * y - 1) * w + x] : a;
+    res[(int64_t)y * w + x] = (A - B) - smooth_tendency(top, a, next);
+}
+void launch_fwd_ycocg(int32_t *c0, int32_t *c1, int32_t *c2, int64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(k_fwd_ycocg, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c0, c1, c2, n);
+}
+void launch_fwd_squeeze(bool horizontal, const int32_t *in, int w, int h, int32_t *avg, int32_t *res, hipStream_t stream) {
+    if (horizontal) hipLaunchKernelGGL(k_fwd_hsqueeze, dim3(((w + 1) / 2 + 255) / 256, h), dim3(256), 0, stream, in, w, h, avg, res);
+    else hipLaunchKernelGGL(k_fwd_vsqueeze, dim3((w + 255) / 256, (h + 1) / 2), dim3(256), 0, stream, in, w, h, avg, res);
+}
+
 // export/write_pam.h:136-150 (the RGB / gray / +alpha path): for every pixel of the w x h image the first
 // `components` channels, CLAMP(v, minval, maxval), one byte per sample or two bytes big-endian.  Planes may be
 // wider than the image (DCT-padded): the row pitch is the plane's own width.  A quarter of the bytes of the

@@ -183,6 +183,13 @@ int fuifgpu_inv_ycbcr(int32_t *c0, int32_t *c1, int32_t *c2, int w, int h, int p
 int fuifgpu_idct8x8(const int32_t *const *src64_dev, int bw, int bh, int32_t *out, int maxval, void *stream);
 /* transform/subsample.h:90-115 "fancy" chroma upsampling, srh/srv in {1,2} */
 int fuifgpu_upsample(const int32_t *in, int w, int h, int srh, int srv, int32_t *out, void *stream);
+/* ---- forward transforms of the writer, raw device planes, contiguous rows ----
+ * transform/ycocg.h:65-95 fwd_YCoCg, in place on three w x h planes */
+int fuifgpu_fwd_ycocg(int32_t *c0, int32_t *c1, int32_t *c2, int w, int h, void *stream);
+/* transform/squeeze.h:135-170 fwd_hsqueeze: in w x h -> avg ((w+1)/2) x h + residual (w/2) x h */
+int fuifgpu_fwd_hsqueeze(const int32_t *in, int w, int h, int32_t *avg, int32_t *res, void *stream);
+/* transform/squeeze.h:227-263 fwd_vsqueeze: in w x h -> avg w x ((h+1)/2) + residual w x (h/2) */
+int fuifgpu_fwd_vsqueeze(const int32_t *in, int w, int h, int32_t *avg, int32_t *res, void *stream);
 
 /* ---- stream writer (host C++; the input generator) --------------------
  * Writes a lossless FUIF stream the reference decoder accepts, with the format decisions of the
@@ -198,7 +205,8 @@ typedef struct {
     int32_t emit_index;     /* 1: append the group index trailer (see fuifgpu_index_*) */
     int32_t split_bits;     /* learned trees: > 0 = a split must save this many bits (flat); 0 = the default rule, the description
                                length of the extra leaf ((k/2) log2 pixels), which follows the reference encoder's tree sizes */
-    int32_t reserved;
+    int32_t gpu_forward;    /* 1: forward YCoCg and Squeeze run on the GPU (fuifgpu_fwd_*); the entropy coder is host code either way.
+                               Same bytes as with 0.  No GPU: FUIFGPU_E_HIP (no silent host route). */
 } fuifgpu_encode_options;
 int fuifgpu_encode_image(const int32_t *planes, int w, int h, int nch, int bit_depth, const fuifgpu_encode_options *opt,
                          uint8_t **blob_out, size_t *size_out);

@@ -191,3 +191,58 @@ def test_upsample_export(glib, olib, w, h, srh, srv):
     d_in, d_out = Dev(src), Dev(np.zeros((h * srv, w * srh), np.int32))
     assert glib.fuifgpu_upsample(d_in.ptr, w, h, srh, srv, d_out.ptr, None) == 0
     assert np.array_equal(d_out.get().reshape(h * srv, w * srh), want)
+
+
+# ---- forward transforms (the writer's GPU path) -----------------------------------------------------
+# The inverse of Squeeze is a function of (avg, residual) and a given plane has exactly one pre-image, so
+# "reference inverse (oracle restatement) of the GPU's forward == the plane" pins the forward kernels bit for bit.
+@pytest.mark.parametrize("w,h", [(1, 1), (2, 1), (1, 2), (3, 3), (8, 5), (33, 17), (64, 64), (255, 2), (2, 255), (640, 37)])
+@pytest.mark.parametrize("horizontal", [True, False])
+def test_fwd_squeeze_exports_are_the_inverse_of_the_reference_inverse(glib, olib, w, h, horizontal):
+    rng = np.random.default_rng(w * 1000 + h * 2 + int(horizontal))
+    plane = rng.integers(-300, 1024, size=(h, w)).astype(np.int32)
+    plane[: h // 2] = rng.integers(0, 4, size=(h // 2, w))       # flat areas: the tendency term is exercised on both signs
+    aw, ah = ((w + 1) // 2, h) if horizontal else (w, (h + 1) // 2)
+    rw, rh = (w - aw, h) if horizontal else (w, h - ah)
+    d_in, d_avg, d_res = Dev(plane), Dev(np.zeros((ah, aw), np.int32)), Dev(np.zeros((max(rh, 1), max(rw, 1)), np.int32))
+    fn = glib.fuifgpu_fwd_hsqueeze if horizontal else glib.fuifgpu_fwd_vsqueeze
+    assert fn(d_in.ptr, w, h, d_avg.ptr, d_res.ptr, None) == 0
+    _sync()
+    avg = d_avg.get()
+    res = d_res.get()[:rh, :rw] if rw * rh else np.zeros((rh, rw), np.int32)
+    res = np.ascontiguousarray(res.reshape(rh, rw))
+    if rw * rh == 0:
+        assert np.array_equal(avg, plane)      # nothing to pair: the plane is its own average
+        return
+    back = ref_squeeze(olib, horizontal, avg, res)
+    assert np.array_equal(back, plane)
+
+
+@pytest.mark.parametrize("w,h,maxval", [(1, 1, 255), (7, 5, 255), (130, 33, 255), (64, 64, 16383)])
+def test_fwd_ycocg_export_round_trip(glib, w, h, maxval):
+    rng = np.random.default_rng(w + h + maxval)
+    rgb = [rng.integers(0, maxval + 1, size=(h, w)).astype(np.int32) for _ in range(3)]
+    d = [Dev(p) for p in rgb]
+    assert glib.fuifgpu_fwd_ycocg(d[0].ptr, d[1].ptr, d[2].ptr, w, h, None) == 0
+    _sync()
+    y, co, cg = [x.get() for x in d]
+    # transform/ycocg.h:65-95 restated
+    assert np.array_equal(y, (((rgb[0] + rgb[2]) >> 1) + rgb[1]) >> 1)
+    assert np.array_equal(co, rgb[0] - rgb[2])
+    assert np.array_equal(cg, rgb[1] - ((rgb[0] + rgb[2]) >> 1))
+    assert glib.fuifgpu_inv_ycocg(d[0].ptr, d[1].ptr, d[2].ptr, w, h, w, w, w, maxval, None) == 0
+    _sync()
+    for k in range(3):
+        assert np.array_equal(d[k].get(), rgb[k])
+
+
+@pytest.mark.parametrize("w,h,c,bits", [(97, 61, 3, 8), (64, 48, 1, 8), (80, 72, 4, 14), (200, 9, 3, 8), (321, 255, 3, 10)])
+def test_writer_with_gpu_forward_transforms_writes_the_same_bytes(gpulib, w, h, c, bits):
+    """fuifgpu_encode_image with gpu_forward = 1 (YCoCg + every Squeeze step on the GPU) against the host forward path,
+    which tests/test_writer.py pins byte for byte to what the reference CLI writes"""
+    from fuif_amd.synth import photographic
+    img = photographic(w, h, c, bits, seed=w + h)
+    for tree_mode in (0, 1):
+        host = gpulib.encode_image(img, bits, tree_mode=tree_mode, index=True)
+        dev = gpulib.encode_image(img, bits, tree_mode=tree_mode, index=True, gpu_forward=True)
+        assert dev == host
