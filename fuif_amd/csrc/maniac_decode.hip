@@ -810,7 +810,13 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         if (tix == kNoWork) {
             if (idle_rounds == 0) st_t0 = sc0;
             if (rflu(ld_agent(P.done_total)) >= (uint32_t)P.n_tiles) { st_idle += realtime() - st_t0; break; }
-            if (++idle_rounds > (kSpinLimit >> 4)) {
+            // A wavefront without work looks again after 1, then 4, then 32 naps of 8128 cycles (idle_rounds counts naps).  Every look
+            // is a dozen agent-scope reads and an atomic; thousands of wavefronts looking every 3 us slow the ones that decode:
+            // a launch of 128 pictures (5000 idle wavefronts) ran the SAME tiles four times slower per symbol than a launch of 1024
+            // (profiles/r2_idle_polling.txt).  A ready tile now waits up to ~0.1 ms for a look; it was suspended for milliseconds.
+            const uint32_t naps = idle_rounds < 8u ? 1u : (idle_rounds < 64u ? 4u : 32u);
+            idle_rounds += naps;
+            if (idle_rounds > (kSpinLimit >> 4)) {
                 // only a lost tile gets here (never observed): flag the unfinished images of the home queue and leave
                 for (uint32_t k = P.q_img_begin[home_q]; k < P.q_img_begin[home_q + 1]; k++) {
                     const uint32_t im = P.q_images[k];
@@ -818,7 +824,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 }
                 break;
             }
-            __builtin_amdgcn_s_sleep(127);
+            for (uint32_t k = 0; k < naps; k++) __builtin_amdgcn_s_sleep(127);
             continue;
         }
         if (idle_rounds) st_idle += sc0 - st_t0;
