@@ -65,6 +65,7 @@ struct fuifgpu_batch {
     std::vector<StreamJob> jobs;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool decode_timed = false, transform_timed = false;
+    bool coef_consumed = false;   // undo_transforms has run on the current decode: several inverse steps work in place on the coefficients
 };
 
 static thread_local std::string g_last_error;
@@ -484,11 +485,16 @@ int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->ev[1], st));
     b->decode_timed = true;
+    b->coef_consumed = false;
     return FUIFGPU_OK;
 }
 
 int fuifgpu_batch_undo_transforms(fuifgpu_batch *b, void *stream) {
     if (!b || b->n_loaded < 1) return FUIFGPU_E_ARG;
+    // dequantisation, YCoCg / YCbCr, Approximate and the match transforms rewrite the coefficient slab (and ChannelMeta::q): a second
+    // pass over the same decode would apply them twice
+    if (b->coef_consumed) { g_last_error = "fuifgpu_batch_undo_transforms: already run on this decode (it works in place on the coefficients); decode again first"; return FUIFGPU_E_ARG; }
+    b->coef_consumed = true;
     hipStream_t st = (hipStream_t)stream;
     const Plan &p = b->plan;
     const int nch = (int)p.coded.size();
@@ -559,6 +565,7 @@ int32_t *fuifgpu_batch_out_ptr(fuifgpu_batch *b, int image) { return (b && image
 
 int fuifgpu_batch_download_coef(fuifgpu_batch *b, int image, int32_t *host, void *stream) {
     if (!b || image < 0 || image >= b->n || !host) return FUIFGPU_E_ARG;
+    if (b->coef_consumed) { g_last_error = "fuifgpu_batch_download_coef: the coefficients were consumed by fuifgpu_batch_undo_transforms"; return FUIFGPU_E_ARG; }
     HIPCHK(hipMemcpyAsync(host, fuifgpu_batch_coef_ptr(b, image), sizeof(int32_t) * (size_t)b->plan.coef_elems, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     return FUIFGPU_OK;

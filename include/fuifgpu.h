@@ -99,6 +99,8 @@ int fuifgpu_batch_decode(fuifgpu_batch *batch, void *stream);
  * inverse Squeeze / Quantize / DCT / ChromaSubsample / YCoCg / YCbCr + final clamp into the
  * output slab. */
 int fuifgpu_batch_undo_transforms(fuifgpu_batch *batch, void *stream);
+/* (once per decode: several inverse steps work in place on the coefficient slab, so a second call, or
+ * fuifgpu_batch_download_coef after it, is refused with FUIFGPU_E_ARG until the batch is decoded again) */
 
 int fuifgpu_batch_sync(fuifgpu_batch *batch, void *stream);
 /* status[n_images] (FUIFGPU_ST_* bits), bytes_consumed[n_images] (io.ftell() at the end) */

@@ -18,8 +18,8 @@ blobs = [inputs[i % len(inputs)][1] for i in range(n)]
 plan = fuif_amd.Plan(blobs[0])
 batch = fuif_amd.Batch(plan, n, sum(len(b) for b in blobs))
 batch.upload(blobs)
-batch.decode(); batch.sync()
 for rep in range(3):
+    batch.decode(); batch.sync()      # undo_transforms consumes the coefficients: once per decode
     batch.undo_transforms(); batch.sync()
     t = batch.timing()
     px = n * w * h
