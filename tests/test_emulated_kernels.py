@@ -22,18 +22,19 @@ CSRC = os.path.join(ROOT, "fuif_amd", "csrc")
 SOURCES = ["plan.cpp", "index.cpp", "writer.cpp", "maniac_decode.hip", "transforms.hip", "capi.hip"]
 
 
-def build_emulated_library():
+def build_emulated_library(extra=(), name="libfuifgpu_emu.so"):
+    lib = os.path.join(EMU_DIR, name)
     os.makedirs(EMU_DIR, exist_ok=True)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "tools", "emu", "emu_runtime.cpp"),
                                                                os.path.join(ROOT, "tools", "emu", "hip", "hip_runtime.h"),
                                                                os.path.join(ROOT, "include", "fuifgpu.h")]
-    if os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(d) for d in deps):
-        return EMU_LIB
-    cmd = ["g++", "-std=c++17", "-O2", "-pthread", "-fPIC", "-shared", "-DFUIF_EMU", "-ffp-contract=off", "-Wno-attributes",
-           "-I", os.path.join(ROOT, "tools", "emu"), "-x", "c++"] + [os.path.join(CSRC, s) for s in SOURCES] + \
-          [os.path.join(ROOT, "tools", "emu", "emu_runtime.cpp"), "-o", EMU_LIB]
+    if os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(d) for d in deps):
+        return lib
+    cmd = ["g++", "-std=c++17", "-O2", "-pthread", "-fPIC", "-shared", "-DFUIF_EMU", "-ffp-contract=off", "-Wno-attributes"] + list(extra) + \
+          ["-I", os.path.join(ROOT, "tools", "emu"), "-x", "c++"] + [os.path.join(CSRC, s) for s in SOURCES] + \
+          [os.path.join(ROOT, "tools", "emu", "emu_runtime.cpp"), "-o", lib]
     subprocess.check_call(cmd)
-    return EMU_LIB
+    return lib
 
 
 SELECTED = [
@@ -87,6 +88,26 @@ def test_gpu_parity_tests_pass_on_the_wavefront_emulator():
     try:
         import xdist  # noqa: F401
         cmd += ["-n", str(max(1, min(6, (os.cpu_count() or 2) - 2)))]
+    except ImportError:
+        pass
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1700)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_node_by_node_walk_beyond_the_supernode_cap():
+    """the library built with room for three supernodes per tree (-DFUIF_MAX_SUPER=3; the product reserves thousands, so the
+    path never runs in the other tests): every subtree beyond them is walked node by node from the parse-order array"""
+    if sys.platform != "linux" or os.uname().machine != "x86_64":
+        pytest.skip("the emulator's context switch is x86-64 SysV assembly")
+    lib = build_emulated_library(extra=["-DFUIF_MAX_SUPER=3"], name="libfuifgpu_emu_cap3.so")
+    env = dict(os.environ)
+    env.update(FUIF_AMD_LIB=lib, FUIF_TEST_MAX_PIXELS="12000", EMU_ALARM="1500")
+    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+           "tests/test_gpu_synthetic.py::test_deep_trees_walk_through_chained_supernodes", "tests/test_gpu_parity.py::test_golden_fixtures_bit_exact"]
+    try:
+        import xdist  # noqa: F401
+        cmd += ["-n", "3"]
     except ImportError:
         pass
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1700)
