@@ -169,12 +169,6 @@ DEV uint2 lds_load_node(uint32_t lds_byte_addr) {
 }
 DEV uint2 global_load_node(const void *p) {
     uint2 v;
-#ifdef FUIF_EXTRA_LOAD
-    // experiment (profiles/r2_traffic_sensitivity.txt): one more 512-byte supernode-sized read per global round, from a
-    // neighbouring record, issued first and never used -- how much does the launch slow down when the bytes go up?
-    uint2 dummy;
-    asm volatile("global_load_dwordx2 %0, %1, off offset:2048" : "=v"(dummy) : "v"(p) : "memory");
-#endif
     asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     return v;
 }

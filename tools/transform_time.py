@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time of the inverse-transform schedule (fuifgpu_batch_undo_transforms) over a batch, from the library's own events.
 
-  python tools/transform_time.py n_images [w h]       (FUIFGPU_HSQ=lds: the staged horizontal unsqueeze, for A/B runs)"""
+  python tools/transform_time.py n_images [w h]"""
 import os
 import sys
 
@@ -24,7 +24,6 @@ for rep in range(3):
     t = batch.timing()
     px = n * w * h
     # every squeeze step reads and writes each sample of its output once (8 B), YCoCg 24 B per pixel
-    print("%s: %d x %dx%d  inverse transforms %.1f ms  (entropy %.1f ms)  %.1f Gpx/s" % (
-        os.environ.get("FUIFGPU_HSQ", "rows"), n, w, h, t[1], t[0], px / t[1] / 1e6), flush=True)
+    print("%d x %dx%d  inverse transforms %.1f ms  (entropy %.1f ms)  %.1f Gpx/s" % (n, w, h, t[1], t[0], px / t[1] / 1e6), flush=True)
 st, _ = batch.status()
 assert not st.any()
