@@ -84,8 +84,11 @@ def make_inputs(k, w, h, channels, bits, seed0, cache_dir, kind="squeeze"):
     return [(seed0 + i, blobs[seed0 + i]) for i in range(k)]
 
 
-def cpu_baseline(blobs, w, h, budget_s=25.0):
-    """single-thread CPU decode (entropy + inverse transforms) of the same streams on this host"""
+def cpu_baseline(blobs, w, h, budget_s=25.0, source=None):
+    """single-thread CPU decode (entropy + inverse transforms) of the same streams on this host.
+    source = (seed, channels, bits) of blobs[0] for lossless workloads: the checker's decode of that stream is compared
+    with the generator's pixels -- the same pixels every GPU-decoded image is compared with, so at full size
+    reference decode == source == GPU decode for that stream (not only decoder(writer(x)) == x)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from oracle_py import Port, Ref
     if Ref.available():
@@ -101,9 +104,18 @@ def cpu_baseline(blobs, w, h, budget_s=25.0):
         n += 1
         if t_total > budget_s:
             break
-    return {"value": round(n * w * h / 1e6 / t_total, 4), "unit": "Mpixels/s", "cores": 1, "kind": kind,
-            "sample": "%d of the bench's %dx%d streams, full decode (entropy + inverse transforms), 1 thread, %.1f s" % (n, w, h, t_total),
-            "host": host_description()}
+    out = {"value": round(n * w * h / 1e6 / t_total, 4), "unit": "Mpixels/s", "cores": 1, "kind": kind,
+           "sample": "%d of the bench's %dx%d streams, full decode (entropy + inverse transforms), 1 thread, %.1f s" % (n, w, h, t_total),
+           "host": host_description()}
+    if source is not None:
+        import numpy as np
+        from fuif_amd.synth import photographic
+        seed, channels, bits = source
+        img = photographic(w, h, channels, bits, seed=seed)
+        d = lib.decode(blobs[0])
+        out["checker_decodes_stream0_to_source_pixels"] = bool(d.ok and len(d.channels) >= channels and all(
+            np.array_equal(np.asarray(d.channels[c]["data"]).reshape(h, w), img[c]) for c in range(channels)))
+    return out
 
 
 def host_description():
@@ -665,7 +677,7 @@ def main():
         if gather_info is not None:
             res["final_gather"] = gather_info
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline([b for _, b in inputs], W, H)
+            res["cpu_baseline"] = cpu_baseline([b for _, b in inputs], W, H, source=(inputs[0][0], C, BITS) if wl["lossless"] else None)
             res["speedup_vs_cpu_1thread"] = round(value / res["cpu_baseline"]["value"], 2)
             if not args.no_cpu_all_cores:
                 name = "synth_idx2_" + wl["kind"] + "_%dx%dx%d_%dbit_seed%d.fuif"
