@@ -83,6 +83,8 @@ JPEG_SPECS = [
     ("jpeg420_256x192_q90", dict(w=256, h=192, channels=3, bits=8, seed=20), dict(quality=90, subsampling=2)),
     ("jpeg444_136x120_q85", dict(w=136, h=120, channels=3, bits=8, seed=21), dict(quality=85, subsampling=0)),
     ("jpeggray_120x88_q80", dict(w=120, h=88, channels=1, bits=8, seed=22), dict(quality=80)),
+    # 4:2:2: chroma subsampled horizontally only (the generic upsampling kernel, factors 2 x 1), odd block counts
+    ("jpeg422_200x104_q88", dict(w=200, h=104, channels=3, bits=8, seed=23), dict(quality=88, subsampling=1)),
 ]
 # animation (FUAF): frames are stacked vertically; -M 0 keeps the 2D-match transform (out of scope) off
 ANIM_SPECS = [
@@ -113,8 +115,17 @@ TRUNCATE = {"permute_channel_rgb8_48x40": [0.5], "permute_explicit_rgb8_48x40": 
 def main():
     ref = Ref()
     manifest = {"generator": "tests/golden/make_golden.py", "reference": "cloudinary/fuif @ /root/reference (unmodified)", "fixtures": []}
+    # GOLDEN_ONLY=name[,name]: (re)generate just these fixtures and merge them into the committed manifest -- the reference
+    # ENCODER is not deterministic on every input (gray8_nosqueeze_60x40), so a full regeneration would churn files
+    only = [n for n in os.environ.get("GOLDEN_ONLY", "").split(",") if n]
+    if only:
+        with open(os.path.join(HERE, "manifest.json")) as f:
+            manifest = json.load(f)
+        manifest["fixtures"] = [e for e in manifest["fixtures"] if e["name"] not in only]
     tmp = tempfile.mkdtemp()
     for name, gen, flags in SPECS + GRAPHIC_SPECS + [(n, g, j) for n, g, j in JPEG_SPECS] + ANIM_SPECS + PERMUTE_SPECS:
+        if only and name not in only:
+            continue
         gen = dict(gen)
         static = gen.pop("static", False)
         if "colors" in gen:
