@@ -386,8 +386,9 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
     }
     b->n_tiles = (int)b->tiles.size();
     {
-        // scheduler state, zeroed before every launch: q_head | done_total | cu claim table | img_next | img_done | ctx_used | tile records
-        const size_t words = 18 + (2 * 4096 + 1) + 2 * (size_t)n_images + 2 * (size_t)b->n_queues + (b->sched ? (size_t)b->n_tiles * (sizeof(TileRec) / 4) : 0);
+        // scheduler state, zeroed before every launch: q_head | done_total | statistics | started_total | heartbeat | cu claim table |
+        // cu_alive | cu_live | cu_foreign | img_next | img_done | ctx_used | tile records
+        const size_t words = 20 + (2 * 4096 + 1) + 3 * 4096 + 2 * (size_t)n_images + 2 * (size_t)b->n_queues + (b->sched ? (size_t)b->n_tiles * (sizeof(TileRec) / 4) : 0);
         if (words > b->sched_words) {
             hipFree(b->d_sched); b->d_sched = nullptr; b->sched_words = 0;
             HIPCHK(hipMalloc((void **)&b->d_sched, words * 4));
@@ -405,6 +406,7 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
             // three times over (FUIFGPU_CTX_MB overrides); a tile that finds the arena full is simply not suspendable.
             size_t per_image = 16u << 20;
             if (const char *e = getenv("FUIFGPU_CTX_MB")) per_image = (size_t)std::max(1, atoi(e)) << 20;
+            if (const char *e = getenv("FUIFGPU_CTX_KB")) per_image = (size_t)std::max(0, atoi(e)) << 10;   // tests: arenas that run out (pinned tiles)
             const size_t images_per_queue = ((size_t)n_images + b->n_queues - 1) / b->n_queues;
             size_t per_queue = per_image * images_per_queue;
             size_t free_b = 0, total_b = 0;
@@ -462,16 +464,17 @@ int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
         HIPCHK(hipMalloc((void **)&b->d_tile_log, sizeof(unsigned long long) * 4 * (size_t)b->n_tiles));
         b->tile_log_cap = b->n_tiles;
     }
-    P.tile_log = b->want_tile_log ? b->d_tile_log : nullptr;
+    P.tile_log = b->want_tile_log ? b->d_tile_log : nullptr;   // (only -DFUIF_STATS kernels write it)
     P.tiles = b->d_tiles; P.n_tiles = b->n_tiles; P.sched = b->sched; P.n_queues = b->n_queues;
     {
         uint32_t *w = b->d_sched;
-        P.q_head = w; P.done_total = w + 1; P.sched_stats = reinterpret_cast<unsigned long long *>(w + 2); w += 18;
+        P.q_head = w; P.done_total = w + 1; P.sched_stats = reinterpret_cast<unsigned long long *>(w + 2); P.started_total = w + 18; P.heartbeat = w + 19; w += 20;
         P.yield_slack = 8;
         if (const char *e = getenv("FUIFGPU_YIELD_SLACK")) P.yield_slack = (uint32_t)std::max(0, atoi(e));
         P.prio_base = kDefaultPrioBase;   // size classes <= base run at wavefront priority 3, base+1 at 2, base+2 at 1; negative: all 0
         if (const char *e = getenv("FUIFGPU_PRIO_BASE")) P.prio_base = atoi(e);
         P.simd_claim = w; w += 2 * 4096 + 1;
+        P.cu_alive = w; w += 4096; P.cu_live = w; w += 4096; P.cu_foreign = w; w += 4096;
         P.img_next = w; w += b->n_loaded;
         P.img_done = w; w += b->n_loaded;
         P.ctx_used = w; w += b->n_queues;
@@ -653,8 +656,14 @@ int fuifgpu_batch_profile(fuifgpu_batch *b, uint64_t *out8_per_image) {
 }
 
 // diagnostic: schedule of the last decode launch.  The first call (cap 0 is fine) switches logging on for later launches.
+// Only the -DFUIF_STATS build of the library records it (the release kernel carries no statistics): FUIFGPU_E_UNSUPPORTED otherwise.
 int fuifgpu_batch_tile_log(fuifgpu_batch *b, uint64_t *out4_per_tile, int cap, int *n_tiles) {
     if (!b || !n_tiles) return FUIFGPU_E_ARG;
+#ifndef FUIF_STATS
+    *n_tiles = 0;
+    g_last_error = "fuifgpu_batch_tile_log: this build of libfuifgpu carries no scheduler statistics (build with -DFUIF_STATS)";
+    return FUIFGPU_E_UNSUPPORTED;
+#endif
     const bool had = b->want_tile_log && b->d_tile_log && b->tile_log_cap >= b->n_tiles;
     b->want_tile_log = true;
     *n_tiles = had ? b->n_tiles : 0;
@@ -667,6 +676,10 @@ int fuifgpu_batch_tile_log(fuifgpu_batch *b, uint64_t *out4_per_tile, int cap, i
 // diagnostic: scheduler counters of the last dense launch {idle ticks (100 MHz) summed over wavefronts, tiles picked up, suspensions, ticks spent picking, ticks spent spinning inside tiles, suspendable tiles that found the arena full}
 int fuifgpu_batch_sched_stats(fuifgpu_batch *b, uint64_t *out8) {
     if (!b || !out8 || !b->d_sched) return FUIFGPU_E_ARG;
+#ifndef FUIF_STATS
+    g_last_error = "fuifgpu_batch_sched_stats: this build of libfuifgpu carries no scheduler statistics (build with -DFUIF_STATS)";
+    return FUIFGPU_E_UNSUPPORTED;
+#endif
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out8, b->d_sched + 2, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return FUIFGPU_OK;

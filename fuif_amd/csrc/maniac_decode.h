@@ -17,7 +17,11 @@ struct TileRec {
     uint32_t flags;                 // status bits 0..7 | eof_flag << 8 | predictor << 9
     uint32_t ctx, ctx_leaves;       // context area: offset into ctx_scratch, offset of the leaf chances inside it (256-byte units)
     uint32_t tree_size, n_super, cur_leaf;
-    uint32_t t_first_lo, t_first_hi, run_ticks, pad[3];
+    uint32_t t_first_lo, t_first_hi, run_ticks;
+    uint32_t pin;                   // 0: the context lives in a context area; else 1 + the wavefront (workgroup id) in whose scratch area it lives
+                                    // (no area was free): only that wavefront can resume the tile
+    uint32_t foreign;               // the tile was started by a CU whose home queue is not its image's queue (cu_foreign counts them)
+    uint32_t pad;
     uint32_t owner;                 // 1 + CU key of the wavefronts that may resume it (the CU that suspended it)
 };
 
@@ -60,11 +64,16 @@ struct DecodeParams {
     uint32_t *img_done;          // sched 1: [n_images] tiles finished; zeroed before the launch
     uint32_t *q_turn;            // sched 1: [n_queues] whose turn it is to start a tile; zeroed before the launch
     uint32_t *done_total;        // sched 1: tiles finished; zeroed before the launch
+    uint32_t *started_total;     // sched 1: tiles started; once it reaches n_tiles a wavefront without work can only ever resume tiles of its own CU
+    uint32_t *heartbeat;         // bumped every few rows by every running tile: "no progress anywhere" is what a stall verdict needs, not "I was idle long"
+    uint32_t *cu_alive;          // sched 1: [4096] per CU key: wavefronts that have arrived and not retired
+    uint32_t *cu_live;           // sched 1: [4096] per CU key: tiles started on that CU and not finished (running or suspended)
+    uint32_t *cu_foreign;        // sched 1: [4096] per CU key: those of them that belong to another queue than the CU's home queue
     TileRec *tile_rec;           // sched 1: [n_tiles]; zeroed before the launch
     uint8_t *ctx_scratch;        // sched 1: one arena per queue for the context areas (supernodes | leaf chances) of its images' tiles
     uint32_t ctx_units_per_queue; //         arena size in 256-byte units
     uint32_t *ctx_used;          // sched 1: [n_queues] units handed out (bump allocation: a launch never frees); zeroed before the launch
-    unsigned long long *sched_stats; // sched 1: {ticks wavefronts spent without work before the last tile finished, tiles picked up, suspensions}; zeroed before the launch
+    unsigned long long *sched_stats; // -DFUIF_STATS builds, sched 1: {ticks wavefronts spent without work before the last tile finished, tiles picked up, suspensions, ...}; zeroed before the launch
     uint32_t *simd_claim;        // [2 * 4096 + 1] {arrivals, 1 + dense index} per physical CU key, then the CU counter; zeroed before the launch
     uint32_t *progress;          // [n_images][n_channels] 0 = nothing yet, 1 + rows finished once the header is known; zeroed before the launch
     uint32_t *group_start;       // [n_images][n_channels] 1 + byte offset of the group that starts at this channel (0 = none); zeroed before the launch
@@ -74,7 +83,7 @@ struct DecodeParams {
     int32_t max_nodes;
     int32_t max_super;           // supernodes the scratch area holds
     unsigned long long *prof;    // -DFUIF_PROF builds: 8 cycle counters per stream (else unused)
-    unsigned long long *tile_log; // [n_tiles][4] {image << 32 | first channel, start, end, waited} in s_memrealtime ticks (100 MHz); waited's top 16 bits = SIMD key
+    unsigned long long *tile_log; // -DFUIF_STATS builds: [n_tiles][4] {image << 32 | first channel, start, end, waited} in s_memrealtime ticks (100 MHz); waited's top 16 bits = SIMD key
 };
 
 int maniac_max_supernodes(int max_nodes);

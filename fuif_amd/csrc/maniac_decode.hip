@@ -141,9 +141,21 @@ DEV unsigned long long realtime() { return 0; }
 #else
 DEV unsigned long long realtime() { return __builtin_amdgcn_s_memrealtime(); }   // 100 MHz, same clock on every CU
 #endif
-constexpr uint32_t kSpinLimit = 1u << 25;
-constexpr uint32_t kYieldSlack = 8;
-constexpr uint32_t kActiveImages = 6;  // images of a queue that are being worked on at a time (context scheduler)   // a suspended tile is resumed once the rows it waits for are this many rows ahead (or final)   // x (sleep + one L2 round trip) ~ a minute: only a lost producer gets here
+// -DFUIF_STATS: scheduler statistics (DecodeParams::sched_stats) and the tile log (fuifgpu_batch_tile_log).  The release
+// kernel carries neither: nine 64-bit counters live across the whole persistent loop cost it ~20 SGPRs (spills).
+#ifdef FUIF_STATS
+#define STATS(...) __VA_ARGS__
+#else
+#define STATS(...)
+#endif
+// A wait gives up (ST_STALLED, reported with ST_CORRUPT) when NOTHING in the launch has made progress for a long while:
+// every kStaleCheck polls the waiting wavefront looks at DecodeParams::heartbeat (bumped by every running tile every few
+// rows); kStaleLimit looks in a row without a change (~5 s) mean the producer is lost.  Time alone says nothing: the long
+// final tiles of a large picture run for seconds while everybody else waits for them.
+constexpr uint32_t kStaleCheck = 1u << 16;
+constexpr uint32_t kStaleLimit = 64;
+constexpr uint32_t kIdleStaleLooks = 1u << 16;   // idle wavefront: looks (>= 0.1 ms apart) without any progress in the launch
+constexpr uint32_t kActiveImages = 6;  // images of a queue that are being worked on at a time (context scheduler)
 
 struct Node {  // maniac/compound.h:41-51; property -1 = leaf, child = leaf id
     int32_t splitval;
@@ -706,6 +718,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         simd_key = key;
         uint32_t idx = 0;
         if (lane == 0) {
+            atomicAdd(&P.cu_alive[key], 1u);
             if (atomicAdd(&P.simd_claim[2 * key], 1u) == 0u) {
                 idx = atomicAdd(&P.simd_claim[2 * 4096], 1u);
                 st_agent(&P.simd_claim[2 * key + 1], idx + 1u);
@@ -718,9 +731,17 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         home_q = (int)(rflu(idx) % (uint32_t)n_queues);
     }
     constexpr uint32_t kNoWork = 0xFFFFFFFFu, kResume = 0x80000000u;
-    // sched == 1: work in queue q -- a suspended tile whose awaited rows have arrived (lowest first: an image's
-    // leaders before its followers), else the next unstarted tile of the first image that has one
-    auto scan_queue = [&](int q) -> uint32_t {
+    const uint32_t my_pin = (uint32_t)blockIdx.x + 1u;
+    // A tile that found no context area (the arenas are bump-allocated per launch and can run out: big trees, a small
+    // FUIFGPU_CTX_MB) keeps its supernodes and leaves in THIS wavefront's scratch area.  It is suspended like any other
+    // tile when it has to wait -- a waiting tile never holds a wavefront, that is what keeps the earliest unfinished tile of
+    // an image runnable -- but only this wavefront can resume it ("pinned"), and until it is finished this wavefront
+    // starts no fresh tile (the tree parse would overwrite the area); it still resumes other tiles, which live in arenas.
+    uint32_t pinned_tix = kNoWork;
+    uint32_t my_turn = (uint32_t)blockIdx.x;   // which active image of the queue a look starts with (wavefront-local: no shared counter to hammer)
+    // sched == 1: work in queue q -- the next unstarted tile of the first image that has one, else (resume_ok) a suspended tile of
+    // this CU whose awaited rows have arrived
+    auto scan_queue = [&](int q, bool fresh_ok, bool resume_ok) -> uint32_t {
         const uint32_t ib = P.q_img_begin[q], ie = P.q_img_begin[q + 1];
         // 1. an unstarted tile of one of the first kActiveImages unfinished images of the queue (stream order inside an
         //    image).  Starting comes first: the long final groups of an image must be under way early, and a tile that
@@ -733,18 +754,25 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
             if (rflu(ld_agent(&P.img_done[im])) >= tn) continue;
             active++;
             uint32_t fresh = kNoWork;
-            if (lane == 0 && ld_agent(&P.img_next[im]) < tn) {
+            if (fresh_ok && lane == 0 && ld_agent(&P.img_next[im]) < tn) {
                 const uint32_t n = atomicAdd(&P.img_next[im], 1u);
-                if (n < tn) fresh = tb + n;
+                if (n < tn) {
+                    fresh = tb + n;
+                    // the tile is counted as live on this CU BEFORE it is counted as started: a wavefront that sees
+                    // started_total == n_tiles sees every cu_live increment (returning atomics: the second is issued
+                    // after the first has come back)
+                    uint32_t seen = atomicAdd(&P.cu_live[simd_key], 1u);
+                    if (q != home_q) { seen |= atomicAdd(&P.cu_foreign[simd_key], 1u); P.tile_rec[fresh].foreign = 1u; }
+                    if (seen != 0xFFFFFFFFu) atomicAdd(P.started_total, 1u);
+                }
             }
             fresh = rflu(fresh);
             if (fresh != kNoWork) return fresh;
         }
+        if (!resume_ok) return kNoWork;
         // 2. a suspended tile whose awaited rows have arrived: the active images take turns (they should finish together,
         //    the last one alone could not keep a CU busy)
-        uint32_t turn = 0;
-        if (lane == 0) turn = atomicAdd(&P.q_turn[q], 1u);
-        turn = rflu(turn);
+        const uint32_t turn = my_turn++;
         const uint32_t nwin = k_end - ib;
         for (uint32_t j = 0; j < nwin; j++) {
             const uint32_t k = ib + (turn + j) % nwin;
@@ -762,8 +790,11 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                     // plain cached stores, and only that CU's own L1 / XCD's L2 are guaranteed to show them (agent-scope
                     // release / acquire fences at every suspension cost an L2 write-back each: measured, 1.3x slower).
                     if (ld_agent(&r->state) == TS_READY && ld_agent(&r->owner) == simd_key + 1u) {
-                        const uint32_t wc = ld_agent(&r->wait_chan), wv = ld_agent(&r->wait_val);
-                        run = ld_agent(&P.progress[(size_t)im * nch + wc]) >= wv;
+                        const uint32_t pin = ld_agent(&r->pin);
+                        if (pin == 0u || pin == my_pin) {
+                            const uint32_t wc = ld_agent(&r->wait_chan), wv = ld_agent(&r->wait_val);
+                            run = ld_agent(&P.progress[(size_t)im * nch + wc]) >= wv;
+                        }
                     }
                 }
                 unsigned long long m = __ballot(run);
@@ -779,9 +810,9 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         }
         return kNoWork;
     };
-    uint32_t idle_rounds = 0;
-    unsigned long long st_idle = 0, st_picks = 0, st_yields = 0, st_scan = 0, st_spin = 0, st_noctx = 0, st_busy = 0, st_pick_t = 0, st_t0 = realtime();
-    const unsigned long long st_begin = st_t0;   // scheduler statistics of this wavefront
+    uint32_t idle_rounds = 0, stale_looks = 0, last_beat = 0;
+    STATS(unsigned long long st_idle = 0, st_picks = 0, st_yields = 0, st_scan = 0, st_spin = 0, st_noctx = 0, st_busy = 0, st_pick_t = 0, st_t0 = realtime();
+          const unsigned long long st_begin = st_t0;)   // scheduler statistics of this wavefront
     for (;;) {
     uint32_t tix = kNoWork;
     bool resumed = false;
@@ -793,44 +824,63 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         tix = rflu(tix);
         if (tix == kNoWork) break;
     } else {
-        // The home queue only, as long as it has anything left: a tile started by a wavefront of another CU can only be
-        // resumed by that CU, which serves its own queue first (such tiles finished seconds late: measured).  A wavefront
-        // that has found nothing for a long while (its queue is done, or this CU is not the one the queue was meant
-        // for) looks at all queues, so a queue without wavefronts of its own is still served.
-        const int reach = idle_rounds > 4096 ? n_queues : 1;
-        const unsigned long long sc0 = realtime();
-        if (st_pick_t) { st_busy += sc0 - st_pick_t; st_pick_t = 0; }
-        for (int d = 0; d < reach && tix == kNoWork; d++) tix = scan_queue(home_q + d < n_queues ? home_q + d : home_q + d - n_queues);
+        // The home queue first.  Other queues are only worth a look while tiles are still unstarted somewhere (a queue whose
+        // CU got no wavefronts of its own must still be served) or when this CU owns a suspended tile of another queue; a
+        // tile started by a wavefront of another CU can only be resumed by that CU (such tiles finished seconds late:
+        // measured), so a foreign queue is a last resort, reached after a long idle spell.
+        STATS(const unsigned long long sc0 = realtime(); if (st_pick_t) { st_busy += sc0 - st_pick_t; st_pick_t = 0; })
+        const bool can_start = pinned_tix == kNoWork;
+        tix = scan_queue(home_q, can_start, true);
+        const bool all_started = rflu(ld_agent(P.started_total)) >= (uint32_t)P.n_tiles;
+        if (tix == kNoWork && idle_rounds > 4096u) {
+            const bool foreign_mine = rflu(ld_agent(&P.cu_foreign[simd_key])) != 0u;
+            if ((!all_started && can_start) || foreign_mine)
+                for (int d = 1; d < n_queues && tix == kNoWork; d++)
+                    tix = scan_queue(home_q + d < n_queues ? home_q + d : home_q + d - n_queues, can_start && !all_started, foreign_mine);
+        }
         if (tix == kNoWork) {
-            if (idle_rounds == 0) st_t0 = sc0;
-            if (rflu(ld_agent(P.done_total)) >= (uint32_t)P.n_tiles) { st_idle += realtime() - st_t0; break; }
-            // A wavefront without work looks again after 1, then 4, then 32 naps of 8128 cycles (idle_rounds counts naps).  Every look
-            // is a dozen agent-scope reads and an atomic; thousands of wavefronts looking every 3 us slow the ones that decode:
-            // a launch of 128 pictures (5000 idle wavefronts) ran the SAME tiles four times slower per symbol than a launch of 1024
-            // (profiles/r2_idle_polling.txt).  A ready tile now waits up to ~0.1 ms for a look; it was suspended for milliseconds.
+            STATS(if (idle_rounds == 0) st_t0 = sc0;)
+            if (rflu(ld_agent(P.done_total)) >= (uint32_t)P.n_tiles) { STATS(st_idle += realtime() - st_t0;) break; }
+            // Retire: once every tile of the launch has been started, a wavefront without work can only ever resume tiles of
+            // its own CU, and a CU needs no more wavefronts than it has unfinished tiles.  The surplus ones leave (cu_alive
+            // never drops below cu_live, and cu_live can only fall from here on): thousands of idle wavefronts polling
+            // agent-scope words slow the ones that decode (a launch of 128 pictures ran the same tiles 2.5x slower per
+            // symbol than a launch of 1024, profiles/r2_idle_polling.txt), and the slots they free are there for the
+            // next launch's wavefronts.
+            if (all_started && can_start) {
+                uint32_t gone = 0;
+                if (lane == 0) {
+                    const uint32_t w = ld_agent(&P.cu_alive[simd_key]), l = ld_agent(&P.cu_live[simd_key]);
+                    if (w > l && atomicCAS(&P.cu_alive[simd_key], w, w - 1u) == w) gone = 1u;
+                }
+                if (rflu(gone)) { STATS(st_idle += realtime() - st_t0;) break; }
+            }
+            // A wavefront without work looks again after 1, then 4, then 32 naps of 8128 cycles (idle_rounds counts naps).
             const uint32_t naps = idle_rounds < 8u ? 1u : (idle_rounds < 64u ? 4u : 32u);
             idle_rounds += naps;
-            if (idle_rounds > (kSpinLimit >> 4)) {
-                // only a lost tile gets here (never observed): flag the unfinished images of the home queue and leave
-                for (uint32_t k = P.q_img_begin[home_q]; k < P.q_img_begin[home_q + 1]; k++) {
-                    const uint32_t im = P.q_images[k];
-                    if (lane == 0 && ld_agent(&P.img_done[im]) < P.img_tile_begin[im + 1] - P.img_tile_begin[im]) atomicOr(&P.status[im], ST_STALLED | ST_CORRUPT);
+            if (naps == 32u) {
+                // only a lost tile gets past this (never observed): nothing in the whole launch has moved for ~7 s
+                const uint32_t beat = rflu(ld_agent(P.heartbeat)) + rflu(ld_agent(P.done_total));
+                stale_looks = beat == last_beat ? stale_looks + 1u : 0u;
+                last_beat = beat;
+                if (stale_looks > kIdleStaleLooks) {
+                    for (uint32_t k = P.q_img_begin[home_q]; k < P.q_img_begin[home_q + 1]; k++) {
+                        const uint32_t im = P.q_images[k];
+                        if (lane == 0 && ld_agent(&P.img_done[im]) < P.img_tile_begin[im + 1] - P.img_tile_begin[im]) atomicOr(&P.status[im], ST_STALLED | ST_CORRUPT);
+                    }
+                    break;
                 }
-                break;
             }
             for (uint32_t k = 0; k < naps; k++) __builtin_amdgcn_s_sleep(127);
             continue;
         }
-        if (idle_rounds) st_idle += sc0 - st_t0;
-        st_pick_t = realtime();
-        st_scan += st_pick_t - sc0;
-        idle_rounds = 0;
-        st_picks++;
+        STATS(if (idle_rounds) st_idle += sc0 - st_t0; st_pick_t = realtime(); st_scan += st_pick_t - sc0; st_picks++;)
+        idle_rounds = 0; stale_looks = 0;
         resumed = (tix & kResume) != 0u;
         tix &= ~kResume;
     }
     const Tile tile = P.tiles[tix];
-    const unsigned long long tile_t0 = realtime();
+    STATS(const unsigned long long tile_t0 = realtime();)
 #ifndef FUIF_EMU
     {
         // the few tiles that hold most of an image are its critical path: they get the issue slots first (s_setprio),
@@ -843,7 +893,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         if (prio == 0) __builtin_amdgcn_s_setprio(0);
     }
 #endif
-    unsigned long long waited = 0;
+    STATS(unsigned long long waited = 0;)
     const int img = rfl((int)tile.image);
     const int first_c = rfl(tile.first_channel), last_c = rfl(tile.last_channel);
 
@@ -867,11 +917,12 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
     TileRec *const rec = sched ? P.tile_rec + tix : nullptr;
     uint2 *snodes_g = snodes_w;
     uint16_t *leaves = leaves_w;
-    int ctx_slot = -1;          // >= 0: the tile owns a context area (256-byte units into ctx_scratch) and gives the wavefront back instead of spinning
+    int ctx_slot = -1;          // >= 0: the tile owns a context area (256-byte units into ctx_scratch)
+    bool can_yield = false;     // the tile gives the wavefront back instead of spinning: it owns a context area, or its context is pinned to this wavefront's scratch area
     uint32_t ctx_leaves_units = 0;
     bool yielded = false;
-    uint32_t yield_chan = 0, yield_val = 0, resume_y = 0, run_ticks0 = 0;
-    unsigned long long tile_first = tile_t0;
+    uint32_t yield_chan = 0, yield_val = 0, resume_y = 0;
+    STATS(uint32_t run_ticks0 = 0; unsigned long long tile_first = tile_t0;)
     if (resumed) {
         s.pos = rflu(rec->pos);
         const uint32_t fl = rflu(rec->flags);
@@ -879,30 +930,46 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         s.eof_flag = (int)((fl >> 8) & 1u);
         ctx_slot = rfl((int)rec->ctx);
         resume_y = rflu(rec->y);
-        run_ticks0 = rflu(rec->run_ticks);
-        tile_first = ((unsigned long long)rflu(rec->t_first_hi) << 32) | rflu(rec->t_first_lo);
+        STATS(run_ticks0 = rflu(rec->run_ticks); tile_first = ((unsigned long long)rflu(rec->t_first_hi) << 32) | rflu(rec->t_first_lo);)
         ctx_leaves_units = rflu(rec->ctx_leaves);
-        uint8_t *cb = P.ctx_scratch + (size_t)(uint32_t)ctx_slot * 256u;
-        snodes_g = reinterpret_cast<uint2 *>(cb);
-        leaves = reinterpret_cast<uint16_t *>(cb + (size_t)ctx_leaves_units * 256u);
+        can_yield = true;
+        if (ctx_slot >= 0) {
+            uint8_t *cb = P.ctx_scratch + (size_t)(uint32_t)ctx_slot * 256u;
+            snodes_g = reinterpret_cast<uint2 *>(cb);
+            leaves = reinterpret_cast<uint16_t *>(cb + (size_t)ctx_leaves_units * 256u);
+        }   // else: pinned to this wavefront -- the scratch area still holds its parse-order nodes, supernodes and leaves
     }
+    // a wait inside a tile that cannot be suspended: bounded by "nothing in the launch moves" (kStaleLimit)
+    uint32_t stale = 0, beat_seen = 0;
+    auto spin_nap = [&](uint32_t &spins) {
+        __builtin_amdgcn_s_sleep(8);
+        if ((++spins & (kStaleCheck - 1u)) == 0u) {
+            const uint32_t beat = rflu(ld_agent(P.heartbeat)) + rflu(ld_agent(P.done_total));
+            stale = beat == beat_seen ? stale + 1u : 0u;
+            beat_seen = beat;
+            if (stale > kStaleLimit) { stalled = true; status |= ST_STALLED | ST_CORRUPT; }
+        }
+    };
     PROF_DECL;
 #ifdef FUIF_PROF
     const unsigned long long prof_seg0 = __builtin_readcyclecounter();   // slot 7: cycles of the whole run segment (pick-up to suspension / end)
 #endif
     // progress word of channel c: 1 = ChannelMeta valid, 1 + r = rows [0,r) final, 1 + h = plane final
     auto publish = [&](int c, uint32_t v) {
-        if (kHandOff) { drain_stores(); if (lane == 0) st_agent(progress + c, v); }
+        if (kHandOff) {
+            drain_stores();
+            if (lane == 0) {
+                st_agent(progress + c, v);
+                if ((v & 31u) == 0u) atomicAdd(P.heartbeat, 1u);   // sign of life for the stall verdicts (every 32nd row is plenty)
+            }
+        }
     };
     auto wait_header = [&](int c) {
         uint32_t spins = 0;
         if (!stalled && rflu(ld_agent(progress + c)) == 0u) {
-            const unsigned long long w0 = realtime();
-            while (!stalled && rflu(ld_agent(progress + c)) == 0u) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > kSpinLimit) { stalled = true; status |= ST_STALLED | ST_CORRUPT; }
-            }
-            waited += realtime() - w0;
+            STATS(const unsigned long long w0 = realtime();)
+            while (!stalled && rflu(ld_agent(progress + c)) == 0u) spin_nap(spins);
+            STATS(waited += realtime() - w0;)
         }
     };
 
@@ -1162,8 +1229,8 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         n_super = 1;
         // A group that may be suspended: a tile of an image ALL of whose tiles are single one-channel groups (Tile::flags),
         // with references to wait for.  Its supernodes and leaves are built in a context area of its image's queue.
-        // (Without a free area -- the arenas are sized generously -- the tile runs to completion on this wavefront and
-        // spins when it has to wait, like the tiles of images that are not suspendable at all.)
+        // (Without a free area the context stays in the wavefront's scratch area and the tile is PINNED to this wavefront: it
+        // is suspended and resumed like the others, but by this wavefront only -- see pinned_tix.)
         int max_super_here = P.max_super;
         if (sched && kHandOff && (rflu(tile.flags) & kTileSuspendable) && beginc == endc && endc == last_c && nrefs > 0) {
             // (7n+5)/12 supernodes are enough for n inner nodes (capi.hip), so nothing falls to the node-by-node walk
@@ -1179,7 +1246,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 }
             }
             off = rflu(off);
-            if (off == 0xFFFFFFFFu) st_noctx++;
+            can_yield = true;
             if (off != 0xFFFFFFFFu) {
                 ctx_slot = (int)off;
                 uint8_t *cb = P.ctx_scratch + (size_t)off * 256u;
@@ -1187,6 +1254,10 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 leaves = reinterpret_cast<uint16_t *>(cb + (size_t)sn_cap * 512u);
                 ctx_leaves_units = sn_cap * 2u;
                 max_super_here = (int)sn_cap;
+            } else {
+                // no area left: the context stays in this wavefront's scratch area and the tile is pinned to the wavefront
+                STATS(st_noctx++;)
+                pinned_tix = tix;
             }
         }
         // Subtree sizes (nodes, saturating): children always have larger indices than their parent in the parse-order
@@ -1332,7 +1403,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                             uint32_t spins = 0;
                             if (__any(ref_seen < need)) {
                                 if (ref_seen < need) ref_seen = ld_agent(fp);
-                                if (__any(ref_seen < need) && ctx_slot >= 0) {
+                                if (__any(ref_seen < need) && can_yield) {
                                     // suspend: the scheduler resumes this tile when the first missing reference is yield_slack rows ahead
                                     const int bl = __builtin_ctzll(__ballot(ref_seen < need));
                                     const RefChan rcb = sh.refs[bl];
@@ -1344,13 +1415,12 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                     break;
                                 }
                                 if (__any(ref_seen < need)) {
-                                    const unsigned long long w0 = realtime();
+                                    STATS(const unsigned long long w0 = realtime();)
                                     while (__any(ref_seen < need) && !stalled) {
-                                        __builtin_amdgcn_s_sleep(8);
-                                        if (++spins > kSpinLimit) { stalled = true; status |= ST_STALLED | ST_CORRUPT; }
+                                        spin_nap(spins);
                                         if (ref_seen < need) ref_seen = ld_agent(fp);
                                     }
-                                    waited += realtime() - w0;
+                                    STATS(waited += realtime() - w0;)
                                 }
                             }
                         }
@@ -1533,8 +1603,9 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 rec->range = rac.range; rec->low = rac.low; rec->pos = s.pos;
                 rec->flags = ((uint32_t)status & 0xFFu) | ((uint32_t)(s.eof_flag & 1) << 8) | ((uint32_t)predictor << 9);
                 rec->ctx = (uint32_t)ctx_slot; rec->ctx_leaves = ctx_leaves_units; rec->tree_size = (uint32_t)tree_size; rec->n_super = (uint32_t)n_super; rec->cur_leaf = (uint32_t)cur_leaf;
-                rec->t_first_lo = (uint32_t)tile_first; rec->t_first_hi = (uint32_t)(tile_first >> 32);
-                rec->run_ticks = run_ticks0 + (uint32_t)(realtime() - tile_t0);
+                STATS(rec->t_first_lo = (uint32_t)tile_first; rec->t_first_hi = (uint32_t)(tile_first >> 32);
+                      rec->run_ticks = run_ticks0 + (uint32_t)(realtime() - tile_t0);)
+                rec->pin = ctx_slot >= 0 ? 0u : my_pin;
                 rec->owner = simd_key + 1u;
             }
             drain_stores();   // the record and the leaf are in this XCD's L2 before the state says so
@@ -1548,7 +1619,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
     if (yielded) prof_acc[7] += __builtin_readcyclecounter() - prof_seg0;
     if (yielded && lane == 0 && P.prof) for (int k = 0; k < 8; k++) atomicAdd(&P.prof[(size_t)img * 8 + k], prof_acc[k]);   // (a suspended tile's laps count too)
 #endif
-    if (yielded) { st_yields++; __syncthreads(); continue; }   // the tile goes on later, on whichever wavefront picks it up
+    if (yielded) { STATS(st_yields++;) __syncthreads(); continue; }   // the tile goes on later, on whichever wavefront picks it up
     if (s_limit_hit(s)) status |= ST_TRUNCATED;
     // The group index is untrusted input (a stale or crafted trailer): a tile that was decoded in full must have stopped
     // exactly where the next tile starts, as it does when the stream is decoded front to back; otherwise the picture is
@@ -1567,12 +1638,18 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         }
     }
     if (lane == 0) { atomicOr(&P.status[img], status); atomicMax(&P.consumed[img], s.pos); }
-    st_spin += waited;
-    if (sched && lane == 0) {
-        st_agent(&rec->state, (uint32_t)TS_DONE);
-        atomicAdd(&P.img_done[img], 1u);
-        atomicAdd(P.done_total, 1u);
+    STATS(st_spin += waited;)
+    if (sched) {
+        if (pinned_tix == tix) pinned_tix = kNoWork;   // the scratch area is free again
+        if (lane == 0) {
+            st_agent(&rec->state, (uint32_t)TS_DONE);
+            if (ld_agent(&rec->foreign)) atomicAdd(&P.cu_foreign[simd_key], 0xFFFFFFFFu);
+            atomicAdd(&P.cu_live[simd_key], 0xFFFFFFFFu);
+            atomicAdd(&P.img_done[img], 1u);
+            atomicAdd(P.done_total, 1u);
+        }
     }
+#ifdef FUIF_STATS
     if (lane == 0 && P.tile_log) {
         // waited = spinning for rows + suspended (first start .. end minus the time some wavefront was running the tile)
         unsigned long long *tl = P.tile_log + (size_t)tix * 4;
@@ -1582,15 +1659,18 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         tl[1] = tile_first; tl[2] = t_end;
         tl[3] = (waited & 0xFFFFFFFFFFFFull) | ((unsigned long long)simd_key << 48);
     }
+#endif
 #ifdef FUIF_PROF
     prof_acc[7] += __builtin_readcyclecounter() - prof_seg0;
     if (lane == 0 && P.prof) for (int k = 0; k < 8; k++) atomicAdd(&P.prof[(size_t)img * 8 + k], prof_acc[k]);
 #endif
     __syncthreads();
     }  // tile loop
+#ifdef FUIF_STATS
     if (sched && lane == 0 && P.sched_stats) {
         atomicAdd(&P.sched_stats[0], st_idle); atomicAdd(&P.sched_stats[1], st_picks); atomicAdd(&P.sched_stats[2], st_yields); atomicAdd(&P.sched_stats[3], st_scan); atomicAdd(&P.sched_stats[4], st_spin); atomicAdd(&P.sched_stats[5], st_noctx); atomicAdd(&P.sched_stats[6], st_busy); atomicAdd(&P.sched_stats[7], realtime() - st_begin);
     }
+#endif
 }
 
 int maniac_max_waves(int dense, int *per_simd) {

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Schedule of one dense k_maniac_decode launch from the kernel's tile log (fuifgpu_batch_tile_log).
 
-  python tools/tile_timeline.py n_images [w h]      (FUIFGPU_TILE_ORDER=group for the round-1 list order)
+  FUIF_AMD_LIB=build/libfuifgpu_stats.so python tools/tile_timeline.py n_images [w h]   (tools/build_variant.sh stats -DFUIF_STATS:
+  the release library records no tile log; FUIFGPU_TILE_ORDER=group for the round-1 list order)
 Prints, per channel group, when its tiles start / end and how long they waited for rows of other tiles; the number
 of tiles running over time; and how evenly the SIMDs finish."""
 import os
@@ -15,7 +16,7 @@ from bench import make_inputs  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (3840, 2160)
-inputs = make_inputs(8, w, h, 3, 8, 1000, "/tmp/fuif_bench_cache")
+inputs = make_inputs(8, w, h, 3, 8, 1000, os.environ.get("FUIF_BENCH_CACHE", "/tmp/fuif_bench_cache"))
 import fuif_amd  # noqa: E402
 
 blobs = [inputs[i % len(inputs)][1] for i in range(n)]
