@@ -1345,10 +1345,12 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         L.touched = 0; L.bits = 0;
         auto switch_leaf = [&](int id) {
             if (LIKELY(id != cur_leaf)) {
+#ifndef FUIF_EXP_NOLEAFLOAD   // (experiment: what the dependent leaf fetch costs -- decodes garbage)
                 if (lane < 32) {
                     leaves[(int64_t)cur_leaf * kLeafStride + lane] = (uint16_t)L.leafv;
                     L.leafv = (int)leaves[(int64_t)id * kLeafStride + lane];
                 }
+#endif
                 cur_leaf = id;
             }
         };

@@ -772,6 +772,29 @@ static void sn_number(const fo_node *n, int size, int *rank) {
     }
     free(queue);
 }
+/* leaf slots: which 6-level subtree (supernode) a leaf hangs off and its order among that supernode's leaves (depth first);
+ * sizes the "leaf slots next to their supernode" layout of the HIP kernel.  slot[leafID] = order, root_owned[leafID] = the
+ * supernode is the root one */
+static uint64_t g_slot_acc[6];   /* accesses: total, root-owned, slot < 4, < 8, < 16, supernodes' leaves > 8 */
+void fo_slotsim_report(uint64_t *out6) { for (int k = 0; k < 6; k++) out6[k] = g_slot_acc[k]; }
+static void slot_dfs(const fo_node *n, int pos, int depth, int *slot, int *next) {
+    if (n[pos].property == -1) { slot[n[pos].childID] = (*next)++; return; }
+    if (depth == 6) return;   /* an inner node 6 levels down roots its own supernode */
+    slot_dfs(n, n[pos].childID, depth + 1, slot, next);
+    slot_dfs(n, n[pos].childID + 1, depth + 1, slot, next);
+}
+static void slot_number(const fo_node *n, int size, const int *sn_rank, int *slot, char *root_owned) {
+    for (int r = 0; r < size; r++) {
+        if (sn_rank[r] < 0) continue;
+        int next = 0, before;
+        /* mark ownership by numbering, then flag the root's */
+        before = 0; (void)before;
+        slot_dfs(n, r, 0, slot, &next);
+        if (r == 0) { /* leaves numbered so far belong to the root supernode */
+            for (int i = 0; i < size; i++) if (n[i].property == -1 && slot[n[i].childID] >= 0) root_owned[n[i].childID] = 1;
+        }
+    }
+}
 void fo_leafsim_report(uint64_t *out6) { out6[0] = g_ls_access; out6[1] = g_ls_same; for (int k = 0; k < 4; k++) out6[2 + k] = g_ls_hit[k]; }
 static void dfs_number(const fo_node *n, int pos, int *ids, int *next) {
     if (n[pos].property == -1) { ids[n[pos].childID] = (*next)++; return; }
@@ -888,8 +911,12 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
     const uint64_t st_dec0 = rac.decisions;
     int *ls_ids = NULL, ls_prev = -1;
     int *sn_rank = NULL;
+    int *lf_slot = NULL; char *lf_root = NULL;
     if (g_leafsim) { ls_ids = (int *)malloc(sizeof(int) * nleaves); int nx = 0; dfs_number(tree.n, 0, ls_ids, &nx); leafsim_reset();
-                     sn_rank = (int *)malloc(sizeof(int) * tree.size); sn_number(tree.n, tree.size, sn_rank); snsim_reset(); }
+                     sn_rank = (int *)malloc(sizeof(int) * tree.size); sn_number(tree.n, tree.size, sn_rank); snsim_reset();
+                     lf_slot = (int *)malloc(sizeof(int) * nleaves); lf_root = (char *)calloc(nleaves, 1);
+                     for (int l = 0; l < nleaves; l++) lf_slot[l] = -1;
+                     slot_number(tree.n, tree.size, sn_rank, lf_slot, lf_root); }
     const int nref = nprops - FO_NB_NONREF;
 
     for (int i = beginc; i <= endc; i++) {
@@ -938,7 +965,9 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
                             if ((int)tree.n[pos].childID == st_prev_leaf) g_st.same_leaf++;
                             st_prev_leaf = tree.n[pos].childID;
                         }
-                        if (g_leafsim) { leafsim_access(ls_ids[tree.n[pos].childID], &ls_prev); g_depth_hist[depth > 31 ? 31 : depth]++; }
+                        if (g_leafsim) { leafsim_access(ls_ids[tree.n[pos].childID], &ls_prev); g_depth_hist[depth > 31 ? 31 : depth]++;
+                                         const int lid = tree.n[pos].childID, sl = lf_slot[lid];
+                                         g_slot_acc[0]++; if (lf_root[lid]) g_slot_acc[1]++; else { if (sl < 4) g_slot_acc[2]++; if (sl < 8) g_slot_acc[3]++; if (sl < 16) g_slot_acc[4]++; } }
                         diff = read_symbol(&rac, leaves + (size_t)tree.n[pos].childID * CH_N, g_table_pixel, mn, mx);
                     }
                     c->data[(size_t)y * c->w + x] = diff + guess;
@@ -962,7 +991,7 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
         fprintf(stderr, "\n");
     }
     img->stat_rac_decisions += rac.decisions;
-    free(ls_ids); free(sn_rank);
+    free(ls_ids); free(sn_rank); free(lf_slot); free(lf_root);
     free(leaves);
     free(tree.n);
     *beginc_io = endc;

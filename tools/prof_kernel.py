@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase cycle breakdown of k_maniac_decode (diagnostic -DFUIF_PROF build).
 
-  hipcc ... -DFUIF_PROF -o fuif_amd/libfuifgpu_prof.so ;  FUIF_AMD_LIB=fuif_amd/libfuifgpu_prof.so python tools/prof_kernel.py [n_streams]
+  tools/build_variant.sh prof -DFUIF_PROF ;  python tools/prof_kernel.py [n_streams [w h]]
 """
 import os
 import sys
@@ -11,13 +11,13 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("FUIF_AMD_LIB", os.path.join(ROOT, "fuif_amd", "libfuifgpu_prof.so"))
+os.environ.setdefault("FUIF_AMD_LIB", os.path.join(ROOT, "build", "libfuifgpu_prof.so"))   # tools/build_variant.sh prof -DFUIF_PROF
 import fuif_amd  # noqa: E402
 from bench import make_inputs  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (3840, 2160)
-inputs = make_inputs(min(n, 8), w, h, 3, 8, 1000, "/tmp/fuif_bench_cache")
+inputs = make_inputs(min(n, 8), w, h, 3, 8, 1000, os.environ.get("FUIF_BENCH_CACHE", "/tmp/fuif_bench_cache"))
 blobs = [inputs[i % len(inputs)][1] for i in range(n)]
 plan = fuif_amd.Plan(blobs[0])
 batch = fuif_amd.Batch(plan, n, sum(len(b) for b in blobs))
@@ -33,6 +33,9 @@ for k in range(7):
     print("  %-16s %8.1f cycles/symbol  %5.1f %%" % (names[k], c / nsym, 100 * c / tot))
 print("  %-16s %8.1f cycles/symbol (instrumented)" % ("total", tot / nsym))
 seg = prof[:, 7].mean()
-ss = batch.sched_stats()
+try:
+    ss = batch.sched_stats()
+except fuif_amd.FuifGpuError:
+    ss = np.zeros(8, np.uint64)   # a build without -DFUIF_STATS
 print("  run segments (pick-up to suspension / end): %.1f cycles/symbol; scheduler busy %.0f wavefront-seconds -> cycle counter at %.2f GHz" % (
     seg / nsym, float(ss[6]) / 1e8, (prof[:, 7].sum() / (float(ss[6]) / 1e8) / 1e9) if ss[6] else 0.0))
