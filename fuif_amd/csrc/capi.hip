@@ -439,6 +439,9 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
         b->scratch_waves = b->n_waves;
     }
     b->n_loaded = n_images;
+    if (getenv("FUIFGPU_VERBOSE"))
+        fprintf(stderr, "fuifgpu: %d images, %d tiles, %s configuration, %d persistent wavefronts (%d per SIMD), %d queues, context scheduler %s\n", n_images, b->n_tiles,
+                b->dense ? "dense" : "wide", b->n_waves, b->waves_per_simd, b->n_queues, b->sched ? "on" : "off");
     return FUIFGPU_OK;
 }
 
@@ -464,7 +467,8 @@ int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
         HIPCHK(hipMalloc((void **)&b->d_tile_log, sizeof(unsigned long long) * 4 * (size_t)b->n_tiles));
         b->tile_log_cap = b->n_tiles;
     }
-    P.tile_log = b->want_tile_log ? b->d_tile_log : nullptr;   // (only -DFUIF_STATS kernels write it)
+    P.tile_log = b->want_tile_log ? b->d_tile_log : nullptr;   // (only -DFUIF_STATS / -DFUIF_PROF / -DFUIF_TILELOG kernels write it)
+    if (P.tile_log) HIPCHK(hipMemsetAsync(b->d_tile_log, 0, sizeof(unsigned long long) * 4 * (size_t)b->n_tiles, st));   // the running time accumulates over a tile's run segments
     P.tiles = b->d_tiles; P.n_tiles = b->n_tiles; P.sched = b->sched; P.n_queues = b->n_queues;
     {
         uint32_t *w = b->d_sched;
@@ -659,7 +663,7 @@ int fuifgpu_batch_profile(fuifgpu_batch *b, uint64_t *out8_per_image) {
 // Only the -DFUIF_STATS build of the library records it (the release kernel carries no statistics): FUIFGPU_E_UNSUPPORTED otherwise.
 int fuifgpu_batch_tile_log(fuifgpu_batch *b, uint64_t *out4_per_tile, int cap, int *n_tiles) {
     if (!b || !n_tiles) return FUIFGPU_E_ARG;
-#ifndef FUIF_STATS
+#if !defined(FUIF_STATS) && !defined(FUIF_PROF) && !defined(FUIF_TILELOG)
     *n_tiles = 0;
     g_last_error = "fuifgpu_batch_tile_log: this build of libfuifgpu carries no scheduler statistics (build with -DFUIF_STATS)";
     return FUIFGPU_E_UNSUPPORTED;

@@ -60,6 +60,12 @@ namespace {
 #define DEV __device__ __forceinline__
 
 // -DFUIF_PROF: per-phase shader-cycle counters (s_memtime) written to DecodeParams::prof[img*8+k]
+// -DFUIF_PROF_BY_CHANNEL: the counters are summed per first channel of the tile over all images (row = channel) instead of per image
+#ifdef FUIF_PROF_BY_CHANNEL
+#define PROF_ROW first_c
+#else
+#define PROF_ROW img
+#endif
 #ifdef FUIF_PROF
 #define PROF_DECL unsigned long long prof_t0 = 0, prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define PROF_START() prof_t0 = __builtin_readcyclecounter()
@@ -147,6 +153,14 @@ DEV unsigned long long realtime() { return __builtin_amdgcn_s_memrealtime(); }  
 #define STATS(...) __VA_ARGS__
 #else
 #define STATS(...)
+#endif
+// the tile log alone (first start / end / running time of every tile) is also part of the -DFUIF_PROF and -DFUIF_TILELOG builds: it keeps
+// one value live across a tile, so that -- unlike the full statistics -- it compiles at 6 wavefronts per SIMD (hipcc 7.2 trips over
+// an odd-aligned 64-bit spill reload, 'Subtarget requires even aligned vector registers', when the pressure goes up)
+#if defined(FUIF_STATS) || defined(FUIF_PROF) || defined(FUIF_TILELOG)
+#define TLOG(...) __VA_ARGS__
+#else
+#define TLOG(...)
 #endif
 // A wait gives up (ST_STALLED, reported with ST_CORRUPT) when NOTHING in the launch has made progress for a long while:
 // every kStaleCheck polls the waiting wavefront looks at DecodeParams::heartbeat (bumped by every running tile every few
@@ -880,7 +894,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         tix &= ~kResume;
     }
     const Tile tile = P.tiles[tix];
-    STATS(const unsigned long long tile_t0 = realtime();)
+    TLOG(const unsigned long long tile_t0 = realtime();)
 #ifndef FUIF_EMU
     {
         // the few tiles that hold most of an image are its critical path: they get the issue slots first (s_setprio),
@@ -922,7 +936,6 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
     uint32_t ctx_leaves_units = 0;
     bool yielded = false;
     uint32_t yield_chan = 0, yield_val = 0, resume_y = 0;
-    STATS(uint32_t run_ticks0 = 0; unsigned long long tile_first = tile_t0;)
     if (resumed) {
         s.pos = rflu(rec->pos);
         const uint32_t fl = rflu(rec->flags);
@@ -930,7 +943,6 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         s.eof_flag = (int)((fl >> 8) & 1u);
         ctx_slot = rfl((int)rec->ctx);
         resume_y = rflu(rec->y);
-        STATS(run_ticks0 = rflu(rec->run_ticks); tile_first = ((unsigned long long)rflu(rec->t_first_hi) << 32) | rflu(rec->t_first_lo);)
         ctx_leaves_units = rflu(rec->ctx_leaves);
         can_yield = true;
         if (ctx_slot >= 0) {
@@ -952,6 +964,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
     };
     PROF_DECL;
 #ifdef FUIF_PROF
+    const unsigned long long prof_rt0 = realtime();   // slot 6: 100 MHz ticks of the run segment (against slot 7: the shader clock the segment ran at)
     const unsigned long long prof_seg0 = __builtin_readcyclecounter();   // slot 7: cycles of the whole run segment (pick-up to suspension / end)
 #endif
     // progress word of channel c: 1 = ChannelMeta valid, 1 + r = rows [0,r) final, 1 + h = plane final
@@ -1582,7 +1595,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                             PROF_START();
                             if (lane < nx) st_plane<kHandOff>(plane + (int64_t)y * w + x0 + lane, rowv);
                             __syncthreads();  // cprops is rewritten by the next chunk
-                            PROF_LAP(6);
+                            PROF_LAP(5);   // (the row store is counted with the rest of the pixel loop: slot 6 holds the segment's wall-clock ticks)
                         }
                         publish(i, (uint32_t)y + 2u);
                     }
@@ -1605,8 +1618,6 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 rec->range = rac.range; rec->low = rac.low; rec->pos = s.pos;
                 rec->flags = ((uint32_t)status & 0xFFu) | ((uint32_t)(s.eof_flag & 1) << 8) | ((uint32_t)predictor << 9);
                 rec->ctx = (uint32_t)ctx_slot; rec->ctx_leaves = ctx_leaves_units; rec->tree_size = (uint32_t)tree_size; rec->n_super = (uint32_t)n_super; rec->cur_leaf = (uint32_t)cur_leaf;
-                STATS(rec->t_first_lo = (uint32_t)tile_first; rec->t_first_hi = (uint32_t)(tile_first >> 32);
-                      rec->run_ticks = run_ticks0 + (uint32_t)(realtime() - tile_t0);)
                 rec->pin = ctx_slot >= 0 ? 0u : my_pin;
                 rec->owner = simd_key + 1u;
             }
@@ -1618,9 +1629,14 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         ci = endc;
     }
 #ifdef FUIF_PROF
-    if (yielded) prof_acc[7] += __builtin_readcyclecounter() - prof_seg0;
-    if (yielded && lane == 0 && P.prof) for (int k = 0; k < 8; k++) atomicAdd(&P.prof[(size_t)img * 8 + k], prof_acc[k]);   // (a suspended tile's laps count too)
+    if (yielded) { prof_acc[7] += __builtin_readcyclecounter() - prof_seg0; prof_acc[6] += realtime() - prof_rt0; }
+    if (yielded && lane == 0 && P.prof) for (int k = 0; k < 8; k++) atomicAdd(&P.prof[(size_t)PROF_ROW * 8 + k], prof_acc[k]);   // (a suspended tile's laps count too)
 #endif
+    TLOG(if (yielded && lane == 0 && P.tile_log) {
+        unsigned long long *tl = P.tile_log + (size_t)tix * 4;
+        if (!resumed) tl[1] = tile_t0;
+        tl[3] = (tl[3] + (realtime() - tile_t0)) & 0xFFFFFFFFFFFFull;
+    })
     if (yielded) { STATS(st_yields++;) __syncthreads(); continue; }   // the tile goes on later, on whichever wavefront picks it up
     if (s_limit_hit(s)) status |= ST_TRUNCATED;
     // The group index is untrusted input (a stale or crafted trailer): a tile that was decoded in full must have stopped
@@ -1651,20 +1667,21 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
             atomicAdd(P.done_total, 1u);
         }
     }
-#ifdef FUIF_STATS
+#if defined(FUIF_STATS) || defined(FUIF_PROF) || defined(FUIF_TILELOG)
     if (lane == 0 && P.tile_log) {
-        // waited = spinning for rows + suspended (first start .. end minus the time some wavefront was running the tile)
+        // {image << 32 | first channel, first start, end, ticks some wavefront was running the tile | CU key << 48}: the log keeps the
+        // first start and the running time itself (nothing extra stays live in registers across the tile)
         unsigned long long *tl = P.tile_log + (size_t)tix * 4;
         const unsigned long long t_end = realtime();
-        waited += (t_end - tile_first) - ((unsigned long long)run_ticks0 + (t_end - tile_t0));
         tl[0] = ((unsigned long long)(uint32_t)img << 32) | (uint32_t)first_c;
-        tl[1] = tile_first; tl[2] = t_end;
-        tl[3] = (waited & 0xFFFFFFFFFFFFull) | ((unsigned long long)simd_key << 48);
+        if (!resumed) tl[1] = tile_t0;
+        tl[2] = t_end;
+        tl[3] = ((tl[3] + (t_end - tile_t0)) & 0xFFFFFFFFFFFFull) | ((unsigned long long)simd_key << 48);
     }
 #endif
 #ifdef FUIF_PROF
-    prof_acc[7] += __builtin_readcyclecounter() - prof_seg0;
-    if (lane == 0 && P.prof) for (int k = 0; k < 8; k++) atomicAdd(&P.prof[(size_t)img * 8 + k], prof_acc[k]);
+    prof_acc[7] += __builtin_readcyclecounter() - prof_seg0; prof_acc[6] += realtime() - prof_rt0;
+    if (lane == 0 && P.prof) for (int k = 0; k < 8; k++) atomicAdd(&P.prof[(size_t)PROF_ROW * 8 + k], prof_acc[k]);
 #endif
     __syncthreads();
     }  // tile loop

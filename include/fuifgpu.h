@@ -125,12 +125,14 @@ int fuifgpu_batch_download_packed(fuifgpu_batch *batch, int image, int component
 /* kernel time of the last decode / undo_transforms launch set, measured with hipEvents on the
  * caller's stream (ms); used by bench.py for the roofline */
 int fuifgpu_batch_last_timing(fuifgpu_batch *batch, float *decode_ms, float *transform_ms);
-/* diagnostic builds (-DFUIF_PROF) only: 8 shader-cycle counters per stream of the last decode
- * {vector phase, property patch, tree walk, leaf switch, symbol decode, per-pixel rest, row store, -};
- * all zero in release builds */
+/* diagnostic builds (-DFUIF_PROF) only: 8 counters per stream of the last decode, shader cycles
+ * {vector phase, property patch, tree walk, leaf switch, symbol decode, per-pixel rest (incl. the row store),
+ * 100 MHz ticks of the run segments, shader cycles of the run segments}; all zero in release builds
+ * (-DFUIF_PROF_BY_CHANNEL: one row per first channel of a tile, summed over the images, instead of one per stream) */
 int fuifgpu_batch_profile(fuifgpu_batch *batch, uint64_t *out8_per_image);
-/* diagnostic: the schedule of the last decode launch, 4 words per tile of the work list {image << 32 | first channel,
- * start, end, ticks spent waiting for other tiles' rows | SIMD key << 48}, times in 100 MHz s_memrealtime ticks.
+/* diagnostic builds (-DFUIF_STATS or -DFUIF_PROF; FUIFGPU_E_UNSUPPORTED from the release library, whose kernel carries no
+ * statistics): the schedule of the last decode launch, 4 words per tile of the work list {image << 32 | first channel,
+ * first start, end, ticks some wavefront was running the tile | CU key << 48}, times in 100 MHz s_memrealtime ticks.
  * Logging starts with the first call (which returns *n_tiles = 0); tools/tile_timeline.py turns it into a report. */
 int fuifgpu_batch_tile_log(fuifgpu_batch *batch, uint64_t *out4_per_tile, int cap, int *n_tiles);
 /* diagnostic: counters of the tile scheduler for the last dense launch {ticks (100 MHz) wavefronts spent without work while

@@ -25,14 +25,15 @@ batch.upload(blobs)
 t0 = time.time(); batch.decode(); batch.sync(); dt = time.time() - t0
 prof = batch.profile().astype(np.float64)
 nsym = plan.info.coef_elems
-names = ["vector phase", "property patch", "tree walk", "leaf switch", "symbol decode", "pixel rest", "row store", "-"]
+names = ["vector phase", "property patch", "tree walk", "leaf switch", "symbol decode", "pixel rest"]
 print("streams %d  kernel %.2f s  -> %.3f us/symbol/stream" % (n, dt, dt / nsym * 1e6))
-tot = prof[:, :7].sum(axis=1).mean()
-for k in range(7):
+tot = prof[:, :6].sum(axis=1).mean()
+for k in range(6):
     c = prof[:, k].mean()
     print("  %-16s %8.1f cycles/symbol  %5.1f %%" % (names[k], c / nsym, 100 * c / tot))
 print("  %-16s %8.1f cycles/symbol (instrumented)" % ("total", tot / nsym))
 seg = prof[:, 7].mean()
+print("  shader clock during run segments: %.2f GHz (cycle counter against the 100 MHz real-time counter)" % (prof[:, 7].sum() / (prof[:, 6].sum() * 10.0)))
 try:
     ss = batch.sched_stats()
 except fuif_amd.FuifGpuError:

@@ -33,7 +33,8 @@ if os.environ.get("TILE_LOG_NPY"):
 img = (raw[:, 0] >> np.uint64(32)).astype(np.int64)
 ch = (raw[:, 0] & np.uint64(0xFFFFFFFF)).astype(np.int64)
 t0 = raw[:, 1].astype(np.float64); t1 = raw[:, 2].astype(np.float64)
-waited = (raw[:, 3] & np.uint64(0xFFFFFFFFFFFF)).astype(np.float64)
+running = (raw[:, 3] & np.uint64(0xFFFFFFFFFFFF)).astype(np.float64)   # ticks some wavefront was running the tile
+waited = (t1 - t0) - running                                             # suspended, or ready and not picked up yet
 key = (raw[:, 3] >> np.uint64(48)).astype(np.int64)
 base = t0.min()
 t0 = (t0 - base) / 1e5; t1 = (t1 - base) / 1e5; waited /= 1e5      # ms (100 MHz ticks)
@@ -54,7 +55,10 @@ for k, e in zip(key.tolist(), t1.tolist()):
     ends[k] = max(ends.get(k, 0.0), e)
 e = np.array(sorted(ends.values()))
 print("per-SIMD finish time: min %.0f  p10 %.0f  median %.0f  p90 %.0f  max %.0f ms" % (e.min(), np.percentile(e, 10), np.median(e), np.percentile(e, 90), e.max()))
-ss = batch.sched_stats()
+try:
+    ss = batch.sched_stats()
+except fuif_amd.FuifGpuError:   # a -DFUIF_TILELOG / -DFUIF_PROF build: the tile log without the scheduler counters
+    ss = np.zeros(8, np.uint64)
 print("scheduler: idle %.0f wavefront-seconds, picking %.0f, spinning inside tiles %.0f; %d pick-ups, %d suspensions, %d tiles without a context area" % (float(ss[0]) / 1e8, float(ss[3]) / 1e8, float(ss[4]) / 1e8, int(ss[1]), int(ss[2]), int(ss[5])))
 print("scheduler: busy (pick-up to next look) %.0f wavefront-seconds, wavefront lifetime %.0f" % (float(ss[6]) / 1e8, float(ss[7]) / 1e8))
 st, _ = batch.status()
