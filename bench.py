@@ -435,6 +435,50 @@ def run_streamed(args, wl, inputs, blobs, dev, dist, rank, world, W, H, C, BITS,
         raise SystemExit("PARITY FAILURE: decoded planes differ from the source pixels")
 
 
+def ensure_ranks(args):
+    """`--gpus N` means N ranks, one per GPU of this node.  Under an external launcher (the driver's `python -m
+    torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) WORLD_SIZE is already set and must agree; started as a
+    plain `python bench.py --gpus N` this process becomes that launcher: it re-runs itself under torch.distributed.run with
+    a free port on 127.0.0.1 and returns its exit code.  A mismatch is an error, never a silent one-GPU run."""
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    world = os.environ.get("WORLD_SIZE")
+    if world is not None:
+        if int(world) != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks: they must agree (one rank per GPU)" % (args.gpus, world))
+        return
+    if args.gpus == 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def launcher_selftest(args):
+    """what tests/test_bench_launcher.py runs on a machine without GPUs: the ranks ensure_ranks() started meet on gloo, agree on the
+    world size through a collective, and rank 0 prints it.  Not a measurement (no metric of BASELINE.json in the line)."""
+    import torch
+    from fuif_amd import dist as fd
+    rank, local_rank, world = fd.env_world()
+    dist = fd.init(backend="gloo")
+    n = torch.ones(1, dtype=torch.int64)
+    if dist is not None:
+        dist.all_reduce(n)
+        dist.barrier()
+    t = fd.max_over_ranks(0.001 * (rank + 1), dist, torch.device("cpu"))
+    if rank == 0:
+        print(json.dumps({"metric": "launcher-selftest", "n_gpus": int(n.item()), "world_size": world, "max_over_ranks_ok": abs(t - 0.001 * world) < 1e-9}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -456,7 +500,12 @@ def main():
                     help="images resident at a time (0 = the whole batch): the batch is streamed through ONE chunk-sized set of coefficient / "
                          "output slabs, chunk after chunk -- how C4 (256 x 8192x8192x4: 275 GB of coefficients alone) runs on one GPU")
     ap.add_argument("--cache", default=os.environ.get("FUIF_BENCH_CACHE", "/tmp/fuif_bench_cache"))
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="(tests) start the ranks as --gpus asks, meet on the gloo backend, print {\"n_gpus\": world} and stop: no decoding, no GPU")
     args = ap.parse_args()
+    ensure_ranks(args)
+    if args.launcher_selftest:
+        return launcher_selftest(args)
 
     import fuif_amd
     rank = int(os.environ.get("RANK", "0"))

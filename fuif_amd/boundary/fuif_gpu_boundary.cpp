@@ -27,6 +27,8 @@
 // expanded parameters) and keeps the device batch alive in a registry keyed by &image so that the
 // following image.undo_transforms() can run the inverse-transform schedule on the coefficients
 // that are still resident in HBM.
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -41,6 +43,14 @@
 #include "transform/transform.h"
 
 #include "fuifgpu.h"
+
+// The reference's DCT helpers (scan script, zig-zag table, default parameters) are definitions inside a header that
+// transform.cpp already instantiates; a second copy in a namespace of its own gives this file the reference's OWN
+// tables without a duplicate symbol (every header dct.h includes has been included above, so only its body lands here).
+namespace refdct {
+#include "transform/dct.h"
+#include "transform/subsample.h"
+}
 
 // the reference's CPU implementations, renamed at compile time (see Makefile)
 bool fuif_decode_file_cpu(const char *filename, Image &image, fuif_options options);
@@ -274,7 +284,7 @@ void fuifgpu_boundary_undo_transforms(Image *self, int keep) {
 // Transform::apply(image, inverse) -- transform/transform.cpp:48-63.  The reference's own definition is kept in the
 // link as Transform::apply_cpu (the Makefile compiles transform.cpp with -Dapply=apply_cpu, and this file too, so the
 // class declares it under that name here); the symbol Transform::apply is bound to the function below.  The INVERSE of
-// Squeeze, YCoCg and YCbCr runs on the MI355X through the single-transform entry points of the C-ABI: this is the path
+// Squeeze, YCoCg, YCbCr, DCT, Quantize and ChromaSubsample runs on the MI355X through the single-transform entry points of the C-ABI: this is the path
 // of Image::undo_transforms(keep != 0) (fuif.cpp:220,230, image.cpp:94-115 calls t.apply(*this, true) per transform),
 // while a plain undo_transforms() replays the whole chain on the planes that are still resident (above).  Everything
 // else -- forward transforms, the other inverses, an image a kernel precondition does not hold for -- goes to apply_cpu.
@@ -312,7 +322,11 @@ bool gpu_inv_color(Image &img, bool ycbcr) {
     if (!p0.put(c0) || !p1.put(c1) || !p2.put(c2)) return false;
     const int rc = ycbcr ? fuifgpu_inv_ycbcr(p0.d, p1.d, p2.d, w, h, c0.w, c1.w, c2.w, img.minval, img.maxval, nullptr)
                          : fuifgpu_inv_ycocg(p0.d, p1.d, p2.d, w, h, c0.w, c1.w, c2.w, img.maxval, nullptr);
-    return rc == FUIFGPU_OK && p0.get(c0) && p1.get(c1) && p2.get(c2);
+    if (rc != FUIFGPU_OK) return false;
+    Channel n0 = c0, n1 = c1, n2 = c2;    // all three or none
+    if (!p0.get(n0) || !p1.get(n1) || !p2.get(n2)) return false;
+    c0 = n0; c1 = n1; c2 = n2;
+    return true;
 }
 
 // transform/squeeze.h:363-388, inverse branch, with explicit parameters (after a decode they always are: meta_apply
@@ -337,13 +351,16 @@ bool gpu_inv_squeeze(Image &img, const std::vector<int> &par) {
             dims.erase(dims.begin() + offset, dims.begin() + offset + (endc - beginc + 1));
         }
     }
+    // (on a copy of the channel table: a step that fails -- allocation, upload, kernel -- must leave the image as it was, so that the
+    // caller's CPU twin, or the error it reports, sees the untouched input and not a half-unsqueezed one)
+    std::vector<Channel> work = img.channel;
     for (int i = (int)par.size() - 3; i >= 0; i -= 3) {
         const bool horizontal = par[i] & 1, in_place = !(par[i] & 2);
         const int beginc = par[i + 1], endc = par[i + 2];
         const int offset = in_place ? endc + 1 : img.nb_meta_channels + img.nb_channels;
         for (int c = beginc; c <= endc; c++) {
-            Channel &chin = img.channel[c];
-            Channel &res = img.channel[offset + c - beginc];
+            Channel &chin = work[c];
+            Channel &res = work[offset + c - beginc];
             if (res.data.size() == 0) res.resize();   // zero-filled residuals of a partial decode (squeeze.h:379-383)
             DevPlane a, r, o;
             if (!a.put(chin) || (res.w * res.h > 0 && !r.put(res))) return false;
@@ -355,10 +372,94 @@ bool gpu_inv_squeeze(Image &img, const std::vector<int> &par) {
             if (horizontal) rc = fuifgpu_inv_hsqueeze(a.d, chin.w, r.d, res.w, chin.h, o.d, 1, 0, 0, 0, nullptr);
             else rc = fuifgpu_inv_vsqueeze(a.d, chin.h, r.d, res.h, chin.w, o.d, 1, 0, 0, 0, nullptr);
             if (rc != FUIFGPU_OK || !o.get(out)) return false;
-            img.channel[c] = out;
+            work[c] = out;
         }
-        img.channel.erase(img.channel.begin() + offset, img.channel.begin() + offset + (endc - beginc + 1));
+        work.erase(work.begin() + offset, work.begin() + offset + (endc - beginc + 1));
     }
+    img.channel.swap(work);
+    return true;
+}
+
+// transform/quantize.h:32-49
+bool gpu_inv_quantize(Image &img) {
+    std::vector<Channel> work = img.channel;
+    for (size_t c = (size_t)img.nb_meta_channels; c < work.size(); c++) {
+        Channel &ch = work[c];
+        if (ch.data.size() == 0) continue;
+        const int q = ch.q;
+        if (q == 1) continue;
+        DevPlane p;
+        if (!p.put(ch) || fuifgpu_inv_quantize(p.d, (int64_t)p.n, q, nullptr) != FUIFGPU_OK || !p.get(ch)) return false;
+        ch.minval *= q;     // (pixel_type arithmetic, as in the reference)
+        ch.maxval *= q;
+        ch.q = 1;
+    }
+    img.channel.swap(work);
+    return true;
+}
+
+// transform/dct.h:249-296.  The 64 coefficient planes of a component must share the block grid (they do in every stream an
+// encoder writes: meta_DCT gives them one geometry); anything else is left to the reference's own loop.
+bool gpu_inv_dct(Image &img, std::vector<int> par) {
+    if (par.empty()) refdct::default_DCT_parameters(par, img);
+    if (par.size() < 2) return false;
+    const int beginc = img.nb_meta_channels + par[0], endc = img.nb_meta_channels + par[1];
+    const int nb = endc - beginc + 1;
+    const int offset = (int)img.channel.size() - 63 * nb;
+    if (nb < 1 || beginc < 0 || offset <= endc) return false;
+    std::vector<std::vector<int>> ordering;
+    std::vector<int> comp, coeff;
+    refdct::default_DCT_scanscript(nb, ordering, comp, coeff);
+    std::vector<Channel> work = img.channel;
+    for (int c = beginc; c <= endc; c++) {
+        int bw = img.channel[c - beginc + offset].w, bh = img.channel[c - beginc + offset].h;
+        if (img.channel[c].w < bw) bw = img.channel[c].w;
+        if (img.channel[c].h < bh) bh = img.channel[c].h;
+        if (bw < 1 || bh < 1) return false;
+        std::vector<DevPlane> planes(64);
+        const int32_t *src[64];
+        for (int i = 0; i < 64; i++) {
+            const Channel &sc = img.channel[i == 0 ? c : offset - nb + ordering[c - beginc][refdct::jpeg_zigzag[i]]];
+            if (sc.w != bw || sc.h < bh || sc.data.size() < (size_t)sc.w * sc.h) return false;
+            if (!planes[i].put(sc)) return false;
+            src[i] = planes[i].d;
+        }
+        DevPlane o;
+        if (!o.alloc((size_t)bw * 8 * bh * 8)) return false;
+        if (fuifgpu_idct8x8(src, bw, bh, o.d, img.maxval, nullptr) != FUIFGPU_OK) return false;
+        Channel outch(bw * 8, bh * 8, 0, 0);
+        outch.component = img.channel[c].component;
+        outch.hshift = img.channel[c].hshift - 3;
+        outch.vshift = img.channel[c].vshift - 3;
+        outch.hcshift = img.channel[c].hcshift - 3;
+        outch.vcshift = img.channel[c].hcshift - 3;   // (sic: dct.h:278 takes hcshift for both)
+        if (!o.get(outch)) return false;
+        work[c] = outch;
+    }
+    work.erase(work.begin() + offset, work.begin() + offset + nb * 63);
+    img.channel.swap(work);
+    return true;
+}
+
+// transform/subsample.h:73-127, the "fancy" factors 1 and 2 (the box filter of larger factors stays with the reference's loop)
+bool gpu_inv_subsample(Image &img, std::vector<int> par) {
+    refdct::check_subsample_parameters(par);
+    std::vector<Channel> work = img.channel;
+    for (size_t i = 0; i + 3 < par.size(); i += 4) {
+        const int c1 = par[i], c2 = par[i + 1], srh = par[i + 2], srv = par[i + 3];
+        if (c1 < 0 || c2 >= (int)work.size() || srh < 1 || srv < 1 || srh > 2 || srv > 2) return false;
+        for (int c = c1; c <= c2; c++) {
+            const int ow = work[c].w, oh = work[c].h;
+            if (ow >= work[img.nb_meta_channels].w && oh >= work[img.nb_meta_channels].h) continue;   // subsample.h:87-91
+            if (ow < 1 || oh < 1) return false;
+            DevPlane in, out;
+            Channel up(ow * srh, oh * srv, work[c].minval, work[c].maxval);
+            if (!in.put(work[c]) || !out.alloc((size_t)up.w * up.h)) return false;
+            if (fuifgpu_upsample(in.d, ow, oh, srh, srv, out.d, nullptr) != FUIFGPU_OK || !out.get(up)) return false;
+            work[c] = up;
+        }
+    }
+    img.channel.swap(work);
     return true;
 }
 }  // namespace
@@ -366,17 +467,27 @@ bool gpu_inv_squeeze(Image &img, const std::vector<int> &par) {
 bool fuifgpu_boundary_transform_apply(Transform *self, Image &input, bool inverse) __asm__("_ZN9Transform5applyER5Imageb");
 bool fuifgpu_boundary_transform_apply(Transform *self, Image &input, bool inverse) {
     if (inverse && !env_flag("FUIFGPU_CPU_TRANSFORMS")) {
-        bool done = false;
+        bool done = false, claimed = true;
         switch (self->ID) {
             case TRANSFORM_YCoCg: done = gpu_inv_color(input, false); break;
             case TRANSFORM_YCbCr: done = gpu_inv_color(input, true); break;
             case TRANSFORM_SQUEEZE: done = gpu_inv_squeeze(input, self->parameters); break;
-            default: break;
+            case TRANSFORM_DCT: done = gpu_inv_dct(input, self->parameters); break;
+            case TRANSFORM_QUANTIZE: done = gpu_inv_quantize(input); break;
+            case TRANSFORM_ChromaSubsample: done = gpu_inv_subsample(input, self->parameters); break;
+            default: claimed = false; break;
         }
         if (done) {
             if (env_flag("FUIFGPU_VERBOSE")) fprintf(stderr, "fuifgpu: inverse %s on the GPU (Transform::apply)\n", self->name());
             return true;
         }
+        // a transform this layer binds, on an image its kernels do not take (or a device error): the image is untouched (every
+        // gpu_inv_* works on a copy), so the reference's own loop can run -- unless the caller asked for the GPU path or nothing
+        if (claimed && env_flag("FUIFGPU_NO_CPU_FALLBACK")) {
+            e_printf("fuifgpu: inverse %s could not run on the GPU (%s) and FUIFGPU_NO_CPU_FALLBACK is set\n", self->name(), fuifgpu_last_error());
+            return false;
+        }
+        if (claimed && env_flag("FUIFGPU_VERBOSE")) fprintf(stderr, "fuifgpu: inverse %s with the reference's CPU code (Transform::apply)\n", self->name());
     }
     return self->apply(input, inverse);   // macro-renamed: Transform::apply_cpu, the reference's own dispatcher
 }

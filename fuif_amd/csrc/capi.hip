@@ -765,6 +765,12 @@ int fuifgpu_inv_ycocg(int32_t *c0, int32_t *c1, int32_t *c2, int w, int h, int p
 int fuifgpu_inv_ycbcr(int32_t *c0, int32_t *c1, int32_t *c2, int w, int h, int p0, int p1, int p2, int minval, int maxval, void *stream) {
     return color_raw(OP_YCBCR, c0, c1, c2, w, h, p0, p1, p2, minval, maxval, stream);
 }
+int fuifgpu_inv_quantize(int32_t *plane, int64_t n_samples, int q, void *stream) {
+    if (!plane || n_samples < 0) return FUIFGPU_E_ARG;
+    launch_scale(plane, n_samples, q, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return FUIFGPU_OK;
+}
 int fuifgpu_idct8x8(const int32_t *const *src64, int bw, int bh, int32_t *out, int maxval, void *stream) {
     if (!src64 || !out || bw < 1 || bh < 1) return FUIFGPU_E_ARG;
     // planes are addressed as element offsets from a null base: every plane pointer is 4-byte aligned

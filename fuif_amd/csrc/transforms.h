@@ -25,6 +25,7 @@ void launch_pack(const Bases &b, const PackedPlanes &pp, int w, int h, int lo, i
 
 // forward YCoCg (in place, three contiguous planes of n samples) and forward Squeeze of one plane (transform/ycocg.h:65-95,
 // transform/squeeze.h:135-170,227-263): raw device pointers, the writer's optional GPU path
+void launch_scale(int32_t *plane, int64_t n, int q, hipStream_t stream);   // transform/quantize.h:32-49 on one plane
 void launch_fwd_ycocg(int32_t *c0, int32_t *c1, int32_t *c2, int64_t n, hipStream_t stream);
 void launch_fwd_squeeze(bool horizontal, const int32_t *in, int w, int h, int32_t *avg, int32_t *res, hipStream_t stream);
 

@@ -19,6 +19,7 @@
 //   k_pack_samples   export/write_pam.h:136-150    interleaved 8/16-bit samples of the final planes (what a PNM/PAM holds)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -534,6 +535,13 @@ __global__ __launch_bounds__(256) void k_fwd_vsqueeze(const int32_t *in, int w, 
     else if (h & 1) next = in[(int64_t)(2 * y + 2) * w + x];
     const int top = y > 0 ? in[(int64_t)(2 * y - 1) * w + x] : a;
     res[(int64_t)y * w + x] = (A - B) - smooth_tendency(top, a, next);
+}
+__global__ __launch_bounds__(256) void k_scale(int32_t *d, int64_t n, int q) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] *= q;
+}
+void launch_scale(int32_t *plane, int64_t n, int q, hipStream_t stream) {
+    if (n <= 0 || q == 1) return;
+    hipLaunchKernelGGL(k_scale, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65535)), dim3(256), 0, stream, plane, n, q);
 }
 void launch_fwd_ycocg(int32_t *c0, int32_t *c1, int32_t *c2, int64_t n, hipStream_t stream) {
     hipLaunchKernelGGL(k_fwd_ycocg, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c0, c1, c2, n);

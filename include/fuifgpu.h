@@ -170,8 +170,9 @@ int fuifgpu_dev_download(void *dst_host, const void *src_device, size_t bytes); 
 
 /* ---- single-transform entry points on raw device planes (row-major int32) ------------------
  * These are what Transform::apply(image, true) (transform/transform.cpp:48-63) dispatches to in the C++ boundary
- * layer (fuif_amd/boundary/fuif_gpu_boundary.cpp binds Transform::apply for Squeeze, YCoCg and YCbCr inverses to them:
- * the path of Image::undo_transforms(keep != 0)); tests/test_gpu_transform_exports.py checks each against the oracle. */
+ * layer (fuif_amd/boundary/fuif_gpu_boundary.cpp binds Transform::apply for the Squeeze, YCoCg, YCbCr, DCT, Quantize and
+ * ChromaSubsample inverses to them: the path of Image::undo_transforms(keep != 0)); tests/test_gpu_transform_exports.py
+ * checks each against the oracle. */
 /* transform/squeeze.h:81-132 inv_hsqueeze: avg w1 x h + residual w2 x h -> out (w1+w2) x h */
 int fuifgpu_inv_hsqueeze(const int32_t *avg, int w1, const int32_t *res, int w2, int h, int32_t *out, int n_planes,
                          int64_t avg_stride, int64_t res_stride, int64_t out_stride, void *stream);
@@ -182,6 +183,8 @@ int fuifgpu_inv_vsqueeze(const int32_t *avg, int h1, const int32_t *res, int h2,
 int fuifgpu_inv_ycocg(int32_t *c0, int32_t *c1, int32_t *c2, int w, int h, int p0, int p1, int p2, int maxval, void *stream);
 /* transform/ycbcr.h:33-63 inv_YCbCr */
 int fuifgpu_inv_ycbcr(int32_t *c0, int32_t *c1, int32_t *c2, int w, int h, int p0, int p1, int p2, int minval, int maxval, void *stream);
+/* transform/quantize.h:32-49 inv_quantize of one plane: every sample times the channel's quantisation constant, in place */
+int fuifgpu_inv_quantize(int32_t *plane, int64_t n_samples, int q, void *stream);
 /* transform/dct.h:88-107 + 282-291: 64 coefficient planes (bw x bh each, src[i] in the
  * reference's own zig-zag position order i=0..63) -> (8bw) x (8bh) samples; DC offset (maxval+1)*4 */
 int fuifgpu_idct8x8(const int32_t *const *src64_dev, int bw, int bh, int32_t *out, int maxval, void *stream);

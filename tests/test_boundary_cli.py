@@ -117,7 +117,12 @@ def test_reference_cli_yuv_output_uses_the_per_transform_binding(tmp_path):
     a, b = str(tmp_path / "gpu.yuv"), str(tmp_path / "ref.yuv")
     r = run_cli(["-d", src, a])
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "inverse Squeeze on the GPU (Transform::apply)" in r.stderr
+    # undo_transforms(2) keeps the colour transform and the chroma subsampling: Squeeze, Quantization and DCT are undone, each
+    # through its GPU entry point (the CLI runs with FUIFGPU_NO_CPU_FALLBACK=1: a transform this layer binds may not fall
+    # back to the reference's loop silently)
+    for name in ("Squeeze", "Quantization", "DCT"):
+        assert "inverse %s on the GPU (Transform::apply)" % name in r.stderr, r.stderr
+    assert "with the reference's CPU code" not in r.stderr
     rb = subprocess.run([ref_cli, "-d", src, b], env=env, capture_output=True, text=True, timeout=300)
     assert rb.returncode == 0
     assert open(a, "rb").read() == open(b, "rb").read()

@@ -145,12 +145,13 @@ def test_reference_cli_through_the_boundary_writes_the_reference_files(tmp_path)
             assert ra.returncode == rb.returncode == 0, (name, extra, ra.stderr[-300:], rb.stderr[-300:])
             assert open(a, "rb").read() == open(b, "rb").read(), (name, extra)
     # `-d x.fuif out.yuv` keeps the colour transform and the chroma subsampling: Image::undo_transforms(2) (fuif.cpp:230),
-    # i.e. Transform::apply(image, true) per transform -- the Squeeze inverse through the boundary's binding to
-    # fuifgpu_inv_hsqueeze / fuifgpu_inv_vsqueeze, Quantize and DCT through the reference's own code
+    # i.e. Transform::apply(image, true) per transform -- Squeeze, Quantization and DCT inverses through the boundary's binding to
+    # fuifgpu_inv_hsqueeze / fuifgpu_inv_vsqueeze / fuifgpu_inv_quantize / fuifgpu_idct8x8
     src = os.path.join(ROOT, "tests", "golden", "jpeg420_256x192_q90.fuif")
     a, b = str(tmp_path / "gpu.yuv"), str(tmp_path / "ref.yuv")
     ra = subprocess.run([gpu_cli, "-d", src, a], env=dict(env_gpu, FUIFGPU_VERBOSE="1"), capture_output=True, text=True, timeout=600)
     rb = subprocess.run([ref_cli, "-d", src, b], env=env, capture_output=True, text=True, timeout=600)
     assert ra.returncode == rb.returncode == 0, (ra.stderr[-300:], rb.stderr[-300:])
-    assert "inverse Squeeze on the GPU (Transform::apply)" in ra.stderr
+    for tname in ("Squeeze", "Quantization", "DCT"):
+        assert "inverse %s on the GPU (Transform::apply)" % tname in ra.stderr, ra.stderr
     assert open(a, "rb").read() == open(b, "rb").read()

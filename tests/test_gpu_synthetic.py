@@ -33,7 +33,11 @@ def test_writer_streams_match_oracle(gpulib, port, w, h, c, bits, ycocg):
     blob = gpulib.encode_image(img, bits, ycocg=ycocg, tree_mode=1)
     pre, post, st, used = gpu_decode(gpulib, [blob])
     d_pre, d_post = port.decode_both(blob)
-    assert st[0] == 0 and used[0] == d_pre.stats["bytes"] if d_pre.stats else True
+    # status and the bytes the decoder consumed against the oracle's own count (decode_both() carries no statistics:
+    # round 2 guarded this line with `if d_pre.stats`, which made it assert nothing)
+    consumed = port.decode(blob, want_data=False).stats["bytes"]
+    assert st[0] == 0
+    assert used[0] == consumed == len(blob)
     for g, e in zip(pre[0], d_pre.channels):
         assert np.array_equal(g, e["data"])
     assert len(post[0]) == len(d_post.channels)
@@ -102,6 +106,37 @@ def test_jpeg_like_dct_path_matches_oracle(gpulib, port, w, h, c, sub):
         assert len(planes) == len(d_post.channels)
         for g, e in zip(planes, d_post.channels):
             assert np.array_equal(g, e["data"])
+
+
+def test_c4_shape_at_4096_matches_oracle(gpulib, port):
+    """BASELINE config C4's shape at a quarter of its area, in the routine -m gpu set: ONE 4096x4096, 4-channel, 14-bit,
+    Squeeze-only lossless stream with the group index (67 M symbols; the trees reach the depth and the leaf counts of the full-size
+    case: the writer caps them at 4095 nodes either way), every coded plane and every output plane against the CPU oracle.
+    About a minute, most of it the writer and the oracle on the host."""
+    w = h = 4096
+    img = photographic(w, h, 4, 14, seed=4096)
+    blob = gpulib.encode_image(img, 14, ycocg=False, tree_mode=1, index=True)
+    plan = gpulib.Plan(blob)
+    batch = gpulib.Batch(plan, 1, len(blob))
+    try:
+        batch.upload([blob])
+        batch.decode()
+        batch.sync()
+        st, used = batch.status()
+        assert st[0] == 0
+        pre = batch.coef_planes(0)
+        batch.undo_transforms()
+        batch.sync()
+        post = batch.out_planes(0)
+    finally:
+        batch.close()
+    d_pre, d_post = port.decode_both(blob)    # (10.7 tree steps per symbol on this picture)
+    for g, e in zip(pre, d_pre.channels):
+        assert np.array_equal(g, e["data"])
+    for g, e in zip(post, d_post.channels):
+        assert np.array_equal(g, e["data"])
+    for k in range(4):
+        assert np.array_equal(post[k], img[k])
 
 
 def test_c4_full_size_image_matches_oracle(gpulib, port):

@@ -1,5 +1,5 @@
 """GPU parity (-m gpu) of the single-transform entry points of the C-ABI (include/fuifgpu.h: fuifgpu_inv_hsqueeze,
-fuifgpu_inv_vsqueeze, fuifgpu_inv_ycocg, fuifgpu_inv_ycbcr, fuifgpu_idct8x8, fuifgpu_upsample) -- what
+fuifgpu_inv_vsqueeze, fuifgpu_inv_ycocg, fuifgpu_inv_ycbcr, fuifgpu_inv_quantize, fuifgpu_idct8x8, fuifgpu_upsample) -- what
 Transform::apply(image, true) (transform/transform.cpp:48-63) dispatches to in the boundary layer.
 
 Each is run on raw device planes (random, incl. negative values, odd and tiny sizes, several planes per launch) and
@@ -180,6 +180,17 @@ def test_idct_known_answer(glib, olib):
     got = d_out.get().reshape(8, 8)
     assert got[0].tolist() == [117, 116, 116, 114, 112, 109, 106, 105]
     assert got[7].tolist() == [119, 120, 120, 120, 118, 117, 115, 114]
+
+
+@pytest.mark.parametrize("n,q", [(1, 7), (1000, 3), (257 * 33, 16), (5, 1)])
+def test_inv_quantize_export(glib, n, q):
+    """transform/quantize.h:32-49: every sample of the plane times Channel::q (the reference's loop is a plain multiply)"""
+    rng = np.random.default_rng(n + q)
+    a = rng.integers(-2000, 2000, n).astype(np.int32)
+    d = Dev(a)
+    assert glib.fuifgpu_inv_quantize(d.ptr, n, q, None) == 0
+    _sync()
+    assert np.array_equal(d.get(), a * q)
 
 
 @pytest.mark.parametrize("w,h,srh,srv", [(1, 1, 2, 2), (5, 3, 2, 2), (64, 17, 2, 1), (33, 40, 1, 2), (240, 135, 2, 2)])
