@@ -202,6 +202,109 @@ bool fuif_decode_file(const char *filename, Image &image, fuif_options options) 
     return fuif_decode(fio, image, options);
 }
 
+void fuifgpu_boundary_undo_transforms(Image *self, int keep) __asm__("_ZN5Image15undo_transformsEi");
+
+// ---- the batch entry (fuifgpu_boundary.h) ----------------------------------------------------------------------------
+#include "fuifgpu_boundary.h"
+namespace {
+// what Image::undo_transforms() leaves behind, from the output planes of image `index` of a batch (the single-image path below
+// builds the same thing)
+void image_from_outputs(Image &img, fuifgpu_plan *plan, fuifgpu_batch *batch, int index, const fuifgpu_image_info &info) {
+    img = Image(info.w, info.h, info.maxval, info.nb_channels, info.colormodel);
+    std::vector<int32_t> slab((size_t)(info.out_elems > 0 ? info.out_elems : 1));
+    fuifgpu_batch_download_out(batch, index, slab.data(), nullptr);
+    std::vector<Channel> outch;
+    for (int c = 0; c < info.nb_output_channels; c++) {
+        fuifgpu_channel_desc d;
+        fuifgpu_plan_output_channel(plan, c, &d);
+        Channel ch(d.w, d.h, (pixel_type)img.minval, (pixel_type)img.maxval, 1, d.hshift, d.vshift, d.hcshift, d.vcshift);
+        ch.component = d.component;
+        const size_t n = (size_t)d.w * d.h;
+        for (size_t i = 0; i < n; i++) ch.data[i] = (pixel_type)slab[(size_t)d.offset + i];
+        outch.push_back(ch);
+    }
+    img.channel = outch;
+    img.nb_meta_channels = 0;
+    img.nb_channels = (int)outch.size();
+    img.transform.clear();
+    img.error = false;
+}
+bool cpu_decode_whole(const std::vector<uint8_t> &bytes, Image &img, const fuif_options &options) {
+    BlobReader io(bytes.data(), bytes.size());
+    if (!fuif_decode_cpu(io, img, options)) return false;
+    img.undo_transforms(0);   // (macro-renamed: the reference's CPU implementation)
+    return !img.error;
+}
+}  // namespace
+
+int fuif_decode_files(const char *const *filenames, int n_files, Image *images, fuif_options options, bool *ok_out) {
+    if (!filenames || !images || n_files < 1) return 0;
+    const bool verbose = env_flag("FUIFGPU_VERBOSE"), no_cpu = env_flag("FUIFGPU_NO_CPU_FALLBACK");
+    std::vector<std::vector<uint8_t>> bytes((size_t)n_files);
+    std::vector<fuifgpu_plan *> plans((size_t)n_files, nullptr);
+    std::vector<char> ok((size_t)n_files, 0), cpu_route((size_t)n_files, 0);
+    std::map<uint64_t, std::vector<int>> groups;   // plan signature -> files
+    for (int i = 0; i < n_files; i++) {
+        FILE *f = fopen(filenames[i], "rb");
+        if (!f) { e_printf("Could not open %s\n", filenames[i]); continue; }
+        FileIO io(f, filenames[i]);
+        bytes[i] = slurp(io);
+        const int rc = fuifgpu_plan_create(bytes[i].data(), bytes[i].size(), &plans[i]);
+        if (rc == FUIFGPU_E_UNSUPPORTED) { cpu_route[i] = 1; continue; }
+        if (rc != FUIFGPU_OK) { e_printf("%s: %s (%s)\n", filenames[i], fuifgpu_strerror(rc), fuifgpu_last_error()); continue; }
+        fuifgpu_image_info info;
+        fuifgpu_plan_info(plans[i], &info);
+        if (info.nb_frames > 1) { cpu_route[i] = 2; continue; }   // animations go one by one through fuif_decode (timing header)
+        groups[info.signature].push_back(i);
+    }
+    for (auto &g : groups) {
+        const std::vector<int> &idx = g.second;
+        fuifgpu_plan *plan = plans[idx[0]];
+        fuifgpu_image_info info;
+        fuifgpu_plan_info(plan, &info);
+        size_t total = 0;
+        std::vector<const uint8_t *> ptr;
+        std::vector<size_t> len;
+        for (int i : idx) { ptr.push_back(bytes[i].data()); len.push_back(bytes[i].size()); total += bytes[i].size(); }
+        fuifgpu_batch *batch = nullptr;
+        int rc = fuifgpu_batch_create(plan, (int)idx.size(), total, nullptr, nullptr, 0, &batch);
+        if (rc == FUIFGPU_OK) rc = fuifgpu_batch_upload(batch, ptr.data(), len.data(), (int)idx.size(), options.preview, nullptr);
+        if (rc == FUIFGPU_OK) rc = fuifgpu_batch_decode(batch, nullptr);
+        if (rc == FUIFGPU_OK) rc = fuifgpu_batch_undo_transforms(batch, nullptr);
+        if (rc == FUIFGPU_OK) rc = fuifgpu_batch_sync(batch, nullptr);
+        if (rc != FUIFGPU_OK) {
+            e_printf("fuifgpu: %s (%s)\n", fuifgpu_strerror(rc), fuifgpu_last_error());
+            if (batch) fuifgpu_batch_destroy(batch);
+            continue;
+        }
+        std::vector<int32_t> status(idx.size(), 0);
+        fuifgpu_batch_status(batch, status.data(), nullptr);
+        for (size_t k = 0; k < idx.size(); k++) {
+            const int i = idx[k];
+            if (status[k] & FUIFGPU_ST_UNSUPPORTED) { cpu_route[i] = 1; continue; }
+            if (status[k] & FUIFGPU_ST_CORRUPT) { e_printf("%s: corruption detected.\n", filenames[i]); continue; }
+            image_from_outputs(images[i], plan, batch, (int)k, info);
+            ok[i] = 1;
+        }
+        if (verbose) fprintf(stderr, "fuifgpu: %d file(s) of %dx%d decoded in one batch on the GPU\n", (int)idx.size(), info.w, info.h);
+        fuifgpu_batch_destroy(batch);
+    }
+    for (int i = 0; i < n_files; i++) {
+        if (cpu_route[i] == 2) {   // an animation: the single-file path (GPU as well)
+            BlobReader io(bytes[i].data(), bytes[i].size());
+            if (fuif_decode(io, images[i], options)) { fuifgpu_boundary_undo_transforms(&images[i], 0); ok[i] = !images[i].error; }
+        } else if (cpu_route[i] == 1) {
+            if (no_cpu) { e_printf("fuifgpu: %s needs a feature outside the GPU path and FUIFGPU_NO_CPU_FALLBACK is set\n", filenames[i]); continue; }
+            if (verbose) fprintf(stderr, "fuifgpu: %s is outside the GPU path, decoding with the reference's CPU code\n", filenames[i]);
+            ok[i] = cpu_decode_whole(bytes[i], images[i], options) ? 1 : 0;
+        }
+        if (plans[i]) fuifgpu_plan_destroy(plans[i]);
+    }
+    int n_ok = 0;
+    for (int i = 0; i < n_files; i++) { n_ok += ok[i]; if (ok_out) ok_out[i] = ok[i] != 0; }
+    return n_ok;
+}
+
 // Image::undo_transforms(int) -- exported under the member's Itanium-ABI name.  This file is compiled
 // with -Dundo_transforms=undo_transforms_cpu (like image.cpp), so inside this translation unit the class
 // declares the reference's CPU implementation as Image::undo_transforms_cpu, and the GPU version is a

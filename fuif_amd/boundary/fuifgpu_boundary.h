@@ -1,0 +1,15 @@
+// fuif_amd/boundary/fuifgpu_boundary.h -- the one entry point the binding ADDS to the reference's decode interface.
+//
+// The reference decodes one file per call: fuif_decode_file(filename, image, options) followed by image.undo_transforms()
+// (encoding/encoding.cpp:745-753, fuif.cpp:213-233).  One file is one launch of a few dozen wavefronts on a device that holds
+// 6144 -- the MI355X path is built for batches.  fuif_decode_files() is the batch form of those two calls: N files in, N
+// finished Images out (entropy decode AND the whole inverse-transform chain), files of equal geometry and transform chain
+// sharing one fuifgpu_batch, i.e. one k_maniac_decode launch.  Everything else about an Image is as fuif_decode_file +
+// undo_transforms leave it, so the reference's writers (export/write_pam.h ...) take it unchanged.
+#pragma once
+#include "encoding/encoding.h"
+#include "image/image.h"
+
+// images[i] receives file i; ok[i] (optional) says whether it decoded.  Returns the number of files decoded.
+// A file outside the GPU scope is decoded by the reference's own code unless FUIFGPU_NO_CPU_FALLBACK is set.
+int fuif_decode_files(const char *const *filenames, int n_files, Image *images, fuif_options options, bool *ok = nullptr);

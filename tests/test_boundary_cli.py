@@ -126,3 +126,41 @@ def test_reference_cli_yuv_output_uses_the_per_transform_binding(tmp_path):
     rb = subprocess.run([ref_cli, "-d", src, b], env=env, capture_output=True, text=True, timeout=300)
     assert rb.returncode == 0
     assert open(a, "rb").read() == open(b, "rb").read()
+
+
+@pytest.mark.gpu
+def test_batch_entry_decodes_many_files_in_one_launch(tmp_path):
+    """fuif_decode_files (fuif_amd/boundary/fuifgpu_boundary.h), the batch form of fuif_decode_file + undo_transforms, through its
+    many-files front end: 40 files of one geometry and three others in ONE invocation; the files of one geometry share a
+    launch (reported on stderr) and every output equals what the unmodified reference CLI writes for that file"""
+    need_cli()
+    import shutil
+    batch_cli = os.path.join(ROOT, "fuif_amd", "boundary", "_build", "fuif_gpu_batch")
+    ref_cli = os.path.join(ROOT, "oracle", "_ref", "fuif")
+    if not (os.path.exists(batch_cli) and os.path.exists(ref_cli)):
+        pytest.skip("fuif_gpu_batch / oracle/_ref/fuif not built")
+    env = dict(os.environ)
+    if os.path.exists("/opt/conda/lib/libjpeg.so.9"):
+        env["LD_PRELOAD"] = "/opt/conda/lib/libjpeg.so.9"
+    outdir = tmp_path / "out"
+    outdir.mkdir()
+    files = []
+    for k in range(40):
+        p = tmp_path / ("c1_%02d.fuif" % k)
+        shutil.copy(os.path.join(GOLDEN, "c1_rgb8_512x512.fuif"), p)
+        files.append(str(p))
+    others = ["jpeg420_256x192_q90", "pal_rgb_graphic_120x90", "rgba14_80x72"]
+    files += [os.path.join(GOLDEN, n + ".fuif") for n in others]
+    r = subprocess.run([batch_cli, str(outdir)] + files, env=dict(env, FUIFGPU_VERBOSE="1", FUIFGPU_NO_CPU_FALLBACK="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-800:]
+    assert "40 file(s) of 512x512 decoded in one batch on the GPU" in r.stderr
+    expect = {}
+    for src in [files[0]] + files[40:]:
+        b = str(tmp_path / "ref.pam")
+        rb = subprocess.run([ref_cli, "-d", src, b], env=env, capture_output=True, text=True, timeout=300)
+        assert rb.returncode == 0
+        expect[os.path.basename(src)[:-5]] = open(b, "rb").read()
+    for k in range(40):
+        assert open(str(outdir / ("c1_%02d.pam" % k)), "rb").read() == expect["c1_00"]
+    for n in others:
+        assert open(str(outdir / (n + ".pam")), "rb").read() == expect[n], n

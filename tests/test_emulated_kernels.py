@@ -144,6 +144,25 @@ def test_reference_cli_through_the_boundary_writes_the_reference_files(tmp_path)
             rb = subprocess.run([ref_cli, "-d"] + extra + [src, b], env=env, capture_output=True, text=True, timeout=600)
             assert ra.returncode == rb.returncode == 0, (name, extra, ra.stderr[-300:], rb.stderr[-300:])
             assert open(a, "rb").read() == open(b, "rb").read(), (name, extra)
+    # the batch entry of the binding (fuif_decode_files, fuifgpu_boundary.h) through its many-files front end: files of three
+    # geometries, two of them twice, one launch per geometry; every output file equal to the unmodified CLI's
+    batch_cli = os.path.join(ROOT, "fuif_amd", "boundary", "_build", "fuif_gpu_batch")
+    if os.path.exists(batch_cli):
+        outdir = tmp_path / "batch"
+        outdir.mkdir()
+        picks = ["rgb8_97x61", "jpeg420_256x192_q90", "pal_rgb_graphic_120x90", "rgba14_80x72"]
+        files = [os.path.join(ROOT, "tests", "golden", n + ".fuif") for n in picks]
+        dup = tmp_path / "rgb8_97x61_again.fuif"
+        shutil.copy(files[0], dup)
+        ra = subprocess.run([batch_cli, str(outdir)] + files + [str(dup)], env=dict(env_gpu, FUIFGPU_VERBOSE="1"), capture_output=True, text=True, timeout=900)
+        assert ra.returncode == 0, ra.stderr[-600:]
+        assert "2 file(s) of 97x61 decoded in one batch on the GPU" in ra.stderr
+        for n in picks + ["rgb8_97x61_again"]:
+            src = str(dup) if n.endswith("_again") else os.path.join(ROOT, "tests", "golden", n + ".fuif")
+            b = str(tmp_path / "ref_batch.pam")
+            rb = subprocess.run([ref_cli, "-d", src, b], env=env, capture_output=True, text=True, timeout=600)
+            assert rb.returncode == 0
+            assert open(str(outdir / (n + ".pam")), "rb").read() == open(b, "rb").read(), n
     # `-d x.fuif out.yuv` keeps the colour transform and the chroma subsampling: Image::undo_transforms(2) (fuif.cpp:230),
     # i.e. Transform::apply(image, true) per transform -- Squeeze, Quantization and DCT inverses through the boundary's binding to
     # fuifgpu_inv_hsqueeze / fuifgpu_inv_vsqueeze / fuifgpu_inv_quantize / fuifgpu_idct8x8
