@@ -1358,10 +1358,14 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         L.touched = 0; L.bits = 0;
         auto switch_leaf = [&](int id) {
             if (LIKELY(id != cur_leaf)) {
-#ifndef FUIF_EXP_NOLEAFLOAD   // (experiment: what the dependent leaf fetch costs -- decodes garbage)
+#ifndef FUIF_EXP_NOLEAFLOAD   // (experiments: what the leaf traffic costs -- FUIF_EXP_NOLEAFLOAD / _NOLEAFSTORE / _NOLEAFFETCH decode garbage)
                 if (lane < 32) {
+#ifndef FUIF_EXP_NOLEAFSTORE
                     leaves[(int64_t)cur_leaf * kLeafStride + lane] = (uint16_t)L.leafv;
+#endif
+#ifndef FUIF_EXP_NOLEAFFETCH
                     L.leafv = (int)leaves[(int64_t)id * kLeafStride + lane];
+#endif
                 }
 #endif
                 cur_leaf = id;
