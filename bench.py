@@ -210,8 +210,15 @@ def pmc_traffic(batch, mode):
         except (OSError, ValueError):
             continue
         if d.get("kernel") == "k_maniac_decode" and d.get("batch") == batch and d.get("mode", "images") == mode:
-            best = d
-    return None if best is None else int(best["traffic_bytes_per_launch"])
+            best = dict(d, _file=os.path.relpath(f, ROOT))
+    if best is None:
+        return None, None
+    # where the figure comes from, so that a stale profile is visible next to this run's own kernel time
+    src = {"profile": best["_file"], "round": best.get("round"), "kernel_ms_when_profiled": best.get("kernel_ms_under_pmc"),
+           "read_factor_leaf_pattern": best.get("read_factor_leaf_pattern", (best.get("calibration", {}).get("read") or {}).get("factor")),
+           "read_factor_supernode_pattern": best.get("read_factor_supernode_pattern"), "read_factor_used": best.get("read_factor_used"),
+           "range_bytes": [best.get("traffic_bytes_per_launch_all_leaf_factor"), best.get("traffic_bytes_per_launch_all_supernode_factor")]}
+    return int(best["traffic_bytes_per_launch"]), src
 
 
 def run_c5(args):
@@ -695,14 +702,16 @@ def main():
         d_avg = float(np.mean(dec_ms)) / 1e3
         t_avg = float(np.mean(tr_ms)) / 1e3
         achieved = alg_kernel / d_avg / 1e9
+        traffic, traffic_src = pmc_traffic(args.batch, "images" if args.no_index else "groups") if args.workload == "c2" else (None, None)
         roofline = {"bound": "hbm", "kernel": "k_maniac_decode", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(args.batch, "images" if args.no_index else "groups") if args.workload == "c2" else None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel_ms": round(d_avg * 1e3, 3), "algorithmic_bytes_per_launch": int(alg_kernel),
                     "tiles_per_launch": n_tiles,
                     "note": "serial range decoders, one wavefront per channel group, 6 per SIMD, suspended while they wait for other groups' rows: "
-                            "bound by the latency of three dependent memory round trips per symbol (supernode, leaf, transition table) and by "
-                            "instruction issue, not by HBM bandwidth (DESIGN.md 4.1, profiles/r2_sq_counters_*); traffic = PMC bytes of the "
-                            "committed profile of this configuration (profiles/r*_pmc_traffic.json), calibrated on the kernel's access pattern",
+                            "bound by the latency of two dependent memory round trips per symbol (supernode, leaf: ~980 cycles each when ~3000 long "
+                            "groups share HBM, profiles/r3_fetch_latency_and_leaf_experiment.txt) and by what the wavefronts of a SIMD issue together, not by "
+                            "HBM bandwidth (DESIGN.md 4.1); traffic = PMC bytes of the committed profile named in traffic_source (NOT measured in this "
+                            "run), calibrated on the kernel's two access patterns",
                     "transforms": {"ms": round(t_avg * 1e3, 3), "achieved": round(args.batch * 4.0 * (N + P) / t_avg / 1e9, 1),
                                    "unit": "GB/s", "algorithmic_bytes": int(args.batch * 4.0 * (N + P))},
                     "path_bytes_per_image": int(S + 8.0 * N + 4.0 * P)}
