@@ -544,13 +544,13 @@ bool gpu_inv_dct(Image &img, std::vector<int> par) {
     return true;
 }
 
-// transform/subsample.h:73-127, the "fancy" factors 1 and 2 (the box filter of larger factors stays with the reference's loop)
+// transform/subsample.h:73-127 (the "fancy" filter for factors 1 and 2, replication for larger ones: both in k_upsample)
 bool gpu_inv_subsample(Image &img, std::vector<int> par) {
     refdct::check_subsample_parameters(par);
     std::vector<Channel> work = img.channel;
     for (size_t i = 0; i + 3 < par.size(); i += 4) {
         const int c1 = par[i], c2 = par[i + 1], srh = par[i + 2], srv = par[i + 3];
-        if (c1 < 0 || c2 >= (int)work.size() || srh < 1 || srv < 1 || srh > 2 || srv > 2) return false;
+        if (c1 < 0 || c2 >= (int)work.size() || srh < 1 || srv < 1 || srh > 8 || srv > 8) return false;
         for (int c = c1; c <= c2; c++) {
             const int ow = work[c].w, oh = work[c].h;
             if (ow >= work[img.nb_meta_channels].w && oh >= work[img.nb_meta_channels].h) continue;   // subsample.h:87-91

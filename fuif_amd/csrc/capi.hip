@@ -814,7 +814,7 @@ int fuifgpu_fwd_vsqueeze(const int32_t *in, int w, int h, int32_t *avg, int32_t 
     return FUIFGPU_OK;
 }
 int fuifgpu_upsample(const int32_t *in, int w, int h, int srh, int srv, int32_t *out, void *stream) {
-    if (!in || !out || w < 1 || h < 1 || srh < 1 || srh > 2 || srv < 1 || srv > 2) return FUIFGPU_E_ARG;
+    if (!in || !out || w < 1 || h < 1 || srh < 1 || srh > 8 || srv < 1 || srv > 8) return FUIFGPU_E_ARG;
     Bases b;
     b.base[0] = const_cast<int32_t *>(in); b.stride[0] = 0; b.base[1] = out; b.stride[1] = 0; b.base[2] = nullptr; b.stride[2] = 0;
     Op op = raw_op(OP_UPSAMPLE);

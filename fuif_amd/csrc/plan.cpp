@@ -253,8 +253,10 @@ struct Builder {
         std::vector<int> p = expand_subsample(params);
         for (size_t i = 0; i < p.size(); i += 4) {
             int c1 = p[i], c2 = p[i + 1], srh = p[i + 2], srv = p[i + 3];
-            if (c1 < 0 || c2 >= (int)live.size() || srh < 1 || srh > 2 || srv < 1 || srv > 2)
-                return fail(FUIFGPU_E_UNSUPPORTED, "subsampling ratio other than 1 or 2");
+            // (the reference asserts ratios of 1 or 2 here, subsample.h:143-144, but its release build has no asserts and 4:1:1 -- ratio 4,
+            // subsample.h:54-59 -- goes through: the shift is 1 for every ratio above 1, the inverse is the box filter of :116-126)
+            if (c1 < 0 || c2 >= (int)live.size() || srh < 1 || srh > 8 || srv < 1 || srv > 8)
+                return fail(FUIFGPU_E_UNSUPPORTED, "subsampling ratio above 8");
             for (int c = c1; c <= c2; c++) {
                 live[c].w = (live[c].w + srh - 1) / srh;
                 live[c].h = (live[c].h + srv - 1) / srv;
@@ -447,7 +449,6 @@ struct Builder {
             for (int c = c1; c <= c2 && c < (int)live.size(); c++) {
                 LiveChannel &ch = live[c];
                 if (ch.w >= live[nb_meta].w && ch.h >= live[nb_meta].h) continue;  // subsample.h:87-91
-                if (srh > 2 || srv > 2) return fail(FUIFGPU_E_UNSUPPORTED, "box upsampling ratios > 2");
                 ProtoOp op;
                 op.kind = OP_UPSAMPLE;
                 int idx = (int)ops.size();

@@ -445,7 +445,9 @@ __global__ __launch_bounds__(256) void k_upsample(Bases b, PlaneRef pi, PlaneRef
         return in[(int64_t)y * ow + Xo];
     };
     int v;
-    if (srv == 2) {
+    if (srh > 2 || srv > 2) {
+        v = in[(int64_t)(Y / srv) * ow + X / srh];   // subsample.h:116-126: plain replication for ratios above 2 (4:1:1)
+    } else if (srv == 2) {
         const int y = Y >> 1;
         const int c = hval(y, X);
         if (Y & 1) v = (3 * c + hval(y + 1 < oh ? y + 1 : y, X) + 2) >> 2;

@@ -39,8 +39,12 @@ def _dct_matrix():
     return k
 
 
-def dct_planes(rgb, quality=90, subsample420=True):
-    """(3,H,W) or (1,H,W) int -> list of per-component quantised coefficient arrays [bh][bw][64] + q tables"""
+def dct_planes(rgb, quality=90, subsample420=True, factors=None):
+    """(3,H,W) or (1,H,W) int -> list of per-component quantised coefficient arrays [bh][bw][64] + q tables.
+    factors = (srh, srv) chroma subsampling factors, e.g. (2, 2) 4:2:0, (2, 1) 4:2:2, (4, 1) 4:1:1 (overrides subsample420)"""
+    if factors is None:
+        factors = (2, 2) if subsample420 else (1, 1)
+    srh, srv = factors
     c, h, w = rgb.shape
     if c == 3:
         r, g, b = [rgb[i].astype(np.float64) for i in range(3)]
@@ -53,11 +57,11 @@ def dct_planes(rgb, quality=90, subsample420=True):
     K = _dct_matrix()
     out, qts, sub = [], [], []
     for ci, p in enumerate(comps):
-        s = 1 if (subsample420 and ci > 0) else 0
+        s = 1 if (ci > 0 and (srh > 1 or srv > 1)) else 0
         if s:
-            ph, pw = (h + 1) // 2 * 2, (w + 1) // 2 * 2
+            ph, pw = (h + srv - 1) // srv * srv, (w + srh - 1) // srh * srh
             pp = np.pad(p, ((0, ph - h), (0, pw - w)), mode="edge")
-            p = np.rint((pp[0::2, 0::2] + pp[0::2, 1::2] + pp[1::2, 0::2] + pp[1::2, 1::2]) / 4.0)
+            p = np.rint(pp.reshape(ph // srv, srv, pw // srh, srh).mean(axis=(1, 3)))
         ch, cw = p.shape
         bh, bw = (ch + 7) // 8, (cw + 7) // 8
         p = np.pad(p, ((0, bh * 8 - ch), (0, bw * 8 - cw)), mode="edge") - 128.0
@@ -67,12 +71,16 @@ def dct_planes(rgb, quality=90, subsample420=True):
         q = np.rint(coef.reshape(bh, bw, 64) / qt).astype(np.int32)
         out.append(q)
         qts.append(qt)
-        sub.append(s)
+        sub.append((1 if srh > 1 else 0, 1 if srv > 1 else 0) if s else (0, 0))   # what read_jpeg.h:156-157 adds to hshift / vshift
     return out, qts, sub
 
 
-def encode_jpeg_like(rgb, quality=90, subsample420=True, tree_mode=1, max_properties=12, index=False):
-    """RGB (3,H,W) / gray (1,H,W) 8-bit -> .fuif bytes with the JPEG-transcode transform chain"""
+_ABBREV = {(2, 2): 0, (2, 1): 1, (1, 2): 2, (4, 1): 3}   # transform/subsample.h:33-60
+
+
+def encode_jpeg_like(rgb, quality=90, subsample420=True, tree_mode=1, max_properties=12, index=False, factors=None):
+    """RGB (3,H,W) / gray (1,H,W) 8-bit -> .fuif bytes with the JPEG-transcode transform chain; factors = (srh, srv) of the chroma
+    planes ((2, 2) = 4:2:0 when subsample420, (2, 1) = 4:2:2, (4, 1) = 4:1:1)"""
     import fuif_amd
     L = fuif_amd.lib()
 
@@ -81,7 +89,11 @@ def encode_jpeg_like(rgb, quality=90, subsample420=True, tree_mode=1, max_proper
                     ("vcshift", C.c_int32), ("component", C.c_int32), ("q", C.c_int32), ("data", C.c_void_p)]
 
     c, h, w = rgb.shape
-    coefs, qts, sub = dct_planes(rgb, quality, subsample420 and c == 3)
+    if factors is None:
+        factors = (2, 2) if subsample420 else (1, 1)
+    if c != 3:
+        factors = (1, 1)
+    coefs, qts, sub = dct_planes(rgb, quality, factors=factors)
     nb = len(coefs)
     nat_of_pos = np.argsort(ZIGZAG)          # natural index bi of coefficient position k
     chans, keep = [], []
@@ -91,13 +103,13 @@ def encode_jpeg_like(rgb, quality=90, subsample420=True, tree_mode=1, max_proper
         plane = np.ascontiguousarray(coefs[comp][:, :, bi], dtype=np.int32)
         keep.append(plane)
         bh, bw = plane.shape
-        chans.append(RawChannel(bw, bh, 3 + sub[comp], 3 + sub[comp], int(DCT_CSHIFTS[pos]), int(DCT_CSHIFTS[pos]), comp,
+        chans.append(RawChannel(bw, bh, 3 + sub[comp][0], 3 + sub[comp][1], int(DCT_CSHIFTS[pos]), int(DCT_CSHIFTS[pos]), comp,
                                 int(qts[comp][bi]), plane.ctypes.data))
     words = []
     if nb == 3:
         words += [0, 0]                      # YCbCr
-        if any(sub):
-            words += [3, 1, 0]               # ChromaSubsample, abbreviated 4:2:0 (subsample.h:37-43)
+        if factors != (1, 1):
+            words += [3, 1, _ABBREV[tuple(factors)]]   # ChromaSubsample, abbreviated parameter (subsample.h:33-60)
     words += [4, 0, 5, 0]                    # DCT (default parameters), Quantize
     arr = (RawChannel * len(chans))(*chans)
     tw = np.array(words, np.int32)

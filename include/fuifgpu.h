@@ -24,7 +24,7 @@ extern "C" {
 #define FUIFGPU_OK 0
 #define FUIFGPU_E_NOT_FUIF 1      /* bad magic / short header */
 #define FUIFGPU_E_CORRUPT 2       /* header or transform list is inconsistent */
-#define FUIFGPU_E_UNSUPPORTED 3   /* feature outside the hot-path scope (Permute, unusual subsampling ratios, ...) */
+#define FUIFGPU_E_UNSUPPORTED 3   /* feature outside the hot-path scope (more than 16 reference properties, a data-driven Permute over channels of unequal geometry, soft 2D matches) */
 #define FUIFGPU_E_ARG 4
 #define FUIFGPU_E_HIP 5           /* a HIP runtime call failed; see fuifgpu_last_error() */
 #define FUIFGPU_E_MISMATCH 6      /* image does not share the batch's plan signature */
@@ -188,7 +188,7 @@ int fuifgpu_inv_quantize(int32_t *plane, int64_t n_samples, int q, void *stream)
 /* transform/dct.h:88-107 + 282-291: 64 coefficient planes (bw x bh each, src[i] in the
  * reference's own zig-zag position order i=0..63) -> (8bw) x (8bh) samples; DC offset (maxval+1)*4 */
 int fuifgpu_idct8x8(const int32_t *const *src64_dev, int bw, int bh, int32_t *out, int maxval, void *stream);
-/* transform/subsample.h:90-115 "fancy" chroma upsampling, srh/srv in {1,2} */
+/* transform/subsample.h:90-126 chroma upsampling: the "fancy" filter for srh, srv in {1,2}, plain replication when either is larger (4:1:1) */
 int fuifgpu_upsample(const int32_t *in, int w, int h, int srh, int srv, int32_t *out, void *stream);
 /* ---- forward transforms of the writer, raw device planes, contiguous rows ----
  * transform/ycocg.h:65-95 fwd_YCoCg, in place on three w x h planes */

@@ -451,7 +451,7 @@ static int meta_subsample(fo_image *img, const fo_transform *t) {
     int ok = 1;
     for (int i = 0; i < n && ok; i += 4) {
         int c1 = p[i], c2 = p[i + 1], srh = p[i + 2], srv = p[i + 3];
-        if (c1 < 0 || c2 >= img->nch || srh < 1 || srv < 1 || srh > 2 || srv > 2) { ok = 0; break; }
+        if (c1 < 0 || c2 >= img->nch || srh < 1 || srv < 1 || srh > 8 || srv > 8) { ok = 0; break; }   /* (the asserts of :143-144 are compiled out of the reference's release build: 4:1:1 goes through) */
         for (int c = c1; c <= c2; c++) {
             img->ch[c].w = (img->ch[c].w + srh - 1) / srh;
             img->ch[c].h = (img->ch[c].h + srv - 1) / srv;

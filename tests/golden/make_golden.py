@@ -85,6 +85,10 @@ JPEG_SPECS = [
     ("jpeggray_120x88_q80", dict(w=120, h=88, channels=1, bits=8, seed=22), dict(quality=80)),
     # 4:2:2: chroma subsampled horizontally only (the generic upsampling kernel, factors 2 x 1), odd block counts
     ("jpeg422_200x104_q88", dict(w=200, h=104, channels=3, bits=8, seed=23), dict(quality=88, subsampling=1)),
+    # 4:1:1 (chroma subsampled 4 x 1; subsample.h:54-59): no JPEG writer at hand produces it, so the STREAM comes from the product's
+    # own writer (fuif_amd/jpeglike.py: the transform list and coefficient planes read_jpeg.h would build from such a JPEG) and the
+    # expected planes from the real reference decoding it -- the inverse is the replication branch of subsample.h:116-126
+    ("jpeg411_176x72_q85", dict(w=176, h=72, channels=3, bits=8, seed=24), dict(quality=85, writer_factors=(4, 1))),
 ]
 # animation (FUAF): frames are stacked vertically; -M 0 keeps the 2D-match transform (out of scope) off
 ANIM_SPECS = [
@@ -154,6 +158,12 @@ def main():
                 write_pnm(os.path.join(tmp, name + "-%02d.ppm" % i), fr, maxval)
             src = os.path.join(tmp, name + "-%02d.ppm")
             cli_flags = [] if flags.get("match") else ["-M", "0"]
+        elif isinstance(flags, dict) and "writer_factors" in flags:
+            sys.path.insert(0, os.path.join(HERE, "..", ".."))
+            from fuif_amd.jpeglike import encode_jpeg_like
+            with open(out, "wb") as f:
+                f.write(encode_jpeg_like(img, flags["quality"], factors=tuple(flags["writer_factors"])))
+            src, cli_flags = None, []
         elif isinstance(flags, dict):
             from PIL import Image
             arr = np.moveaxis(img, 0, -1).astype(np.uint8)
@@ -171,7 +181,7 @@ def main():
                 raise SystemExit("reference CLI failed for %s: %s %s" % (name, r.stdout[-400:], r.stderr[-400:]))
         blob = open(out, "rb").read()
         entry = {"name": name, "file": name + ".fuif", "bytes": len(blob), "file_sha256": hashlib.sha256(blob).hexdigest(),
-                 "source": gen, "cli_flags": cli_flags if not isinstance(flags, dict) else (["<library: oracle/ref_driver.cpp fuifref_encode>", json.dumps(flags)] if "permute" in flags else ["<jpeg/anim>", json.dumps(flags)] + cli_flags), "cases": []}
+                 "source": gen, "cli_flags": cli_flags if not isinstance(flags, dict) else (["<library: oracle/ref_driver.cpp fuifref_encode>", json.dumps(flags)] if "permute" in flags else ["<stream written by fuif_amd/jpeglike.py; expected planes = the reference decoding it>", json.dumps(flags)] if "writer_factors" in flags else ["<jpeg/anim>", json.dumps(flags)] + cli_flags), "cases": []}
         cases = [("full", -1, len(blob))]
         cases += [("preview%d" % k, k, len(blob)) for k in PREVIEWS.get(name, [])]
         cases += [("trunc%02d" % int(f * 100), -1, int(len(blob) * f)) for f in TRUNCATE.get(name, []) + TRUNCATE_EXTRA.get(name, [])]

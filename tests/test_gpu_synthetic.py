@@ -90,12 +90,12 @@ def test_truncated_learned_tree_stream(gpulib, port):
             assert np.array_equal(g, e["data"])
 
 
-@pytest.mark.parametrize("w,h,c,sub", [(1280, 720, 3, True), (333, 257, 3, False), (640, 480, 1, False)])
+@pytest.mark.parametrize("w,h,c,sub", [(1280, 720, 3, True), (333, 257, 3, False), (640, 480, 1, False), (500, 120, 3, (4, 1)), (96, 200, 3, (2, 1))])
 def test_jpeg_like_dct_path_matches_oracle(gpulib, port, w, h, c, sub):
-    """config C3 shape at size: YCbCr + 4:2:0 + 8x8 FP64 iDCT + dequantisation + Squeeze of DC, bit-exact"""
+    """config C3 shape at size: YCbCr + 4:2:0 (or 4:1:1 / 4:2:2: sub = the chroma factors) + 8x8 FP64 iDCT + dequantisation + Squeeze of DC, bit-exact"""
     from fuif_amd.jpeglike import encode_jpeg_like
     img = photographic(w, h, c, 8, seed=6000 + w, sigma=1.0)
-    blob = encode_jpeg_like(img, 90, sub)
+    blob = encode_jpeg_like(img, 90, factors=sub) if isinstance(sub, tuple) else encode_jpeg_like(img, 90, sub)
     pre, post, st, used = gpu_decode(gpulib, [blob, blob])
     d_pre, d_post = port.decode_both(blob)
     assert not st.any()
