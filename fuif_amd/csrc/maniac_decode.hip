@@ -1680,7 +1680,13 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         tl[0] = ((unsigned long long)(uint32_t)img << 32) | (uint32_t)first_c;
         if (!resumed) tl[1] = tile_t0;
         tl[2] = t_end;
-        tl[3] = ((tl[3] + (t_end - tile_t0)) & 0xFFFFFFFFFFFFull) | ((unsigned long long)simd_key << 48);
+        // (CU key in bits 48..59, the SIMD the LAST run segment sat on in bits 60..61: HW_REG_HW_ID[5:4])
+#ifdef FUIF_EMU
+        const unsigned long long simd_id = (unsigned long long)blockIdx.x & 3ull;
+#else
+        const unsigned long long simd_id = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3ull;
+#endif
+        tl[3] = ((tl[3] + (t_end - tile_t0)) & 0xFFFFFFFFFFFFull) | ((unsigned long long)simd_key << 48) | (simd_id << 60);
     }
 #endif
 #ifdef FUIF_PROF

@@ -35,7 +35,7 @@ ch = (raw[:, 0] & np.uint64(0xFFFFFFFF)).astype(np.int64)
 t0 = raw[:, 1].astype(np.float64); t1 = raw[:, 2].astype(np.float64)
 running = (raw[:, 3] & np.uint64(0xFFFFFFFFFFFF)).astype(np.float64)   # ticks some wavefront was running the tile
 waited = (t1 - t0) - running                                             # suspended, or ready and not picked up yet
-key = (raw[:, 3] >> np.uint64(48)).astype(np.int64)
+key = ((raw[:, 3] >> np.uint64(48)) & np.uint64(0xFFF)).astype(np.int64)      # CU; bits 60..61: the SIMD of the tile's last run segment
 base = t0.min()
 t0 = (t0 - base) / 1e5; t1 = (t1 - base) / 1e5; waited /= 1e5      # ms (100 MHz ticks)
 print("launch %.1f ms by HIP events; tile log spans %.1f ms; %d tiles, %d images, %d SIMD keys" % (ms, t1.max(), len(raw), n, len(set(key.tolist()))))
