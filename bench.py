@@ -504,7 +504,7 @@ def main():
     ap.add_argument("--no-index", action="store_true", help="ignore the streams' group index: one wavefront per image for the timed steps")
     ap.add_argument("--no-seq-compare", action="store_true", help="skip the extra one-wavefront-per-image step reported next to the headline")
     ap.add_argument("--chunk", type=int, default=0,
-                    help="images resident at a time (0 = the whole batch): the batch is streamed through ONE chunk-sized set of coefficient / "
+                    help="images resident at a time (0 = the whole batch, -1 = as many as the device holds): the batch is streamed through ONE chunk-sized set of coefficient / "
                          "output slabs, chunk after chunk -- how C4 (256 x 8192x8192x4: 275 GB of coefficients alone) runs on one GPU")
     ap.add_argument("--cache", default=os.environ.get("FUIF_BENCH_CACHE", "/tmp/fuif_bench_cache"))
     ap.add_argument("--launcher-selftest", action="store_true",
@@ -550,6 +550,13 @@ def main():
     dev = torch.device("cuda", local_rank)
     dist = fd.init(device=dev)
 
+    if args.chunk < 0:
+        # as many images per chunk as the device holds: coefficient + output slabs (int32) and the stream of every resident image,
+        # next to ~45 GB of decoder scratch, context arenas and the transform arena (C4: 86 of the 256 8192x8192x4 images)
+        pinfo = fuif_amd.Plan(blobs[0]).info
+        per_image = 4 * (pinfo.coef_elems + pinfo.out_elems) + max(len(b) for _, b in inputs) + (32 << 20)
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        args.chunk = int(max(1, min(args.batch, (free_b - (45 << 30)) // per_image)))
     if args.chunk and args.chunk < args.batch:
         return run_streamed(args, wl, inputs, blobs, dev, dist, rank, world, W, H, C, BITS, K, t_gen)
 
