@@ -32,6 +32,12 @@ class FuifGpuError(RuntimeError):
         self.code = code
 
 
+# -ffp-contract=off: the FP64 paths (iDCT, YCbCr) must round every product and every sum on their own like the reference's
+# x86-64 build; hipcc's default fuses them into v_fma_f64 in the BACKEND, which no source pragma switches off
+# (tests/test_abi_and_plan.py::test_fp64_kernels_are_not_contracted looks at the ISA)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value"]
+
+
 def build(force=False, verbose=False):
     """Compile libfuifgpu.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(_HERE, "csrc", s) for s in _SOURCES]
@@ -41,8 +47,7 @@ def build(force=False, verbose=False):
         return _LIB_PATH
     if not force and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return _LIB_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-o", _LIB_PATH] + srcs
+    cmd = ["hipcc"] + HIPCC_FLAGS + ["-fPIC", "-shared", "-o", _LIB_PATH] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -17,7 +17,7 @@ enum : int {
 constexpr int kMaxBitDepth = 15;        // config.h:5 (MAX_BIT_DEPTH)
 constexpr int kNonRefProps = 13;        // encoding/context_predict.h:210
 constexpr int kMaxProps = 32;           // 2*6 reference properties + 13 local ones = 25 at default options
-constexpr int kMaxRefs = 8;
+constexpr int kMaxRefs = 9;            // 2*9 + 13 = 31 properties: what the 32 property lanes of the pixel loop hold (-E 18)
 constexpr int kMaxNodes = 65535;        // childID is uint16_t (maniac/compound.h:46)
 constexpr int kLeafStride = 32;         // 31 chances (maniac/symbol.h:72-77) padded to 64 bytes
 constexpr int kTreeStackDepth = 2048;   // explicit stack replacing the recursion of compound.h:277-308
@@ -93,7 +93,11 @@ enum : int {
     OP_MATCH_INIT = 13,   // dst[0] = linear index every sample copies from (itself / -1 = before the first sample); src[0] match plane, p0 softmatch
     OP_MATCH_JUMP = 14,   // dst[0][p] = src[0][src[0][p]]: one doubling step; src[1] match plane (mode check)
     OP_MATCH_APPLY = 15,  // listed planes[p] = planes[src[0][p]] in place; src[1] match plane (mode check)
-    OP_PERMUTE = 16       // dst[0] = listed plane number perm[p0], perm = the samples of the 1-row meta plane src[0] (p1 = its length): transform/permute.h:31-54
+    OP_PERMUTE = 16,      // dst[0] = listed plane number perm[p0], perm = the samples of the 1-row meta plane src[0] (p1 = its length): transform/permute.h:31-54
+    // the last three ops of a default YCoCg + Squeeze chain in one pass (planner peephole, plan.cpp finalize()): the horizontal
+    // unsqueeze of Co (src[0] avg, src[1] residual) and of Cg (src[2] avg, ext[0] residual) followed by the inverse YCoCg with
+    // the finished Y plane dst[0]; R, G, B go to dst[0], dst[1], dst[2] (squeeze.h:81-132 twice + ycocg.h:49-61)
+    OP_HSQ2_YCOCG = 17
 };
 struct Op {
     int32_t kind;
@@ -104,6 +108,7 @@ struct Op {
     PlaneRef dst[3];
     int32_t idct_first;        // OP_IDCT: index into Plan::idct_src of the 64 source planes
     int32_t pad;
+    PlaneRef ext[1];           // OP_HSQ2_YCOCG: a fourth source
 };
 
 struct TransformDesc {

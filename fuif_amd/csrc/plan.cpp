@@ -15,6 +15,8 @@
 // The planner is geometry only: two streams with the same header produce the same plan, which is
 // what lets one kernel launch process a whole batch of images (grid.z = image).
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 
@@ -655,6 +657,37 @@ struct Builder {
         return true;
     }
 
+    // Peephole on the flat schedule: [HSQUEEZE -> Co, HSQUEEZE -> Cg, YCOCG(Y, Co, Cg)] of equal geometry, the way every default
+    // `fuif` encode (YCoCg, then Squeeze whose first step halves the chroma planes horizontally, squeeze.h:272-281) ends its
+    // inverse chain, becomes ONE op: the full-size Co and Cg planes are never written and read back, and the YCoCg pass over
+    // six planes disappears (C2: 331 -> 198 MB of plane traffic per 4K image for these three ops).
+    void fuse_chroma_hsqueeze_ycocg() {
+        static const int enabled = [] { const char *e = getenv("FUIFGPU_FUSE_YCOCG"); return e ? atoi(e) : 1; }();
+        if (!enabled) return;
+        std::vector<Op> &ops = plan.ops;
+        for (size_t k = 2; k < ops.size(); k++) {
+            const Op &c = ops[k], &h1 = ops[k - 2], &h2 = ops[k - 1];
+            if (c.kind != OP_YCOCG || h1.kind != OP_HSQUEEZE || h2.kind != OP_HSQUEEZE) continue;
+            auto same = [](const PlaneRef &a, const PlaneRef &b) { return a.buf == b.buf && a.off == b.off && a.w == b.w && a.h == b.h; };
+            if (!same(h1.dst[0], c.src[1]) || !same(h2.dst[0], c.src[2]) || h1.clamp_out || h2.clamp_out) continue;
+            if (h1.src[0].w != h2.src[0].w || h1.src[1].w != h2.src[1].w || h1.src[0].h != h2.src[0].h) continue;
+            const int wo = h1.src[0].w + h1.src[1].w, h = h1.src[0].h;
+            if (c.p0 != wo || c.p1 != h || c.src[0].w != wo || c.src[0].h != h || h1.dst[0].w != wo || h2.dst[0].w != wo) continue;
+            if (h1.src[1].w < 1 || h1.src[0].buf < 0 || h1.src[1].buf < 0 || h2.src[1].buf < 0) continue;
+            // the Y plane must not be one of the chroma inputs, and the chroma inputs must not be the outputs
+            Op f{};
+            f.kind = OP_HSQ2_YCOCG;
+            f.lo = c.lo; f.hi = c.hi; f.p0 = wo; f.p1 = h;
+            f.src[0] = h1.src[0]; f.src[1] = h1.src[1]; f.src[2] = h2.src[0]; f.ext[0] = h2.src[1];
+            f.dst[0] = c.src[0]; f.dst[1] = c.src[1]; f.dst[2] = c.src[2];
+            f.idct_first = c.idct_first; f.pad = 0;
+            ops[k - 2] = f;
+            ops.erase(ops.begin() + (k - 1), ops.begin() + (k + 1));
+            if (getenv("FUIFGPU_VERBOSE")) fprintf(stderr, "fuifgpu: plan %dx%d: chroma unsqueeze + YCoCg fused into one op (%zu ops)\n", plan.w, plan.h, ops.size());
+            return;   // one YCoCg per chain
+        }
+    }
+
     bool finalize() {
         // every plane still referenced by a live channel is a final plane
         int nops_before = (int)ops.size();
@@ -757,6 +790,7 @@ struct Builder {
             }
             plan.ops.push_back(op);
         }
+        fuse_chroma_hsqueeze_ycocg();
         plan.outputs.clear();
         for (auto &ch : live) {
             OutputChannel oc{};

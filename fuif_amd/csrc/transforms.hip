@@ -26,6 +26,13 @@
 #include "fuifgpu_internal.h"
 #include "transforms.h"
 
+// The reference's x86-64 build has no fused multiply-add: every product and every sum of the FP64 paths (iDCT, YCbCr) is rounded
+// on its own.  hipcc fuses a*b+c into v_fma_f64 by default, in the backend, also through __dmul_rn / __dadd_rn (plain operators
+// in HIP) and whatever `#pragma clang fp contract(off)` says: this file MUST be compiled with -ffp-contract=off
+// (fuif_amd.HIPCC_FLAGS; tests/test_abi_and_plan.py checks the ISA).  Rounds 1-2 shipped contracted code; it passed every
+// fixture because a last-bit difference in a double only shows when the value sits within ~1e-13 of a rounding boundary of the
+// integer result.
+
 namespace fuifgpu {
 
 namespace {
@@ -59,6 +66,10 @@ DEV void unsqueeze_pair(int avg, int diff, int &A, int &B) {
 
 // ---------------------------------------------------------------------------------------------
 // vertical unsqueeze: avg (w x h1) + residual (w x h2) -> out (w x (h1+h2)), h1-h2 in {0,1}
+#ifndef FUIF_VS_STEP
+#define FUIF_VS_STEP 8
+#endif
+constexpr int VS_STEP = FUIF_VS_STEP;
 __global__ __launch_bounds__(256) void k_inv_vsqueeze(Bases b, PlaneRef pa, PlaneRef pr, PlaneRef po, int clamp, int lo, int hi) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int w = pa.w, h1 = pa.h, h2 = pr.h;
@@ -68,7 +79,28 @@ __global__ __launch_bounds__(256) void k_inv_vsqueeze(Bases b, PlaneRef pa, Plan
     int32_t *o = plane_ptr(b, po, blockIdx.z) + x;
     int avg = a[0];
     int prevB = avg;  // first pair uses tendency(avg,avg,next): squeeze.h:186
-    for (int y = 0; y < h2; y++) {
+    int y = 0;
+    // VS_STEP row pairs per step, their loads issued together (the recurrence down the column is serial: with one pair per
+    // step a lane has a single pair of loads in flight)
+    for (; y + VS_STEP < h1 && y + VS_STEP <= h2; y += VS_STEP) {   // avg rows y+1 .. y+VS_STEP all exist
+        int nv[VS_STEP], rv[VS_STEP];
+#pragma unroll
+        for (int k = 0; k < VS_STEP; k++) {
+            nv[k] = a[(int64_t)(y + 1 + k) * w];
+            rv[k] = r[(int64_t)(y + k) * w];
+        }
+#pragma unroll
+        for (int k = 0; k < VS_STEP; k++) {
+            const int diff = rv[k] + smooth_tendency(prevB, avg, nv[k]);
+            int A, B;
+            unsqueeze_pair(avg, diff, A, B);
+            o[(int64_t)(2 * (y + k)) * w] = clamp ? clampi(A, lo, hi) : A;
+            o[(int64_t)(2 * (y + k) + 1) * w] = clamp ? clampi(B, lo, hi) : B;
+            prevB = B;
+            avg = nv[k];
+        }
+    }
+    for (; y < h2; y++) {
         const int next_avg = (y + 1 < h1) ? a[(int64_t)(y + 1) * w] : avg;
         const int res = r[(int64_t)y * w];
         const int diff = res + smooth_tendency(prevB, avg, next_avg);
@@ -147,6 +179,244 @@ __global__ __launch_bounds__(256) void k_inv_hsqueeze_rows(Bases b, PlaneRef pa,
     }
 }
 
+// The same recurrence with COALESCED global accesses: one wavefront (= one workgroup, so __syncthreads() is wave-local) owns 64
+// rows and moves them in tiles of 64 rows x HL_P pairs through its own LDS tile.  Load: 8 lanes fetch the 128 bytes of one
+// input row (16 bytes each), 8 rows per instruction; each lane then reads ITS row out of LDS, runs the HL_P pairs, puts the
+// 2*HL_P outputs back into LDS (the output tile aliases the input tiles: every lane holds its inputs in registers by then)
+// and the tile is written out 16 lanes per 256-byte output row.  Row pitches of 36 / 68 words keep the b128 LDS accesses of
+// 16 neighbouring lanes on different banks.
+constexpr int HL_P = 32;
+constexpr int HL_IN_PITCH = HL_P + 4;        // words
+constexpr int HL_OUT_PITCH = 2 * HL_P + 4;
+__global__ __launch_bounds__(64) void k_inv_hsqueeze_tiles(Bases b, PlaneRef pa, PlaneRef pr, PlaneRef po, int clamp, int lo, int hi) {
+    __shared__ __attribute__((aligned(16))) int32_t tile[2 * 64 * HL_IN_PITCH];   // 18432 bytes; the 64 x 68-word output tile needs 17408
+    const int lane = threadIdx.x;
+    const int y0 = blockIdx.x * 64;
+    const int w1 = pa.w, w2 = pr.w, h = pa.h, wo = w1 + w2;
+    const int rows = min(64, h - y0);
+    if (rows <= 0) return;
+    const int32_t *A = plane_ptr(b, pa, blockIdx.z) + (int64_t)y0 * w1;
+    const int32_t *R = plane_ptr(b, pr, blockIdx.z) + (int64_t)y0 * w2;
+    int32_t *O = plane_ptr(b, po, blockIdx.z) + (int64_t)y0 * wo;
+    const bool mine = lane < rows;
+    const int32_t *a = A + (int64_t)(mine ? lane : 0) * w1;
+    const int32_t *r = R + (int64_t)(mine ? lane : 0) * w2;
+    int32_t *o = O + (int64_t)(mine ? lane : 0) * wo;
+    int avg = a[0];
+    int left = avg;   // first pair: tendency(avg, avg, next), squeeze.h:89
+    int x = 0;
+    int32_t *t_res = tile, *t_avg = tile + 64 * HL_IN_PITCH;
+    for (; x + HL_P < w1 && x + HL_P <= w2; x += HL_P) {   // avg[x+1 .. x+HL_P] all exist
+        {
+            const int piece = lane & 7, sub = lane >> 3;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int row = 8 * i + sub;
+                if (row < rows) {
+                    const Int4U rv = *reinterpret_cast<const Int4U *>(R + (int64_t)row * w2 + x + 4 * piece);
+                    const Int4U nv = *reinterpret_cast<const Int4U *>(A + (int64_t)row * w1 + x + 1 + 4 * piece);
+                    *reinterpret_cast<int4 *>(t_res + row * HL_IN_PITCH + 4 * piece) = make_int4(rv.v[0], rv.v[1], rv.v[2], rv.v[3]);
+                    *reinterpret_cast<int4 *>(t_avg + row * HL_IN_PITCH + 4 * piece) = make_int4(nv.v[0], nv.v[1], nv.v[2], nv.v[3]);
+                }
+            }
+        }
+        __syncthreads();
+        int4 rv[HL_P / 4], nv[HL_P / 4];
+#pragma unroll
+        for (int q = 0; q < HL_P / 4; q++) {
+            rv[q] = *reinterpret_cast<const int4 *>(t_res + lane * HL_IN_PITCH + 4 * q);
+            nv[q] = *reinterpret_cast<const int4 *>(t_avg + lane * HL_IN_PITCH + 4 * q);
+        }
+        __syncthreads();   // every lane has its inputs: the output tile may overwrite them
+#pragma unroll
+        for (int q = 0; q < HL_P / 4; q++) {
+            const int rr[4] = {rv[q].x, rv[q].y, rv[q].z, rv[q].w}, nn[4] = {nv[q].x, nv[q].y, nv[q].z, nv[q].w};
+            int ov[8];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int next_avg = nn[k];
+                const int diff = rr[k] + smooth_tendency(left, avg, next_avg);
+                int A2, B2;
+                unsqueeze_pair(avg, diff, A2, B2);
+                left = B2;
+                avg = next_avg;
+                if (clamp) { A2 = clampi(A2, lo, hi); B2 = clampi(B2, lo, hi); }
+                ov[2 * k] = A2; ov[2 * k + 1] = B2;
+            }
+            *reinterpret_cast<int4 *>(tile + lane * HL_OUT_PITCH + 8 * q) = make_int4(ov[0], ov[1], ov[2], ov[3]);
+            *reinterpret_cast<int4 *>(tile + lane * HL_OUT_PITCH + 8 * q + 4) = make_int4(ov[4], ov[5], ov[6], ov[7]);
+        }
+        __syncthreads();
+        {
+            const int piece = lane & 15, sub = lane >> 4;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int row = 4 * i + sub;
+                if (row < rows) {
+                    const int4 v = *reinterpret_cast<const int4 *>(tile + row * HL_OUT_PITCH + 4 * piece);
+                    Int4U u; u.v[0] = v.x; u.v[1] = v.y; u.v[2] = v.z; u.v[3] = v.w;
+                    *reinterpret_cast<Int4U *>(O + (int64_t)row * wo + 2 * x + 4 * piece) = u;
+                }
+            }
+        }
+        __syncthreads();   // the next tile's loads overwrite what the stores just read
+    }
+    if (!mine) return;
+    for (; x < w2; x++) {
+        const int next_avg = x + 1 < w1 ? a[x + 1] : avg;   // squeeze.h:100
+        const int diff = r[x] + smooth_tendency(left, avg, next_avg);
+        int A2, B2;
+        unsqueeze_pair(avg, diff, A2, B2);
+        o[2 * x] = clamp ? clampi(A2, lo, hi) : A2;
+        o[2 * x + 1] = clamp ? clampi(B2, lo, hi) : B2;
+        left = B2;
+        avg = next_avg;
+    }
+    if (wo & 1) {  // squeeze.h:129
+        const int v = a[w1 - 1];
+        o[wo - 1] = clamp ? clampi(v, lo, hi) : v;
+    }
+}
+
+// OP_HSQ2_YCOCG: the horizontal unsqueeze of Co and of Cg (squeeze.h:81-132) and the inverse YCoCg (ycocg.h:49-61) in one pass.
+// Same tiling as k_inv_hsqueeze_tiles with HF_P = 16 pairs per tile row: a lane runs the recurrences of ITS row for both chroma
+// planes and leaves the 2 x 32 outputs in LDS; the colour transform then runs in the STORE layout (8 lanes per 128-byte row
+// segment), where the Y samples are read straight from global memory and R, G, B are written straight back: the full-size Co
+// and Cg planes never exist in memory.
+constexpr int HF_P = 16;
+constexpr int HF_IN_PITCH = HF_P + 4;
+constexpr int HF_OUT_PITCH = 2 * HF_P + 4;
+__global__ __launch_bounds__(64) void k_inv_hsq2_ycocg(Bases b, PlaneRef pa0, PlaneRef pr0, PlaneRef pa1, PlaneRef pr1, PlaneRef py, PlaneRef pg, PlaneRef pb,
+                                                       int maxval) {
+    __shared__ __attribute__((aligned(16))) int32_t tile[4 * 64 * HF_IN_PITCH];   // 20480 bytes; the two 64 x 36-word output tiles need 18432
+    const int lane = threadIdx.x;
+    const int y0 = blockIdx.x * 64;
+    const int w1 = pa0.w, w2 = pr0.w, h = pa0.h, wo = w1 + w2;
+    const int rows = min(64, h - y0);
+    if (rows <= 0) return;
+    const int32_t *A[2] = {plane_ptr(b, pa0, blockIdx.z) + (int64_t)y0 * w1, plane_ptr(b, pa1, blockIdx.z) + (int64_t)y0 * w1};
+    const int32_t *R[2] = {plane_ptr(b, pr0, blockIdx.z) + (int64_t)y0 * w2, plane_ptr(b, pr1, blockIdx.z) + (int64_t)y0 * w2};
+    int32_t *OY = plane_ptr(b, py, blockIdx.z) + (int64_t)y0 * py.w;
+    int32_t *OG = plane_ptr(b, pg, blockIdx.z) + (int64_t)y0 * pg.w;
+    int32_t *OB = plane_ptr(b, pb, blockIdx.z) + (int64_t)y0 * pb.w;
+    const bool mine = lane < rows;
+    const int my = mine ? lane : 0;
+    int avg[2] = {A[0][(int64_t)my * w1], A[1][(int64_t)my * w1]};
+    int left[2] = {avg[0], avg[1]};   // first pair: tendency(avg, avg, next), squeeze.h:89
+    auto rgb = [&](int Yv, int Co, int Cg, int &Rr, int &Gg, int &Bb) {   // ycocg.h:49-61
+        const int Y = clampi(Yv, 0, maxval);
+        Gg = clampi(Y - ((-Cg) >> 1), 0, maxval);
+        Bb = clampi(Y + ((1 - Cg) >> 1) - (Co >> 1), 0, maxval);
+        Rr = clampi(Co + Bb, 0, maxval);
+    };
+    int x = 0;
+    for (; x + HF_P < w1 && x + HF_P <= w2; x += HF_P) {   // avg[x+1 .. x+HF_P] all exist
+        Int4U yv[8];
+        {
+            // 4 lanes per 64-byte input row segment, 16 rows per instruction; Y: 8 lanes per 128-byte segment, 8 rows per instruction
+            const int piece = lane & 3, sub = lane >> 2;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int row = 16 * i + sub;
+                if (row < rows) {
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        const Int4U rv = *reinterpret_cast<const Int4U *>(R[c] + (int64_t)row * w2 + x + 4 * piece);
+                        const Int4U nv = *reinterpret_cast<const Int4U *>(A[c] + (int64_t)row * w1 + x + 1 + 4 * piece);
+                        *reinterpret_cast<int4 *>(tile + (2 * c) * 64 * HF_IN_PITCH + row * HF_IN_PITCH + 4 * piece) = make_int4(rv.v[0], rv.v[1], rv.v[2], rv.v[3]);
+                        *reinterpret_cast<int4 *>(tile + (2 * c + 1) * 64 * HF_IN_PITCH + row * HF_IN_PITCH + 4 * piece) = make_int4(nv.v[0], nv.v[1], nv.v[2], nv.v[3]);
+                    }
+                }
+            }
+            const int ypiece = lane & 7, ysub = lane >> 3;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int row = 8 * i + ysub;
+                if (row < rows) yv[i] = *reinterpret_cast<const Int4U *>(OY + (int64_t)row * py.w + 2 * x + 4 * ypiece);
+            }
+        }
+        __syncthreads();
+        int4 rv[2][HF_P / 4], nv[2][HF_P / 4];
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int q = 0; q < HF_P / 4; q++) {
+                rv[c][q] = *reinterpret_cast<const int4 *>(tile + (2 * c) * 64 * HF_IN_PITCH + lane * HF_IN_PITCH + 4 * q);
+                nv[c][q] = *reinterpret_cast<const int4 *>(tile + (2 * c + 1) * 64 * HF_IN_PITCH + lane * HF_IN_PITCH + 4 * q);
+            }
+        __syncthreads();   // every lane has its inputs: the output tiles may overwrite them
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int q = 0; q < HF_P / 4; q++) {
+                const int rr[4] = {rv[c][q].x, rv[c][q].y, rv[c][q].z, rv[c][q].w}, nn[4] = {nv[c][q].x, nv[c][q].y, nv[c][q].z, nv[c][q].w};
+                int ov[8];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int next_avg = nn[k];
+                    const int diff = rr[k] + smooth_tendency(left[c], avg[c], next_avg);
+                    int A2, B2;
+                    unsqueeze_pair(avg[c], diff, A2, B2);
+                    left[c] = B2;
+                    avg[c] = next_avg;
+                    ov[2 * k] = A2; ov[2 * k + 1] = B2;
+                }
+                *reinterpret_cast<int4 *>(tile + c * 64 * HF_OUT_PITCH + lane * HF_OUT_PITCH + 8 * q) = make_int4(ov[0], ov[1], ov[2], ov[3]);
+                *reinterpret_cast<int4 *>(tile + c * 64 * HF_OUT_PITCH + lane * HF_OUT_PITCH + 8 * q + 4) = make_int4(ov[4], ov[5], ov[6], ov[7]);
+            }
+        __syncthreads();
+        {
+            const int piece = lane & 7, sub = lane >> 3;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int row = 8 * i + sub;
+                if (row < rows) {
+                    const int4 co = *reinterpret_cast<const int4 *>(tile + row * HF_OUT_PITCH + 4 * piece);
+                    const int4 cg = *reinterpret_cast<const int4 *>(tile + 64 * HF_OUT_PITCH + row * HF_OUT_PITCH + 4 * piece);
+                    const int cov[4] = {co.x, co.y, co.z, co.w}, cgv[4] = {cg.x, cg.y, cg.z, cg.w};
+                    Int4U r4, g4, b4;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        int Rr, Gg, Bb;
+                        rgb(yv[i].v[k], cov[k], cgv[k], Rr, Gg, Bb);
+                        r4.v[k] = Rr; g4.v[k] = Gg; b4.v[k] = Bb;
+                    }
+                    *reinterpret_cast<Int4U *>(OY + (int64_t)row * py.w + 2 * x + 4 * piece) = r4;
+                    *reinterpret_cast<Int4U *>(OG + (int64_t)row * pg.w + 2 * x + 4 * piece) = g4;
+                    *reinterpret_cast<Int4U *>(OB + (int64_t)row * pb.w + 2 * x + 4 * piece) = b4;
+                }
+            }
+        }
+        __syncthreads();   // the next tile's loads overwrite what the stores just read
+    }
+    if (!mine) return;
+    const int32_t *a0 = A[0] + (int64_t)lane * w1, *a1 = A[1] + (int64_t)lane * w1, *r0 = R[0] + (int64_t)lane * w2, *r1 = R[1] + (int64_t)lane * w2;
+    int32_t *oy = OY + (int64_t)lane * py.w, *og = OG + (int64_t)lane * pg.w, *ob = OB + (int64_t)lane * pb.w;
+    for (; x < w2; x++) {
+        int P[2][2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int32_t *a = c ? a1 : a0, *r = c ? r1 : r0;
+            const int next_avg = x + 1 < w1 ? a[x + 1] : avg[c];   // squeeze.h:100
+            const int diff = r[x] + smooth_tendency(left[c], avg[c], next_avg);
+            unsqueeze_pair(avg[c], diff, P[c][0], P[c][1]);
+            left[c] = P[c][1];
+            avg[c] = next_avg;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            int Rr, Gg, Bb;
+            rgb(oy[2 * x + k], P[0][k], P[1][k], Rr, Gg, Bb);
+            oy[2 * x + k] = Rr; og[2 * x + k] = Gg; ob[2 * x + k] = Bb;
+        }
+    }
+    if (wo & 1) {  // squeeze.h:129
+        int Rr, Gg, Bb;
+        rgb(oy[wo - 1], a0[w1 - 1], a1[w1 - 1], Rr, Gg, Bb);
+        oy[wo - 1] = Rr; og[wo - 1] = Gg; ob[wo - 1] = Bb;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // transform/ycocg.h:49-61, in place on three planes (own row pitches), region w x h
 __global__ __launch_bounds__(256) void k_inv_ycocg(Bases b, PlaneRef p0, PlaneRef p1, PlaneRef p2, int w, int h, int maxval) {
@@ -162,6 +432,27 @@ __global__ __launch_bounds__(256) void k_inv_ycocg(Bases b, PlaneRef p0, PlaneRe
     const int B = clampi(Y + ((1 - Cg) >> 1) - (Co >> 1), 0, maxval);
     const int R = clampi(Co + B, 0, maxval);
     *c0 = R; *c1 = G; *c2 = B;
+}
+
+// the same, four pixels per lane (16-byte accesses): rows whose pitch, offset and width are multiples of four samples
+__global__ __launch_bounds__(256) void k_inv_ycocg4(Bases b, PlaneRef p0, PlaneRef p1, PlaneRef p2, int w4, int h, int maxval) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w4 || y >= h) return;
+    int4 *c0 = reinterpret_cast<int4 *>(plane_ptr(b, p0, blockIdx.z) + (int64_t)y * p0.w) + x;
+    int4 *c1 = reinterpret_cast<int4 *>(plane_ptr(b, p1, blockIdx.z) + (int64_t)y * p1.w) + x;
+    int4 *c2 = reinterpret_cast<int4 *>(plane_ptr(b, p2, blockIdx.z) + (int64_t)y * p2.w) + x;
+    const int4 vy = *c0, vo = *c1, vg = *c2;
+    const int Yv[4] = {vy.x, vy.y, vy.z, vy.w}, Cov[4] = {vo.x, vo.y, vo.z, vo.w}, Cgv[4] = {vg.x, vg.y, vg.z, vg.w};
+    int R[4], G[4], B[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int Y = clampi(Yv[k], 0, maxval);
+        G[k] = clampi(Y - ((-Cgv[k]) >> 1), 0, maxval);
+        B[k] = clampi(Y + ((1 - Cgv[k]) >> 1) - (Cov[k] >> 1), 0, maxval);
+        R[k] = clampi(Cov[k] + B[k], 0, maxval);
+    }
+    *c0 = make_int4(R[0], R[1], R[2], R[3]); *c1 = make_int4(G[0], G[1], G[2], G[3]); *c2 = make_int4(B[0], B[1], B[2], B[3]);
 }
 
 // transform/ycbcr.h:49-60: `float` operands, double arithmetic left to right, no contraction,
@@ -223,19 +514,23 @@ __global__ __launch_bounds__(256) void k_inv_palette(Bases b, PlaneRef pidx, Pla
 
 // transform/permute.h:31-54 with the permutation in a meta-channel: output plane i is a copy of candidate plane perm[i],
 // perm = the decoded samples of the 1-row meta plane -- per image.  A value that is no channel number (the reference would
-// index outside its channel vector) flags the image corrupt and copies nothing.
+// index outside its channel vector) flags the image corrupt and ZERO-FILLS the output plane, so that a flagged image is
+// deterministic and shows nothing of an earlier batch's slab.  A value that repeats an earlier one is refused as well:
+// stricter than inv_permute (:39-46 copies blindly, twice) but the same verdict as the decode-time metadata permutation
+// of encoding.cpp:576-596 / meta_permute (:68-73) and as oracle/fuif_oracle.c gives.
 __global__ __launch_bounds__(256) void k_permute_plane(Bases b, PlaneRef pperm, const PlaneRef *cand, int nb, int which, PlaneRef po, int clamp, int lo,
                                                        int hi, int32_t *status, int img_first) {
     const int c = plane_ptr(b, pperm, blockIdx.z)[which];
     bool bad = c < 0 || c >= nb;
     for (int j = 0; j < which && !bad; j++) bad = plane_ptr(b, pperm, blockIdx.z)[j] == c;
+    int32_t *d = plane_ptr(b, po, blockIdx.z);
+    const int64_t n = (int64_t)po.w * po.h;
     if (bad) {
         if (status && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&status[img_first + blockIdx.z], (int32_t)ST_CORRUPT);
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = 0;
         return;
     }
     const int32_t *s = plane_ptr(b, cand[c], blockIdx.z);
-    int32_t *d = plane_ptr(b, po, blockIdx.z);
-    const int64_t n = (int64_t)po.w * po.h;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = clamp ? clampi(s[i], lo, hi) : s[i];
 }
 
@@ -370,7 +665,7 @@ __global__ __launch_bounds__(256) void k_match_apply(Bases b, PlaneRef pm, Plane
 
 // ---------------------------------------------------------------------------------------------
 // transform/dct.h:60-77 -- the constants exactly as the reference prints them
-__constant__ double kDCT[64] = {
+constexpr double kDCT[64] = {
     0.3535533906, 0.3535533906, 0.3535533906, 0.3535533906, 0.3535533906, 0.3535533906, 0.3535533906, 0.3535533906,
     0.4903926402, 0.4157348062, 0.2777851165, 0.0975451610, -0.0975451610, -0.2777851165, -0.4157348062, -0.4903926402,
     0.4619397663, 0.1913417162, -0.1913417162, -0.4619397663, -0.4619397663, -0.1913417162, 0.1913417162, 0.4619397663,
@@ -385,39 +680,81 @@ __constant__ double kDCT[64] = {
 // 0.0 + sum_{u=0..7} k[8u+o]*in[u] accumulated left to right in double with separate mul and add
 // (the x86-64 reference build has no FMA), DC gets the float DC offset in float arithmetic
 // (dct.h:281,285), result rounded half away from zero (dct.h:289).
+//
+// The 64 constants are 7 magnitudes with signs, and k*x and (-k)*x are the same product with the other sign, exactly.  So one
+// 8-point pass needs 22 multiplications, not 64 (row u of the matrix holds 1, 4, 2, 4, 1, 4, 2, 4 different magnitudes), and
+// 56 additions / subtractions in the reference's order: the leading `0.0 +` is dropped -- it only matters for a first product
+// of -0.0, which cannot occur (row 0 of the matrix is positive and no input is -0.0: the coefficients are integers and a sum
+// that starts from +0.0 never yields -0.0).  Seven constants live in 14 SGPRs (round 2 kept all 64 in SGPRs: 252 spilled
+// lanes, two v_readlane per multiplication).
+constexpr double kDctMag[7] = {0.3535533906, 0.4903926402, 0.4157348062, 0.2777851165, 0.0975451610, 0.4619397663, 0.1913417162};
+// sign * (magnitude index + 1) of kDCT[8u + o]
+constexpr signed char kDctCode[64] = {
+    1, 1, 1, 1, 1, 1, 1, 1,
+    2, 3, 4, 5, -5, -4, -3, -2,
+    6, 7, -7, -6, -6, -7, 7, 6,
+    3, -5, -2, -4, 4, 2, 5, -3,
+    1, -1, -1, 1, 1, -1, -1, 1,
+    4, -2, 5, 3, -3, -5, 2, -4,
+    7, -6, 6, -7, -7, 6, -6, 7,
+    5, -4, 3, -2, 2, -3, 4, -5,
+};
+constexpr bool dct_code_matches_matrix() {
+    for (int i = 0; i < 64; i++) {
+        const int c = kDctCode[i];
+        const double v = c > 0 ? kDctMag[c - 1] : -kDctMag[-c - 1];
+        if (v != kDCT[i]) return false;
+    }
+    return true;
+}
+static_assert(dct_code_matches_matrix(), "kDctCode / kDctMag must spell out transform/dct.h:60-77");
+DEV void idct_1d(const double (&in)[8], double (&out)[8]) {
+    double pr[8][7];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+#pragma unroll
+        for (int m = 0; m < 7; m++) pr[u][m] = __dmul_rn(kDctMag[m], in[u]);   // the products no output uses are dead code
+#pragma unroll
+    for (int o = 0; o < 8; o++) {
+        double acc = pr[0][0];
+#pragma unroll
+        for (int u = 1; u < 8; u++) {
+            const int c = kDctCode[8 * u + o];
+            acc = c > 0 ? __dadd_rn(acc, pr[u][c - 1]) : __dadd_rn(acc, -pr[u][-c - 1]);
+        }
+        out[o] = acc;
+    }
+}
 __global__ __launch_bounds__(64) void k_idct8x8(Bases b, const PlaneRef *list, PlaneRef po, int bw, int bh, int maxval, int clamp, int lo, int hi) {
     const int bx = blockIdx.x * blockDim.x + threadIdx.x;
     const int by = blockIdx.y;
     if (bx >= bw || by >= bh) return;
-    double blk[64];
     const float dcoff = (float)(((double)maxval + 1.0) * 4.0);
-#pragma unroll
-    for (int i = 0; i < 64; i++) {
-        const PlaneRef p = list[i];
-        const int v = plane_ptr(b, p, blockIdx.z)[(int64_t)by * p.w + bx];
-        blk[i] = (i == 0) ? (double)__fadd_rn((float)v, dcoff) : (double)v;
-    }
-    double tmp[64];
+    double tmp[64];   // [output row o][column x] after the column pass
 #pragma unroll
     for (int x = 0; x < 8; x++) {
+        double col[8], res[8];
 #pragma unroll
-        for (int o = 0; o < 8; o++) {
-            double acc = 0.0;
-#pragma unroll
-            for (int u = 0; u < 8; u++) acc = __dadd_rn(acc, __dmul_rn(kDCT[8 * u + o], blk[u * 8 + x]));
-            tmp[o * 8 + x] = acc;
+        for (int u = 0; u < 8; u++) {
+            const PlaneRef p = list[u * 8 + x];
+            const int v = plane_ptr(b, p, blockIdx.z)[(int64_t)by * p.w + bx];
+            col[u] = (u == 0 && x == 0) ? (double)__fadd_rn((float)v, dcoff) : (double)v;
         }
+        idct_1d(col, res);
+#pragma unroll
+        for (int o = 0; o < 8; o++) tmp[o * 8 + x] = res[o];
     }
     int32_t *o = plane_ptr(b, po, blockIdx.z) + (int64_t)(by * 8) * po.w + bx * 8;
 #pragma unroll
     for (int y = 0; y < 8; y++) {
+        double row[8], res[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) row[u] = tmp[8 * y + u];
+        idct_1d(row, res);
         int outv[8];
 #pragma unroll
         for (int oo = 0; oo < 8; oo++) {
-            double acc = 0.0;
-#pragma unroll
-            for (int u = 0; u < 8; u++) acc = __dadd_rn(acc, __dmul_rn(kDCT[8 * u + oo], tmp[8 * y + u]));
-            int v = (int)round(acc);
+            int v = (int)round(res[oo]);
             outv[oo] = clamp ? clampi(v, lo, hi) : v;
         }
         int4 *dst = reinterpret_cast<int4 *>(o + (int64_t)y * po.w);
@@ -597,11 +934,30 @@ void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMe
         case OP_HSQUEEZE: {
             const int h = op.src[0].h;
             if (h <= 0 || op.dst[0].w <= 0) break;
-            hipLaunchKernelGGL(k_inv_hsqueeze_rows, dim3((h + 255) / 256, 1, n_images), dim3(256), 0, stream, b, op.src[0], op.src[1],
-                               op.dst[0], op.clamp_out, op.lo, op.hi);
+            static const int tiles = [] { const char *e = getenv("FUIFGPU_HSQUEEZE_TILES"); return e ? atoi(e) : 0; }();
+            if (tiles && op.src[1].w >= 2 * HL_P)
+                hipLaunchKernelGGL(k_inv_hsqueeze_tiles, dim3((h + 63) / 64, 1, n_images), dim3(64), 0, stream, b, op.src[0], op.src[1],
+                                   op.dst[0], op.clamp_out, op.lo, op.hi);
+            else
+                hipLaunchKernelGGL(k_inv_hsqueeze_rows, dim3((h + 255) / 256, 1, n_images), dim3(256), 0, stream, b, op.src[0], op.src[1],
+                                   op.dst[0], op.clamp_out, op.lo, op.hi);
+            break;
+        }
+        case OP_HSQ2_YCOCG: {
+            const int h = op.src[0].h;
+            if (h <= 0 || op.p0 <= 0) break;
+            hipLaunchKernelGGL(k_inv_hsq2_ycocg, dim3((h + 63) / 64, 1, n_images), dim3(64), 0, stream, b, op.src[0], op.src[1], op.src[2], op.ext[0],
+                               op.dst[0], op.dst[1], op.dst[2], op.hi);
             break;
         }
         case OP_YCOCG:
+            if (op.p0 % 4 == 0 && op.src[0].w % 4 == 0 && op.src[1].w % 4 == 0 && op.src[2].w % 4 == 0 && op.src[0].off % 4 == 0 &&
+                op.src[1].off % 4 == 0 && op.src[2].off % 4 == 0 && b.stride[op.src[0].buf] % 4 == 0 && b.stride[op.src[1].buf] % 4 == 0 &&
+                b.stride[op.src[2].buf] % 4 == 0 && ((uintptr_t)b.base[op.src[0].buf] | (uintptr_t)b.base[op.src[1].buf] | (uintptr_t)b.base[op.src[2].buf]) % 16 == 0) {
+                hipLaunchKernelGGL(k_inv_ycocg4, dim3((op.p0 / 4 + 255) / 256, op.p1, n_images), dim3(256), 0, stream, b, op.src[0], op.src[1],
+                                   op.src[2], op.p0 / 4, op.p1, op.hi);
+                break;
+            }
             hipLaunchKernelGGL(k_inv_ycocg, dim3((op.p0 + 255) / 256, op.p1, n_images), dim3(256), 0, stream, b, op.src[0], op.src[1], op.src[2],
                                op.p0, op.p1, op.hi);
             break;

@@ -24,7 +24,7 @@ extern "C" {
 #define FUIFGPU_OK 0
 #define FUIFGPU_E_NOT_FUIF 1      /* bad magic / short header */
 #define FUIFGPU_E_CORRUPT 2       /* header or transform list is inconsistent */
-#define FUIFGPU_E_UNSUPPORTED 3   /* feature outside the hot-path scope (more than 16 reference properties, a data-driven Permute over channels of unequal geometry, soft 2D matches) */
+#define FUIFGPU_E_UNSUPPORTED 3   /* feature outside the hot-path scope (more than 18 reference properties -- `-E k` > 18; the CLI default is 12 --, a data-driven Permute over channels of unequal geometry, soft 2D matches) */
 #define FUIFGPU_E_ARG 4
 #define FUIFGPU_E_HIP 5           /* a HIP runtime call failed; see fuifgpu_last_error() */
 #define FUIFGPU_E_MISMATCH 6      /* image does not share the batch's plan signature */

@@ -108,3 +108,26 @@ def test_header_is_plain_c(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_fp64_kernels_are_not_contracted(tmp_path):
+    """the reference build has no fused multiply-add; hipcc fuses by default, in the backend.  Compile transforms.hip with the
+    product's flags and look at the ISA of the two FP64 kernels: no v_fma / v_fmac, and the iDCT's 22 + 56 operations per
+    8-point pass (352 products + the DC offset; 896 sums + round()'s)."""
+    import shutil
+    import subprocess
+    import fuif_amd
+    if not shutil.which("hipcc"):
+        pytest.skip("needs hipcc")
+    out = str(tmp_path / "transforms.s")
+    subprocess.run(["hipcc"] + fuif_amd.HIPCC_FLAGS + ["-S", "--cuda-device-only", os.path.join(ROOT, "fuif_amd", "csrc", "transforms.hip"), "-o", out],
+                   check=True, stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    for name in ("k_idct8x8", "k_inv_ycbcr"):
+        m = re.search(r"^_ZN7fuifgpu\d+%s\w*:[^\n]*\n(.*?)s_endpgm" % name, text, re.S | re.M)
+        assert m, name
+        body = m.group(1)
+        assert not re.search(r"\bv_fmac?_f(64|32)", body), name + " holds fused multiply-adds"
+        if name == "k_idct8x8":
+            assert len(re.findall(r"\bv_mul_f64", body)) == 353
+            assert 896 <= len(re.findall(r"\bv_add_f64", body)) <= 896 + 3 * 64 + 1

@@ -42,6 +42,7 @@ SELECTED = [
     "tests/test_gpu_parity.py::test_batch_of_replicas_and_distinct_streams",
     "tests/test_gpu_parity.py::test_packed_output_is_the_pam_payload",
     "tests/test_gpu_parity.py::test_undo_transforms_is_once_per_decode",
+    "tests/test_gpu_parity.py::test_invalid_permutation_flags_the_image_and_zero_fills",
     "tests/test_gpu_group_parallel.py::test_reference_written_files_indexed_after_the_fact",
     "tests/test_gpu_group_parallel.py::test_previews_of_indexed_streams",
     "tests/test_gpu_group_parallel.py::test_writer_indexed_streams_vs_oracle[97-61-3-8-2]",

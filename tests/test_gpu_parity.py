@@ -145,3 +145,31 @@ def test_undo_transforms_is_once_per_decode(gpulib, manifest):
         assert all(np.array_equal(a, b) for a, b in zip(first, again))
     finally:
         batch.close()
+
+
+def test_invalid_permutation_flags_the_image_and_zero_fills(gpulib, manifest):
+    """a Permute whose permutation is stream data and comes out invalid (here: the stream ends right behind its header, the
+    meta-channel reads 0,0,0 -- a repeated channel number): the image is flagged corrupt and its output planes are ZERO,
+    not what the previous decode left in the output slab (k_permute_plane used to leave the slab as it was)"""
+    e = next(x for x in manifest["fixtures"] if x["name"] == "permute_channel_rgb8_48x40")
+    blob = golden_blob(e, e["cases"][0])
+    plan = gpulib.Plan(blob)
+    batch = gpulib.Batch(plan, 1, len(blob))
+    try:
+        for stream, good in ((blob, True), (blob[: plan.info.data_start], False), (blob, True)):
+            batch.upload([stream])
+            batch.decode()
+            batch.undo_transforms()
+            batch.sync()
+            st, _ = batch.status()
+            planes = batch.out_planes(0)
+            if good:
+                assert st[0] == 0
+                for g, exp in zip(planes, e["cases"][0]["post"]):
+                    assert plane_hash(g) == exp["sha256"]
+            else:
+                assert st[0] & 2
+                for g in planes:
+                    assert not g.any()
+    finally:
+        batch.close()

@@ -171,3 +171,54 @@ def test_c4_full_size_image_matches_oracle(gpulib, port):
         assert np.array_equal(g, e["data"])
     for k in range(4):
         assert np.array_equal(post[k], img[k])
+
+
+def test_two_batches_over_one_pair_of_slabs_pipeline_uploads(gpulib):
+    """the pipelining pattern behind bench.py's `value_incl_h2d` (INTEGRATION.md "Hiding the upload"): two Batches created over
+    the SAME external coefficient and output slabs; while one decodes on the launch stream, a host thread parses and uploads
+    the next set of streams into the other on a copy stream.  Three different sets of pictures go through, every one must
+    come out as its own source pixels."""
+    import threading
+    import torch
+    n = 4
+    sets = [[photographic(640, 480, 3, 8, seed=6000 + 10 * s + i) for i in range(n)] for s in range(3)]
+    blobs = [[gpulib.encode_image(im, 8, tree_mode=1, index=True) for im in st] for st in sets]
+    plan = gpulib.Plan(blobs[0][0])
+    info = plan.info
+    cap = max(sum(len(b) for b in bs) for bs in blobs)
+    coef = torch.empty(n * max(info.coef_elems, 1), dtype=torch.int32, device="cuda")
+    out = torch.empty(n * max(info.out_elems, 1), dtype=torch.int32, device="cuda")
+    pair = [gpulib.Batch(plan, n, cap, coef_ptr=coef.data_ptr(), out_ptr=out.data_ptr()) for _ in range(2)]
+    copy_stream = torch.cuda.Stream()
+    errors = []
+
+    def uploader(bt, bs):
+        try:
+            torch.cuda.set_device(0)
+            bt.upload(bs, stream=copy_stream.cuda_stream)
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    try:
+        pair[0].upload(blobs[0])
+        for k in range(3):
+            cur = pair[k % 2]
+            th = None
+            if k + 1 < 3:
+                th = threading.Thread(target=uploader, args=(pair[(k + 1) % 2], blobs[k + 1]))
+                th.start()
+            cur.decode()
+            cur.undo_transforms()
+            if th is not None:
+                th.join()
+            cur.sync()
+            assert not errors, errors
+            st, used = cur.status()
+            assert not st.any()
+            for i in range(n):
+                planes = cur.out_planes(i)
+                for c in range(3):
+                    assert np.array_equal(planes[c], sets[k][i][c]), (k, i, c)
+    finally:
+        for b in pair:
+            b.close()
