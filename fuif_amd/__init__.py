@@ -41,7 +41,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 def build(force=False, verbose=False):
     """Compile libfuifgpu.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(_HERE, "csrc", s) for s in _SOURCES]
-    deps = srcs + [os.path.join(_HERE, "csrc", h) for h in ("fuifgpu_internal.h", "maniac_decode.h", "transforms.h")]
+    deps = srcs + [os.path.join(_HERE, "csrc", h) for h in ("fuifgpu_internal.h", "maniac_decode.h", "transforms.h", "squeeze_arith.h")]
     deps.append(os.path.join(_HERE, "..", "include", "fuifgpu.h"))
     if os.environ.get("FUIF_AMD_LIB"):
         return _LIB_PATH

@@ -25,6 +25,7 @@
 
 #include "fuifgpu_internal.h"
 #include "transforms.h"
+#include "squeeze_arith.h"
 
 // The reference's x86-64 build has no fused multiply-add: every product and every sum of the FP64 paths (iDCT, YCbCr) is rounded
 // on its own.  hipcc fuses a*b+c into v_fma_f64 by default, in the backend, also through __dmul_rn / __dadd_rn (plain operators
@@ -41,26 +42,6 @@ namespace {
 
 DEV int32_t *plane_ptr(const Bases &b, const PlaneRef &p, int z) { return b.base[p.buf] + (int64_t)z * b.stride[p.buf] + p.off; }
 DEV int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
-// transform/squeeze.h:61-77.  C '/' truncates toward zero; the two clamps per branch are order dependent.
-DEV int smooth_tendency(int B, int a, int n) {
-    int diff = 0;
-    if (B >= a && a >= n) {
-        diff = (4 * B - 3 * n - a + 6) / 12;
-        if (diff - (diff & 1) > 2 * (B - a)) diff = 2 * (B - a) + 1;
-        if (diff + (diff & 1) > 2 * (a - n)) diff = 2 * (a - n);
-    } else if (B <= a && a <= n) {
-        diff = (4 * B - 3 * n - a - 6) / 12;
-        if (diff + (diff & 1) < 2 * (B - a)) diff = 2 * (B - a) - 1;
-        if (diff - (diff & 1) < 2 * (a - n)) diff = 2 * (a - n);
-    }
-    return diff;
-}
-// squeeze.h:103-107: A = ((avg<<1)+diff+(diff>0?-(diff&1):(diff&1)))>>1 ; B = A-diff
-DEV void unsqueeze_pair(int avg, int diff, int &A, int &B) {
-    A = ((avg << 1) + diff + (diff > 0 ? -(diff & 1) : (diff & 1))) >> 1;
-    B = A - diff;
-}
 
 }  // namespace
 
@@ -432,27 +413,6 @@ __global__ __launch_bounds__(256) void k_inv_ycocg(Bases b, PlaneRef p0, PlaneRe
     const int B = clampi(Y + ((1 - Cg) >> 1) - (Co >> 1), 0, maxval);
     const int R = clampi(Co + B, 0, maxval);
     *c0 = R; *c1 = G; *c2 = B;
-}
-
-// the same, four pixels per lane (16-byte accesses): rows whose pitch, offset and width are multiples of four samples
-__global__ __launch_bounds__(256) void k_inv_ycocg4(Bases b, PlaneRef p0, PlaneRef p1, PlaneRef p2, int w4, int h, int maxval) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= w4 || y >= h) return;
-    int4 *c0 = reinterpret_cast<int4 *>(plane_ptr(b, p0, blockIdx.z) + (int64_t)y * p0.w) + x;
-    int4 *c1 = reinterpret_cast<int4 *>(plane_ptr(b, p1, blockIdx.z) + (int64_t)y * p1.w) + x;
-    int4 *c2 = reinterpret_cast<int4 *>(plane_ptr(b, p2, blockIdx.z) + (int64_t)y * p2.w) + x;
-    const int4 vy = *c0, vo = *c1, vg = *c2;
-    const int Yv[4] = {vy.x, vy.y, vy.z, vy.w}, Cov[4] = {vo.x, vo.y, vo.z, vo.w}, Cgv[4] = {vg.x, vg.y, vg.z, vg.w};
-    int R[4], G[4], B[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int Y = clampi(Yv[k], 0, maxval);
-        G[k] = clampi(Y - ((-Cgv[k]) >> 1), 0, maxval);
-        B[k] = clampi(Y + ((1 - Cgv[k]) >> 1) - (Cov[k] >> 1), 0, maxval);
-        R[k] = clampi(Cov[k] + B[k], 0, maxval);
-    }
-    *c0 = make_int4(R[0], R[1], R[2], R[3]); *c1 = make_int4(G[0], G[1], G[2], G[3]); *c2 = make_int4(B[0], B[1], B[2], B[3]);
 }
 
 // transform/ycbcr.h:49-60: `float` operands, double arithmetic left to right, no contraction,
@@ -934,7 +894,7 @@ void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMe
         case OP_HSQUEEZE: {
             const int h = op.src[0].h;
             if (h <= 0 || op.dst[0].w <= 0) break;
-            static const int tiles = [] { const char *e = getenv("FUIFGPU_HSQUEEZE_TILES"); return e ? atoi(e) : 0; }();
+            static const int tiles = [] { const char *e = getenv("FUIFGPU_HSQUEEZE_TILES"); return e ? atoi(e) : 1; }();   // 0: the lane-per-row kernel for every width (A/B measurements)
             if (tiles && op.src[1].w >= 2 * HL_P)
                 hipLaunchKernelGGL(k_inv_hsqueeze_tiles, dim3((h + 63) / 64, 1, n_images), dim3(64), 0, stream, b, op.src[0], op.src[1],
                                    op.dst[0], op.clamp_out, op.lo, op.hi);
@@ -951,13 +911,6 @@ void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMe
             break;
         }
         case OP_YCOCG:
-            if (op.p0 % 4 == 0 && op.src[0].w % 4 == 0 && op.src[1].w % 4 == 0 && op.src[2].w % 4 == 0 && op.src[0].off % 4 == 0 &&
-                op.src[1].off % 4 == 0 && op.src[2].off % 4 == 0 && b.stride[op.src[0].buf] % 4 == 0 && b.stride[op.src[1].buf] % 4 == 0 &&
-                b.stride[op.src[2].buf] % 4 == 0 && ((uintptr_t)b.base[op.src[0].buf] | (uintptr_t)b.base[op.src[1].buf] | (uintptr_t)b.base[op.src[2].buf]) % 16 == 0) {
-                hipLaunchKernelGGL(k_inv_ycocg4, dim3((op.p0 / 4 + 255) / 256, op.p1, n_images), dim3(256), 0, stream, b, op.src[0], op.src[1],
-                                   op.src[2], op.p0 / 4, op.p1, op.hi);
-                break;
-            }
             hipLaunchKernelGGL(k_inv_ycocg, dim3((op.p0 + 255) / 256, op.p1, n_images), dim3(256), 0, stream, b, op.src[0], op.src[1], op.src[2],
                                op.p0, op.p1, op.hi);
             break;

@@ -105,6 +105,7 @@ static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; 
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 // EMU_WAVES: persistent wavefronts of the entropy kernel (each becomes a workgroup; run them on EMU_THREADS >= EMU_WAVES threads)
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { const char *e = getenv("EMU_WAVES"); p->multiProcessorCount = e ? std::max(1, atoi(e)) : 1; return hipSuccess; }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }   // v_mul_hi_u32
 static inline int __mul24(int a, int b) { return (int)((unsigned)(((a << 8) >> 8)) * (unsigned)(((b << 8) >> 8))); }   // v_mul_i32_i24: the low 24 bits of both factors, sign extended
 static inline hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) { *free_b = (size_t)1 << 30; *total_b = (size_t)2 << 30; return hipSuccess; }
 template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, K, int, size_t) { *n = 1; return hipSuccess; }
