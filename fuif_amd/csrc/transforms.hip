@@ -187,19 +187,25 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze_tiles(Bases b, PlaneRef pa,
     int left = avg;   // first pair: tendency(avg, avg, next), squeeze.h:89
     int x = 0;
     int32_t *t_res = tile, *t_avg = tile + 64 * HL_IN_PITCH;
-    for (; x + HL_P < w1 && x + HL_P <= w2; x += HL_P) {   // avg[x+1 .. x+HL_P] all exist
-        {
-            const int piece = lane & 7, sub = lane >> 3;
+    // Software pipeline: the global loads of tile k+1 are issued before tile k is computed and wait in registers (the
+    // occupancy is set by the LDS tile, two wavefronts per SIMD; registers are free)
+    const int piece8 = lane & 7, sub8 = lane >> 3;
+    Int4U grv[8], gnv[8];
+    auto fetch = [&](int xt) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int row = 8 * i + sub;
-                if (row < rows) {
-                    const Int4U rv = *reinterpret_cast<const Int4U *>(R + (int64_t)row * w2 + x + 4 * piece);
-                    const Int4U nv = *reinterpret_cast<const Int4U *>(A + (int64_t)row * w1 + x + 1 + 4 * piece);
-                    *reinterpret_cast<int4 *>(t_res + row * HL_IN_PITCH + 4 * piece) = make_int4(rv.v[0], rv.v[1], rv.v[2], rv.v[3]);
-                    *reinterpret_cast<int4 *>(t_avg + row * HL_IN_PITCH + 4 * piece) = make_int4(nv.v[0], nv.v[1], nv.v[2], nv.v[3]);
-                }
-            }
+        for (int i = 0; i < 8; i++) {
+            const int row = min(8 * i + sub8, rows - 1);   // rows beyond the plane repeat its last row: no branches around the loads
+            grv[i] = *reinterpret_cast<const Int4U *>(R + (int64_t)row * w2 + xt + 4 * piece8);
+            gnv[i] = *reinterpret_cast<const Int4U *>(A + (int64_t)row * w1 + xt + 1 + 4 * piece8);
+        }
+    };
+    if (HL_P < w1 && HL_P <= w2) fetch(0);
+    for (; x + HL_P < w1 && x + HL_P <= w2; x += HL_P) {   // avg[x+1 .. x+HL_P] all exist
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int row = 8 * i + sub8;
+            *reinterpret_cast<int4 *>(t_res + row * HL_IN_PITCH + 4 * piece8) = make_int4(grv[i].v[0], grv[i].v[1], grv[i].v[2], grv[i].v[3]);
+            *reinterpret_cast<int4 *>(t_avg + row * HL_IN_PITCH + 4 * piece8) = make_int4(gnv[i].v[0], gnv[i].v[1], gnv[i].v[2], gnv[i].v[3]);
         }
         __syncthreads();
         int4 rv[HL_P / 4], nv[HL_P / 4];
@@ -209,6 +215,7 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze_tiles(Bases b, PlaneRef pa,
             nv[q] = *reinterpret_cast<const int4 *>(t_avg + lane * HL_IN_PITCH + 4 * q);
         }
         __syncthreads();   // every lane has its inputs: the output tile may overwrite them
+        if (x + 2 * HL_P < w1 && x + 2 * HL_P <= w2) fetch(x + HL_P);
 #pragma unroll
         for (int q = 0; q < HL_P / 4; q++) {
             const int rr[4] = {rv[q].x, rv[q].y, rv[q].z, rv[q].w}, nn[4] = {nv[q].x, nv[q].y, nv[q].z, nv[q].w};
@@ -298,22 +305,20 @@ __global__ __launch_bounds__(64) void k_inv_hsq2_ycocg(Bases b, PlaneRef pa0, Pl
             const int piece = lane & 3, sub = lane >> 2;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const int row = 16 * i + sub;
-                if (row < rows) {
+                const int row = 16 * i + sub, src = min(row, rows - 1);   // rows beyond the plane repeat its last row: no branches around the loads
 #pragma unroll
-                    for (int c = 0; c < 2; c++) {
-                        const Int4U rv = *reinterpret_cast<const Int4U *>(R[c] + (int64_t)row * w2 + x + 4 * piece);
-                        const Int4U nv = *reinterpret_cast<const Int4U *>(A[c] + (int64_t)row * w1 + x + 1 + 4 * piece);
-                        *reinterpret_cast<int4 *>(tile + (2 * c) * 64 * HF_IN_PITCH + row * HF_IN_PITCH + 4 * piece) = make_int4(rv.v[0], rv.v[1], rv.v[2], rv.v[3]);
-                        *reinterpret_cast<int4 *>(tile + (2 * c + 1) * 64 * HF_IN_PITCH + row * HF_IN_PITCH + 4 * piece) = make_int4(nv.v[0], nv.v[1], nv.v[2], nv.v[3]);
-                    }
+                for (int c = 0; c < 2; c++) {
+                    const Int4U rv = *reinterpret_cast<const Int4U *>(R[c] + (int64_t)src * w2 + x + 4 * piece);
+                    const Int4U nv = *reinterpret_cast<const Int4U *>(A[c] + (int64_t)src * w1 + x + 1 + 4 * piece);
+                    *reinterpret_cast<int4 *>(tile + (2 * c) * 64 * HF_IN_PITCH + row * HF_IN_PITCH + 4 * piece) = make_int4(rv.v[0], rv.v[1], rv.v[2], rv.v[3]);
+                    *reinterpret_cast<int4 *>(tile + (2 * c + 1) * 64 * HF_IN_PITCH + row * HF_IN_PITCH + 4 * piece) = make_int4(nv.v[0], nv.v[1], nv.v[2], nv.v[3]);
                 }
             }
             const int ypiece = lane & 7, ysub = lane >> 3;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                const int row = 8 * i + ysub;
-                if (row < rows) yv[i] = *reinterpret_cast<const Int4U *>(OY + (int64_t)row * py.w + 2 * x + 4 * ypiece);
+                const int row = min(8 * i + ysub, rows - 1);
+                yv[i] = *reinterpret_cast<const Int4U *>(OY + (int64_t)row * py.w + 2 * x + 4 * ypiece);
             }
         }
         __syncthreads();
