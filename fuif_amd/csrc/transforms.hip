@@ -276,7 +276,7 @@ constexpr int HF_IN_PITCH = HF_P + 4;
 constexpr int HF_OUT_PITCH = 2 * HF_P + 4;
 __global__ __launch_bounds__(64) void k_inv_hsq2_ycocg(Bases b, PlaneRef pa0, PlaneRef pr0, PlaneRef pa1, PlaneRef pr1, PlaneRef py, PlaneRef pg, PlaneRef pb,
                                                        int maxval) {
-    __shared__ __attribute__((aligned(16))) int32_t tile[4 * 64 * HF_IN_PITCH];   // 20480 bytes: per chroma plane a residual and an average tile, later its 64 x 36-word output tile
+    __shared__ __attribute__((aligned(16))) int32_t tile[4 * 64 * HF_IN_PITCH];   // 20480 bytes; the two 64 x 36-word output tiles need 18432
     const int lane = threadIdx.x;
     const int y0 = blockIdx.x * 64;
     const int w1 = pa0.w, w2 = pr0.w, h = pa0.h, wo = w1 + w2;
@@ -298,32 +298,20 @@ __global__ __launch_bounds__(64) void k_inv_hsq2_ycocg(Bases b, PlaneRef pa0, Pl
         Rr = clampi(Co + Bb, 0, maxval);
     };
     int x = 0;
-    // Software pipeline as in k_inv_hsqueeze_tiles: the chroma inputs of tile k+1 are fetched before tile k is computed.
-    // 4 lanes per 64-byte input row segment, 16 rows per instruction; Y: 8 lanes per 128-byte segment, 8 rows per instruction
-    const int piece4 = lane & 3, sub4 = lane >> 2;
-    Int4U grv[2][4], gnv[2][4];
-    auto fetch = [&](int xt) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int src = min(16 * i + sub4, rows - 1);   // rows beyond the plane repeat its last row: no branches around the loads
-#pragma unroll
-            for (int c = 0; c < 2; c++) {
-                grv[c][i] = *reinterpret_cast<const Int4U *>(R[c] + (int64_t)src * w2 + xt + 4 * piece4);
-                gnv[c][i] = *reinterpret_cast<const Int4U *>(A[c] + (int64_t)src * w1 + xt + 1 + 4 * piece4);
-            }
-        }
-    };
-    if (HF_P < w1 && HF_P <= w2) fetch(0);
     for (; x + HF_P < w1 && x + HF_P <= w2; x += HF_P) {   // avg[x+1 .. x+HF_P] all exist
         Int4U yv[8];
         {
+            // 4 lanes per 64-byte input row segment, 16 rows per instruction; Y: 8 lanes per 128-byte segment, 8 rows per instruction
+            const int piece = lane & 3, sub = lane >> 2;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const int row = 16 * i + sub4;
+                const int row = 16 * i + sub, src = min(row, rows - 1);   // rows beyond the plane repeat its last row: no branches around the loads
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
-                    *reinterpret_cast<int4 *>(tile + (2 * c) * 64 * HF_IN_PITCH + row * HF_IN_PITCH + 4 * piece4) = make_int4(grv[c][i].v[0], grv[c][i].v[1], grv[c][i].v[2], grv[c][i].v[3]);
-                    *reinterpret_cast<int4 *>(tile + (2 * c + 1) * 64 * HF_IN_PITCH + row * HF_IN_PITCH + 4 * piece4) = make_int4(gnv[c][i].v[0], gnv[c][i].v[1], gnv[c][i].v[2], gnv[c][i].v[3]);
+                    const Int4U rv = *reinterpret_cast<const Int4U *>(R[c] + (int64_t)src * w2 + x + 4 * piece);
+                    const Int4U nv = *reinterpret_cast<const Int4U *>(A[c] + (int64_t)src * w1 + x + 1 + 4 * piece);
+                    *reinterpret_cast<int4 *>(tile + (2 * c) * 64 * HF_IN_PITCH + row * HF_IN_PITCH + 4 * piece) = make_int4(rv.v[0], rv.v[1], rv.v[2], rv.v[3]);
+                    *reinterpret_cast<int4 *>(tile + (2 * c + 1) * 64 * HF_IN_PITCH + row * HF_IN_PITCH + 4 * piece) = make_int4(nv.v[0], nv.v[1], nv.v[2], nv.v[3]);
                 }
             }
             const int ypiece = lane & 7, ysub = lane >> 3;
@@ -334,22 +322,20 @@ __global__ __launch_bounds__(64) void k_inv_hsq2_ycocg(Bases b, PlaneRef pa0, Pl
             }
         }
         __syncthreads();
-        // one chroma plane at a time: its 64 x 32 outputs go over ITS two input tiles (2 x 64 x 20 words hold 64 x 36), so only one
-        // plane's inputs are in registers at a time while the next tile's inputs wait in theirs
+        int4 rv[2][HF_P / 4], nv[2][HF_P / 4];
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
-            int32_t *t_c = tile + c * (2 * 64 * HF_IN_PITCH);
-            int4 rv[HF_P / 4], nv[HF_P / 4];
+        for (int c = 0; c < 2; c++)
 #pragma unroll
             for (int q = 0; q < HF_P / 4; q++) {
-                rv[q] = *reinterpret_cast<const int4 *>(t_c + lane * HF_IN_PITCH + 4 * q);
-                nv[q] = *reinterpret_cast<const int4 *>(t_c + 64 * HF_IN_PITCH + lane * HF_IN_PITCH + 4 * q);
+                rv[c][q] = *reinterpret_cast<const int4 *>(tile + (2 * c) * 64 * HF_IN_PITCH + lane * HF_IN_PITCH + 4 * q);
+                nv[c][q] = *reinterpret_cast<const int4 *>(tile + (2 * c + 1) * 64 * HF_IN_PITCH + lane * HF_IN_PITCH + 4 * q);
             }
-            __syncthreads();   // every lane has this plane's inputs: its output tile may overwrite them
-            if (c == 0 && x + 2 * HF_P < w1 && x + 2 * HF_P <= w2) fetch(x + HF_P);
+        __syncthreads();   // every lane has its inputs: the output tiles may overwrite them
+#pragma unroll
+        for (int c = 0; c < 2; c++)
 #pragma unroll
             for (int q = 0; q < HF_P / 4; q++) {
-                const int rr[4] = {rv[q].x, rv[q].y, rv[q].z, rv[q].w}, nn[4] = {nv[q].x, nv[q].y, nv[q].z, nv[q].w};
+                const int rr[4] = {rv[c][q].x, rv[c][q].y, rv[c][q].z, rv[c][q].w}, nn[4] = {nv[c][q].x, nv[c][q].y, nv[c][q].z, nv[c][q].w};
                 int ov[8];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -361,10 +347,9 @@ __global__ __launch_bounds__(64) void k_inv_hsq2_ycocg(Bases b, PlaneRef pa0, Pl
                     avg[c] = next_avg;
                     ov[2 * k] = A2; ov[2 * k + 1] = B2;
                 }
-                *reinterpret_cast<int4 *>(t_c + lane * HF_OUT_PITCH + 8 * q) = make_int4(ov[0], ov[1], ov[2], ov[3]);
-                *reinterpret_cast<int4 *>(t_c + lane * HF_OUT_PITCH + 8 * q + 4) = make_int4(ov[4], ov[5], ov[6], ov[7]);
+                *reinterpret_cast<int4 *>(tile + c * 64 * HF_OUT_PITCH + lane * HF_OUT_PITCH + 8 * q) = make_int4(ov[0], ov[1], ov[2], ov[3]);
+                *reinterpret_cast<int4 *>(tile + c * 64 * HF_OUT_PITCH + lane * HF_OUT_PITCH + 8 * q + 4) = make_int4(ov[4], ov[5], ov[6], ov[7]);
             }
-        }
         __syncthreads();
         {
             const int piece = lane & 7, sub = lane >> 3;
@@ -373,7 +358,7 @@ __global__ __launch_bounds__(64) void k_inv_hsq2_ycocg(Bases b, PlaneRef pa0, Pl
                 const int row = 8 * i + sub;
                 if (row < rows) {
                     const int4 co = *reinterpret_cast<const int4 *>(tile + row * HF_OUT_PITCH + 4 * piece);
-                    const int4 cg = *reinterpret_cast<const int4 *>(tile + 2 * 64 * HF_IN_PITCH + row * HF_OUT_PITCH + 4 * piece);
+                    const int4 cg = *reinterpret_cast<const int4 *>(tile + 64 * HF_OUT_PITCH + row * HF_OUT_PITCH + 4 * piece);
                     const int cov[4] = {co.x, co.y, co.z, co.w}, cgv[4] = {cg.x, cg.y, cg.z, cg.w};
                     Int4U r4, g4, b4;
 #pragma unroll
