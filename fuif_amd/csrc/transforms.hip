@@ -166,11 +166,17 @@ __global__ __launch_bounds__(256) void k_inv_hsqueeze_rows(Bases b, PlaneRef pa,
 // 2*HL_P outputs back into LDS (the output tile aliases the input tiles: every lane holds its inputs in registers by then)
 // and the tile is written out 16 lanes per 256-byte output row.  Row pitches of 36 / 68 words keep the b128 LDS accesses of
 // 16 neighbouring lanes on different banks.
-constexpr int HL_P = 32;
+#ifndef FUIF_HL_P
+#define FUIF_HL_P 32
+#endif
+constexpr int HL_P = FUIF_HL_P;            // pairs per tile row: 32 (128-byte input segments, 18 KB of LDS) or 16 (64-byte segments, 9 KB)
+constexpr int HL_IN_LANES = HL_P / 4;      // lanes that fetch one input row segment (16 bytes each)
+constexpr int HL_IN_STEPS = HL_P / 4;      // load instructions per input tile: 64 rows / (64 / HL_IN_LANES) rows per instruction
+constexpr int HL_OUT_LANES = HL_P / 2, HL_OUT_STEPS = HL_P / 2;
 constexpr int HL_IN_PITCH = HL_P + 4;        // words
 constexpr int HL_OUT_PITCH = 2 * HL_P + 4;
 __global__ __launch_bounds__(64) void k_inv_hsqueeze_tiles(Bases b, PlaneRef pa, PlaneRef pr, PlaneRef po, int clamp, int lo, int hi) {
-    __shared__ __attribute__((aligned(16))) int32_t tile[2 * 64 * HL_IN_PITCH];   // 18432 bytes; the 64 x 68-word output tile needs 17408
+    __shared__ __attribute__((aligned(16))) int32_t tile[2 * 64 * HL_IN_PITCH];   // HL_P = 32: 18432 bytes; the 64 x 68-word output tile needs 17408
     const int lane = threadIdx.x;
     const int y0 = blockIdx.x * 64;
     const int w1 = pa.w, w2 = pr.w, h = pa.h, wo = w1 + w2;
@@ -189,12 +195,12 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze_tiles(Bases b, PlaneRef pa,
     int32_t *t_res = tile, *t_avg = tile + 64 * HL_IN_PITCH;
     // Software pipeline: the global loads of tile k+1 are issued before tile k is computed and wait in registers (the
     // occupancy is set by the LDS tile, two wavefronts per SIMD; registers are free)
-    const int piece8 = lane & 7, sub8 = lane >> 3;
-    Int4U grv[8], gnv[8];
+    const int piece8 = lane % HL_IN_LANES, sub8 = lane / HL_IN_LANES;
+    Int4U grv[HL_IN_STEPS], gnv[HL_IN_STEPS];
     auto fetch = [&](int xt) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int row = min(8 * i + sub8, rows - 1);   // rows beyond the plane repeat its last row: no branches around the loads
+        for (int i = 0; i < HL_IN_STEPS; i++) {
+            const int row = min((64 / HL_IN_LANES) * i + sub8, rows - 1);   // rows beyond the plane repeat its last row: no branches around the loads
             grv[i] = *reinterpret_cast<const Int4U *>(R + (int64_t)row * w2 + xt + 4 * piece8);
             gnv[i] = *reinterpret_cast<const Int4U *>(A + (int64_t)row * w1 + xt + 1 + 4 * piece8);
         }
@@ -202,8 +208,8 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze_tiles(Bases b, PlaneRef pa,
     if (HL_P < w1 && HL_P <= w2) fetch(0);
     for (; x + HL_P < w1 && x + HL_P <= w2; x += HL_P) {   // avg[x+1 .. x+HL_P] all exist
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int row = 8 * i + sub8;
+        for (int i = 0; i < HL_IN_STEPS; i++) {
+            const int row = (64 / HL_IN_LANES) * i + sub8;
             *reinterpret_cast<int4 *>(t_res + row * HL_IN_PITCH + 4 * piece8) = make_int4(grv[i].v[0], grv[i].v[1], grv[i].v[2], grv[i].v[3]);
             *reinterpret_cast<int4 *>(t_avg + row * HL_IN_PITCH + 4 * piece8) = make_int4(gnv[i].v[0], gnv[i].v[1], gnv[i].v[2], gnv[i].v[3]);
         }
@@ -236,10 +242,10 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze_tiles(Bases b, PlaneRef pa,
         }
         __syncthreads();
         {
-            const int piece = lane & 15, sub = lane >> 4;
+            const int piece = lane % HL_OUT_LANES, sub = lane / HL_OUT_LANES;
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int row = 4 * i + sub;
+            for (int i = 0; i < HL_OUT_STEPS; i++) {
+                const int row = (64 / HL_OUT_LANES) * i + sub;
                 if (row < rows) {
                     const int4 v = *reinterpret_cast<const int4 *>(tile + row * HL_OUT_PITCH + 4 * piece);
                     Int4U u; u.v[0] = v.x; u.v[1] = v.y; u.v[2] = v.z; u.v[3] = v.w;
