@@ -701,51 +701,69 @@ def main():
         t_h2d = time.perf_counter() - t0
         serial = round(args.batch * W * H / 1e6 / (t_h2d + ms_per_step / 1e3), 3)
         h2d = {"upload_s": round(t_h2d, 3), "bytes": int(sum(len(b) for b in separate)), "value_serial": serial, "unit": "Mpixels/s"}
-        try:
-            other = fuif_amd.Batch(plan, args.batch, sum(len(b) for b in blobs), coef_ptr=batch.coef_ptr(0), out_ptr=out.data_ptr())
-        except fuif_amd.FuifGpuError as e:
-            other = None
-            h2d["pipelined_error"] = str(e)
+        # the second Batch needs its own stream buffer, transform arena and context arenas next to the first one's: hand torch's
+        # cached blocks (checksum temporaries, the packed pictures) back to the device first and size the arena to what is free
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        blob_bytes = sum(len(b) for b in blobs)
+        per_tmp = 4 * max(int(info.tmp_elems), 1)
+        spare = free_b - blob_bytes - (2 << 30)
+        tmp_images = int(min(args.batch, (8 << 30) // per_tmp, spare // 3 // per_tmp)) if spare > 0 else 0
+        h2d["free_device_bytes_before_second_batch"] = int(free_b)
+        other = None
+        if tmp_images < 1:
+            h2d["pipelined_error"] = "not enough free device memory for a second set of stream buffers"
+        else:
+            try:
+                other = fuif_amd.Batch(plan, args.batch, blob_bytes, coef_ptr=batch.coef_ptr(0), out_ptr=out.data_ptr(), tmp_images=tmp_images)
+            except fuif_amd.FuifGpuError as e:
+                h2d["pipelined_error"] = str(e)
         if other is not None:
-            other.set_group_parallel(not args.no_index)
-            copy_stream = torch.cuda.Stream(device=dev)
-            pair, up_s, failed = [batch, other], [], []
+            try:
+                other.set_group_parallel(not args.no_index)
+                copy_stream = torch.cuda.Stream(device=dev)
+                pair, up_s, failed = [batch, other], [], []
 
-            def uploader(bt):
-                try:
-                    torch.cuda.set_device(dev)
-                    t = time.perf_counter()
-                    bt.upload(separate, stream=copy_stream.cuda_stream)     # returns after its copies have landed
-                    up_s.append(time.perf_counter() - t)
-                except Exception as e:                                       # noqa: BLE001 -- reported in the JSON line
-                    failed.append(repr(e))
+                def uploader(bt):
+                    try:
+                        torch.cuda.set_device(dev)
+                        t = time.perf_counter()
+                        bt.upload(separate, stream=copy_stream.cuda_stream)     # returns after its copies have landed
+                        up_s.append(time.perf_counter() - t)
+                    except Exception as e:                                       # noqa: BLE001 -- reported in the JSON line
+                        failed.append(repr(e))
 
-            n_pipe = max(2, args.steps)
-            # `batch` holds step 0's streams already (the serial upload above); the first overlapped upload also allocates
-            th = threading.Thread(target=uploader, args=(other,))
-            th.start()
-            step()
-            th.join()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for k in range(1, n_pipe + 1):
-                th = threading.Thread(target=uploader, args=(pair[(k + 1) % 2],))
+                n_pipe = max(2, args.steps)
+                # `batch` holds step 0's streams already (the serial upload above); the first overlapped upload also allocates
+                th = threading.Thread(target=uploader, args=(other,))
                 th.start()
-                pair[k % 2].decode()
-                pair[k % 2].undo_transforms()
+                step()
                 th.join()
-                pair[k % 2].sync()
-            torch.cuda.synchronize()
-            t_pipe = (time.perf_counter() - t0) / n_pipe
-            st3, _ = pair[n_pipe % 2].status()
-            same = bool(torch.equal(fd.plane_checksums(view), checks)) and not st3.any() and not failed
-            ok = ok and same
-            h2d.update({"value_incl_h2d": round(args.batch * W * H / 1e6 / t_pipe, 3), "ms_per_step_pipelined": round(t_pipe * 1e3, 3),
-                        "pipelined_steps": n_pipe, "upload_s_beside_the_kernel": round(sum(up_s[1:]) / max(1, len(up_s) - 1), 3),
-                        "identical_output": same, "errors": failed or None,
-                        "note": "steady state of a two-deep pipeline: every step's %d streams are parsed on the host and copied from pageable "
-                                "memory on a copy stream into the second Batch's buffers while the previous step decodes; both Batches decode "
-                                "into one pair of slabs; a job's very first upload (upload_s) is not hidden" % args.batch})
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for k in range(1, n_pipe + 1):
+                    th = threading.Thread(target=uploader, args=(pair[(k + 1) % 2],))
+                    th.start()
+                    pair[k % 2].decode()
+                    pair[k % 2].undo_transforms()
+                    th.join()
+                    pair[k % 2].sync()
+                torch.cuda.synchronize()
+                t_pipe = (time.perf_counter() - t0) / n_pipe
+                st3, _ = pair[n_pipe % 2].status()
+                same = bool(torch.equal(fd.plane_checksums(view), checks)) and not st3.any() and not failed
+                ok = ok and same
+                h2d.update({"value_incl_h2d": round(args.batch * W * H / 1e6 / t_pipe, 3), "ms_per_step_pipelined": round(t_pipe * 1e3, 3),
+                            "pipelined_steps": n_pipe, "upload_s_beside_the_kernel": round(sum(up_s[1:]) / max(1, len(up_s) - 1), 3),
+                            "identical_output": same, "errors": failed or None,
+                            "note": "steady state of a two-deep pipeline: every step's %d streams are parsed on the host and copied from pageable "
+                                    "memory on a copy stream into the second Batch's buffers while the previous step decodes; both Batches decode "
+                                    "into one pair of slabs; a job's very first upload (upload_s) is not hidden" % args.batch})
+            except (RuntimeError, fuif_amd.FuifGpuError) as e:   # e.g. torch out of memory in the checksum pass: report, keep the serial figure
+                h2d["pipelined_error"] = repr(e)[:300]
+                h2d["value_incl_h2d"] = serial
             other.close()
         else:
             h2d.update({"value_incl_h2d": serial, "note": "host parse of every stream + H2D copies from pageable memory + one step; not overlapped"})
