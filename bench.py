@@ -685,8 +685,8 @@ def main():
         ok = ok and seq["identical_output"]
 
     # PCIe-inclusive rate: the boundary takes HOST buffers.  (1) serial: one upload of the whole batch from 1024 separate host blobs
-    # (no replica shortcut), then one step.  (2) pipelined: a second Batch over the SAME coefficient and output slabs
-    # (fuifgpu_batch_create's coef_ext / out_ext) owns the other set of stream buffers, tile lists and context arenas; a host
+    # (no replica shortcut), then one step.  (2) pipelined: a sibling Batch (fuifgpu_batch_create_sibling) owns a second set of stream
+    # buffers and tile lists over the SAME slabs, decoder scratch and arenas; a host
     # thread parses and uploads step k+1 into it on a copy stream while step k's kernels run.  Reported next to `value`, never
     # as `value`.
     h2d = None
@@ -701,25 +701,18 @@ def main():
         t_h2d = time.perf_counter() - t0
         serial = round(args.batch * W * H / 1e6 / (t_h2d + ms_per_step / 1e3), 3)
         h2d = {"upload_s": round(t_h2d, 3), "bytes": int(sum(len(b) for b in separate)), "value_serial": serial, "unit": "Mpixels/s"}
-        # the second Batch needs its own stream buffer, transform arena and context arenas next to the first one's: hand torch's
-        # cached blocks (checksum temporaries, the packed pictures) back to the device first and size the arena to what is free
+        # a sibling Batch: a second set of stream buffers (fuifgpu_batch_create_sibling); it launches with the first one's slabs,
+        # decoder scratch, context arenas and transform arena
         import gc
         gc.collect()
         torch.cuda.empty_cache()
         free_b, _ = torch.cuda.mem_get_info(dev)
-        blob_bytes = sum(len(b) for b in blobs)
-        per_tmp = 4 * max(int(info.tmp_elems), 1)
-        spare = free_b - blob_bytes - (2 << 30)
-        tmp_images = int(min(args.batch, (8 << 30) // per_tmp, spare // 3 // per_tmp)) if spare > 0 else 0
-        h2d["free_device_bytes_before_second_batch"] = int(free_b)
+        h2d["free_device_bytes_before_sibling"] = int(free_b)
         other = None
-        if tmp_images < 1:
-            h2d["pipelined_error"] = "not enough free device memory for a second set of stream buffers"
-        else:
-            try:
-                other = fuif_amd.Batch(plan, args.batch, blob_bytes, coef_ptr=batch.coef_ptr(0), out_ptr=out.data_ptr(), tmp_images=tmp_images)
-            except fuif_amd.FuifGpuError as e:
-                h2d["pipelined_error"] = str(e)
+        try:
+            other = batch.sibling(sum(len(b) for b in blobs))
+        except fuif_amd.FuifGpuError as e:
+            h2d["pipelined_error"] = str(e)
         if other is not None:
             try:
                 other.set_group_parallel(not args.no_index)
@@ -759,7 +752,7 @@ def main():
                             "pipelined_steps": n_pipe, "upload_s_beside_the_kernel": round(sum(up_s[1:]) / max(1, len(up_s) - 1), 3),
                             "identical_output": same, "errors": failed or None,
                             "note": "steady state of a two-deep pipeline: every step's %d streams are parsed on the host and copied from pageable "
-                                    "memory on a copy stream into the second Batch's buffers while the previous step decodes; both Batches decode "
+                                    "memory on a copy stream into the sibling Batch's stream buffers while the previous step decodes; both decode "
                                     "into one pair of slabs; a job's very first upload (upload_s) is not hidden" % args.batch})
             except (RuntimeError, fuif_amd.FuifGpuError) as e:   # e.g. torch out of memory in the checksum pass: report, keep the serial figure
                 h2d["pipelined_error"] = repr(e)[:300]

@@ -78,7 +78,7 @@ class EncodeOptions(C.Structure):
 ABI_SYMBOLS = [
     "fuifgpu_strerror", "fuifgpu_last_error", "fuifgpu_abi_version", "fuifgpu_plan_create", "fuifgpu_plan_destroy",
     "fuifgpu_plan_info", "fuifgpu_plan_coded_channel", "fuifgpu_plan_output_channel", "fuifgpu_plan_transform",
-    "fuifgpu_build_chance_table", "fuifgpu_batch_create", "fuifgpu_batch_destroy", "fuifgpu_batch_upload",
+    "fuifgpu_build_chance_table", "fuifgpu_batch_create", "fuifgpu_batch_create_sibling", "fuifgpu_batch_destroy", "fuifgpu_batch_upload",
     "fuifgpu_batch_decode", "fuifgpu_batch_undo_transforms", "fuifgpu_batch_sync", "fuifgpu_batch_status",
     "fuifgpu_batch_channel_meta", "fuifgpu_batch_coef_ptr", "fuifgpu_batch_out_ptr", "fuifgpu_batch_download_coef",
     "fuifgpu_batch_download_out", "fuifgpu_batch_last_timing", "fuifgpu_batch_profile", "fuifgpu_batch_tile_log", "fuifgpu_batch_sched_stats", "fuifgpu_inv_hsqueeze", "fuifgpu_inv_vsqueeze",
@@ -131,6 +131,7 @@ def lib():
     L.fuifgpu_plan_transform.argtypes = [vp, C.c_int, i32p, vp, C.c_int, i32p]
     L.fuifgpu_build_chance_table.argtypes = [vp, C.c_uint32, C.c_int]; L.fuifgpu_build_chance_table.restype = None
     L.fuifgpu_batch_create.argtypes = [vp, C.c_int, C.c_size_t, vp, vp, C.c_int, C.POINTER(vp)]
+    L.fuifgpu_batch_create_sibling.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.fuifgpu_batch_destroy.argtypes = [vp]; L.fuifgpu_batch_destroy.restype = None
     L.fuifgpu_batch_upload.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, vp]
     L.fuifgpu_batch_decode.argtypes = [vp, vp]
@@ -229,6 +230,16 @@ class Batch:
         self._h = C.c_void_p()
         _check(L.fuifgpu_batch_create(plan._h, n_images, blob_capacity, coef_ptr, out_ptr, tmp_images, C.byref(self._h)))
         self._keep = None
+
+    def sibling(self, blob_capacity):
+        """a second set of stream buffers over this Batch's slabs, scratch and arenas (fuifgpu_batch_create_sibling): upload
+        into one while the other decodes.  Upload `self` once before the sibling's first upload; close the sibling first."""
+        other = Batch.__new__(Batch)
+        other.plan, other.n, other._keep = self.plan, self.n, None
+        other._h = C.c_void_p()
+        other._primary = self          # keeps the primary alive as long as the sibling
+        _check(lib().fuifgpu_batch_create_sibling(self._h, blob_capacity, C.byref(other._h)))
+        return other
 
     def close(self):
         if getattr(self, "_h", None) and _lib is not None:

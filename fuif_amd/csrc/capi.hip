@@ -66,7 +66,11 @@ struct fuifgpu_batch {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool decode_timed = false, transform_timed = false;
     bool coef_consumed = false;   // undo_transforms has run on the current decode: several inverse steps work in place on the coefficients
+    // A sibling (fuifgpu_batch_create_sibling) owns only what an UPLOAD writes -- stream bytes, tile lists, per-image results -- and
+    // decodes with the primary's slabs, decoder scratch, context arenas and transform arena (everything a LAUNCH uses)
+    fuifgpu_batch *share = nullptr;
 };
+static inline const fuifgpu_batch *launch_res(const fuifgpu_batch *b) { return b->share ? b->share : b; }
 
 static thread_local std::string g_last_error;
 
@@ -190,9 +194,9 @@ void fuifgpu_batch_destroy(fuifgpu_batch *b) {
     delete b;
 }
 
-int fuifgpu_batch_create(const fuifgpu_plan *plan, int n_images, size_t blob_capacity_bytes, int32_t *coef_ext, int32_t *out_ext,
-                         int tmp_images, fuifgpu_batch **out) {
-    if (!plan || !out || n_images < 1 || n_images > 65535) return FUIFGPU_E_ARG;
+static int batch_create_impl(const Plan &plan_in, int n_images, size_t blob_capacity_bytes, int32_t *coef_ext, int32_t *out_ext,
+                             int tmp_images, fuifgpu_batch *share, fuifgpu_batch **out) {
+    if (!out || n_images < 1 || n_images > 65535) return FUIFGPU_E_ARG;
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
@@ -200,8 +204,9 @@ int fuifgpu_batch_create(const fuifgpu_plan *plan, int n_images, size_t blob_cap
         return FUIFGPU_E_HIP;
     }
     fuifgpu_batch *b = new fuifgpu_batch();
-    b->plan = plan->plan;
+    b->plan = plan_in;
     b->n = n_images;
+    b->share = share;
     const Plan &p = b->plan;
     const int nch = (int)p.coded.size();
     b->blob_cap = blob_capacity_bytes + (size_t)n_images * 32 + 1024;  // + slack for the 256-byte read window
@@ -240,7 +245,7 @@ int fuifgpu_batch_create(const fuifgpu_plan *plan, int n_images, size_t blob_cap
         tmp_images = (int)std::max<int64_t>(1, std::min<int64_t>(n_images, (8LL << 30) / per));
     }
     b->tmp_images = std::min(tmp_images, n_images);
-    CHK(hipMalloc((void **)&b->d_tmp, sizeof(int32_t) * (size_t)std::max<int64_t>(p.tmp_elems, 1) * b->tmp_images));
+    if (!share) CHK(hipMalloc((void **)&b->d_tmp, sizeof(int32_t) * (size_t)std::max<int64_t>(p.tmp_elems, 1) * b->tmp_images));
     if (!p.idct_src.empty()) {
         CHK(hipMalloc((void **)&b->d_list, sizeof(PlaneRef) * p.idct_src.size()));
         CHK(hipMemcpy(b->d_list, p.idct_src.data(), sizeof(PlaneRef) * p.idct_src.size(), hipMemcpyHostToDevice));
@@ -251,6 +256,17 @@ int fuifgpu_batch_create(const fuifgpu_plan *plan, int n_images, size_t blob_cap
 #undef CHK
     *out = b;
     return FUIFGPU_OK;
+}
+
+int fuifgpu_batch_create(const fuifgpu_plan *plan, int n_images, size_t blob_capacity_bytes, int32_t *coef_ext, int32_t *out_ext,
+                         int tmp_images, fuifgpu_batch **out) {
+    if (!plan) return FUIFGPU_E_ARG;
+    return batch_create_impl(plan->plan, n_images, blob_capacity_bytes, coef_ext, out_ext, tmp_images, nullptr, out);
+}
+
+int fuifgpu_batch_create_sibling(fuifgpu_batch *primary, size_t blob_capacity_bytes, fuifgpu_batch **out) {
+    if (!primary || primary->share) return FUIFGPU_E_ARG;
+    return batch_create_impl(primary->plan, primary->n, blob_capacity_bytes, primary->d_coef, primary->d_out, primary->tmp_images, primary, out);
 }
 
 int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const size_t *sizes, int n_images, int preview, void *stream) {
@@ -400,7 +416,7 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
             b->layout_cap = layout.size();
         }
         if (!layout.empty()) HIPCHK(hipMemcpyAsync(b->d_layout, layout.data(), layout.size() * 4, hipMemcpyHostToDevice, st));
-        if (b->sched) {
+        if (b->sched && !b->share) {
             // Context arenas: a suspendable tile keeps its supernodes and leaf chances in its image's queue arena (bump
             // allocation inside a launch).  16 MiB per image covers trees of ~2000 nodes on every tile of a 61-tile image
             // three times over (FUIFGPU_CTX_MB overrides); a tile that finds the arena full is simply not suspendable.
@@ -433,7 +449,10 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
     if (b->n_tiles) HIPCHK(hipMemcpyAsync(b->d_tiles, b->tiles.data(), sizeof(Tile) * (size_t)b->n_tiles, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));  // b->tiles / b->jobs may be rebuilt by the next upload
     // one persistent wavefront per tile up to what the device holds at once; each owns a scratch area
-    if (b->n_waves > b->scratch_waves) {
+    if (b->share) {
+        // a sibling launches with the primary's decoder scratch: the primary must have been loaded with at least as many tiles
+        if (b->n_waves > b->share->scratch_waves) { g_last_error = "sibling batch: upload the primary first (its decoder scratch serves both)"; return FUIFGPU_E_ARG; }
+    } else if (b->n_waves > b->scratch_waves) {
         hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_waves = 0;
         HIPCHK(hipMalloc((void **)&b->d_scratch, b->scratch_stride * (size_t)b->n_waves));
         b->scratch_waves = b->n_waves;
@@ -460,7 +479,8 @@ int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
     DecodeParams P{};
     P.blobs = b->d_blobs; P.jobs = b->d_jobs; P.n_images = b->n_loaded; P.n_channels = nch; P.geom = b->d_geom;
     P.coef = b->d_coef; P.coef_stride = b->plan.coef_elems; P.meta = b->d_meta; P.status = b->d_status; P.consumed = b->d_consumed;
-    P.tables = b->d_tables; P.scratch = b->d_scratch; P.scratch_stride = b->scratch_stride; P.bfs_off = b->bfs_off; P.leaves_off = b->leaves_off;
+    const fuifgpu_batch *r = launch_res(b);
+    P.tables = b->d_tables; P.scratch = r->d_scratch; P.scratch_stride = b->scratch_stride; P.bfs_off = b->bfs_off; P.leaves_off = b->leaves_off;
     P.stack_off = b->stack_off; P.queue_off = b->queue_off; P.subtree_off = b->subtree_off; P.max_properties = b->plan.max_properties; P.max_nodes = b->max_nodes; P.max_super = maniac_max_supernodes(b->max_nodes); P.prof = b->d_prof;
     if (b->want_tile_log && b->tile_log_cap < b->n_tiles) {
         hipFree(b->d_tile_log); b->d_tile_log = nullptr; b->tile_log_cap = 0;
@@ -485,7 +505,8 @@ int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
         P.q_turn = w; w += b->n_queues;
         P.tile_rec = reinterpret_cast<TileRec *>(w);
         P.q_img_begin = b->d_layout; P.q_images = b->d_layout + b->n_queues + 1; P.img_tile_begin = b->d_layout + b->n_queues + 1 + b->n_loaded;
-        P.ctx_scratch = b->d_ctx; P.ctx_units_per_queue = b->ctx_units_per_queue;
+        P.ctx_scratch = r->d_ctx;
+        P.ctx_units_per_queue = b->share ? (uint32_t)std::min<size_t>(r->ctx_bytes / (size_t)std::max(b->n_queues, 1) / 256, (size_t)0xFFFFFF00u / (size_t)std::max(b->n_queues, 1)) : b->ctx_units_per_queue;
     } P.progress = b->d_progress; P.group_start = b->d_group_start;
     HIPCHK(hipEventRecord(b->ev[0], st));
     launch_maniac_decode(P, b->n_waves, b->dense, b->n_tiles > b->n_loaded ? 1 : 0, st);
@@ -506,12 +527,13 @@ int fuifgpu_batch_undo_transforms(fuifgpu_batch *b, void *stream) {
     const Plan &p = b->plan;
     const int nch = (int)p.coded.size();
     HIPCHK(hipEventRecord(b->ev[2], st));
-    for (int i0 = 0; i0 < b->n_loaded; i0 += b->tmp_images) {
-        const int cnt = std::min(b->tmp_images, b->n_loaded - i0);
+    const fuifgpu_batch *r = launch_res(b);
+    for (int i0 = 0; i0 < b->n_loaded; i0 += r->tmp_images) {
+        const int cnt = std::min(r->tmp_images, b->n_loaded - i0);
         Bases bases;
         bases.base[BUF_COEF] = b->d_coef + (int64_t)i0 * p.coef_elems; bases.stride[BUF_COEF] = p.coef_elems;
         bases.base[BUF_OUT] = b->d_out + (int64_t)i0 * p.out_elems; bases.stride[BUF_OUT] = p.out_elems;
-        bases.base[BUF_TMP] = b->d_tmp; bases.stride[BUF_TMP] = p.tmp_elems;
+        bases.base[BUF_TMP] = r->d_tmp; bases.stride[BUF_TMP] = p.tmp_elems;
         for (const Op &op : p.ops) launch_op(op, bases, b->d_list, b->d_meta, nch, i0, cnt, st, b->d_status);
     }
     HIPCHK(hipGetLastError());
@@ -613,7 +635,7 @@ int fuifgpu_batch_pack_out(fuifgpu_batch *b, int first_image, int n_images, int 
     Bases bases;
     bases.base[BUF_COEF] = b->d_coef + (int64_t)first_image * p.coef_elems; bases.stride[BUF_COEF] = p.coef_elems;
     bases.base[BUF_OUT] = b->d_out + (int64_t)first_image * p.out_elems; bases.stride[BUF_OUT] = p.out_elems;
-    bases.base[BUF_TMP] = b->d_tmp; bases.stride[BUF_TMP] = p.tmp_elems;
+    bases.base[BUF_TMP] = launch_res(b)->d_tmp; bases.stride[BUF_TMP] = p.tmp_elems;
     launch_pack(bases, pp, p.w, p.h, p.minval, p.maxval, bps, dst_device, (int64_t)p.w * p.h * pp.n * bps, n_images, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return FUIFGPU_OK;

@@ -83,6 +83,17 @@ int fuifgpu_batch_create(const fuifgpu_plan *plan, int n_images, size_t blob_cap
                          int32_t *coef_ext, int32_t *out_ext, int tmp_images, fuifgpu_batch **out);
 void fuifgpu_batch_destroy(fuifgpu_batch *batch);
 
+/* A second set of stream buffers for the SAME slabs, so that the upload of the next batch (host parse + H2D copies, on a copy
+ * stream, from another host thread) runs while the previous batch decodes: the sibling owns what fuifgpu_batch_upload writes
+ * (stream bytes, tile lists, per-image status / consumed / metadata) and launches with the primary's coefficient and output
+ * slabs, decoder scratch, context arenas and transform arena -- ~12 MB per 4K stream instead of a second 45 GB of launch state.
+ * Rules: upload the primary once before the sibling's first upload (its scratch serves both); decode / undo_transforms of the
+ * two on ONE stream (they share the slabs); destroy the sibling first.  The pattern, per step k: thread U uploads into batch
+ * (k+1)%2 on the copy stream while the caller runs decode + undo_transforms of batch k%2; join; consume; repeat
+ * (bench.py's `value_incl_h2d`, tests/test_gpu_synthetic.py).  The reference has no counterpart: it reads one file at a time
+ * (encoding/encoding.cpp:745-753). */
+int fuifgpu_batch_create_sibling(fuifgpu_batch *primary, size_t blob_capacity_bytes, fuifgpu_batch **out);
+
 /* Stage compressed streams (host pointers) into HBM.  Every blob must parse to the batch's
  * signature.  preview: -1 = full decode, 0..4 = responsive truncation point
  * (fuif_options::preview, encoding/encoding.h:34).  Replaces the IO object handed to

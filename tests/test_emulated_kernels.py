@@ -54,6 +54,7 @@ SELECTED = [
     "tests/test_fuzz.py::test_gpu_agrees_with_oracle_on_corrupt_payload",
     "tests/test_gpu_transform_exports.py",
     "tests/test_gpu_synthetic.py::test_deep_trees_walk_through_chained_supernodes",
+    "tests/test_gpu_synthetic.py::test_sibling_batch_pipelines_uploads",
 ]
 
 

@@ -173,34 +173,42 @@ def test_c4_full_size_image_matches_oracle(gpulib, port):
         assert np.array_equal(post[k], img[k])
 
 
-def test_two_batches_over_one_pair_of_slabs_pipeline_uploads(gpulib):
-    """the pipelining pattern behind bench.py's `value_incl_h2d` (INTEGRATION.md "Hiding the upload"): two Batches created over
-    the SAME external coefficient and output slabs; while one decodes on the launch stream, a host thread parses and uploads
-    the next set of streams into the other on a copy stream.  Three different sets of pictures go through, every one must
-    come out as its own source pixels."""
+def test_sibling_batch_pipelines_uploads(gpulib):
+    """the pattern behind bench.py's `value_incl_h2d` (include/fuifgpu.h: fuifgpu_batch_create_sibling; INTEGRATION.md "Hiding the
+    upload"): a sibling Batch owns a second set of stream buffers over the primary's slabs, decoder scratch and arenas; while
+    one decodes on the launch stream, a host thread parses and uploads the next set of streams into the other on a copy
+    stream.  Three different sets of pictures go through, every one must come out as its own source pixels; a sibling used
+    before its primary was ever loaded is refused."""
+    import os
     import threading
-    import torch
     n = 4
-    sets = [[photographic(640, 480, 3, 8, seed=6000 + 10 * s + i) for i in range(n)] for s in range(3)]
+    emulated = os.environ.get("FUIF_AMD_LIB", "").endswith("_emu.so")
+    w, h = (96, 64) if emulated else (640, 480)      # (the wavefront emulator of tests/test_emulated_kernels.py runs this test too)
+    sets = [[photographic(w, h, 3, 8, seed=6000 + 10 * s + i) for i in range(n)] for s in range(3)]
     blobs = [[gpulib.encode_image(im, 8, tree_mode=1, index=True) for im in st] for st in sets]
     plan = gpulib.Plan(blobs[0][0])
-    info = plan.info
     cap = max(sum(len(b) for b in bs) for bs in blobs)
-    coef = torch.empty(n * max(info.coef_elems, 1), dtype=torch.int32, device="cuda")
-    out = torch.empty(n * max(info.out_elems, 1), dtype=torch.int32, device="cuda")
-    pair = [gpulib.Batch(plan, n, cap, coef_ptr=coef.data_ptr(), out_ptr=out.data_ptr()) for _ in range(2)]
-    copy_stream = torch.cuda.Stream()
+    copy_stream, set_device = None, (lambda: None)
+    if not emulated:
+        import torch
+        keep = torch.cuda.Stream()          # (the emulator has one "stream")
+        copy_stream, set_device = keep.cuda_stream, (lambda: torch.cuda.set_device(0))
+    primary = gpulib.Batch(plan, n, cap)
+    other = primary.sibling(cap)
+    pair = [primary, other]
     errors = []
 
     def uploader(bt, bs):
         try:
-            torch.cuda.set_device(0)
-            bt.upload(bs, stream=copy_stream.cuda_stream)
+            set_device()
+            bt.upload(bs, stream=copy_stream)
         except Exception as e:      # noqa: BLE001
             errors.append(repr(e))
 
     try:
-        pair[0].upload(blobs[0])
+        with pytest.raises(gpulib.FuifGpuError):
+            other.upload(blobs[0])          # the primary's scratch serves both: it has to be loaded first
+        primary.upload(blobs[0])
         for k in range(3):
             cur = pair[k % 2]
             th = None
@@ -220,5 +228,5 @@ def test_two_batches_over_one_pair_of_slabs_pipeline_uploads(gpulib):
                 for c in range(3):
                     assert np.array_equal(planes[c], sets[k][i][c]), (k, i, c)
     finally:
-        for b in pair:
-            b.close()
+        other.close()
+        primary.close()
