@@ -22,7 +22,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("FUIF_AMD_LIB") or os.path.join(_HERE, "libfuifgpu.so")  # FUIF_AMD_LIB: diagnostic (-DFUIF_PROF) build
-_SOURCES = ["plan.cpp", "index.cpp", "writer.cpp", "maniac_decode.hip", "transforms.hip", "capi.hip"]
+_SOURCES = ["plan.cpp", "index.cpp", "writer.cpp", "maniac_decode.hip", "maniac_encode.hip", "transforms.hip", "capi.hip"]
 _lib = None
 
 
@@ -41,7 +41,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 def build(force=False, verbose=False):
     """Compile libfuifgpu.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(_HERE, "csrc", s) for s in _SOURCES]
-    deps = srcs + [os.path.join(_HERE, "csrc", h) for h in ("fuifgpu_internal.h", "maniac_decode.h", "transforms.h", "squeeze_arith.h")]
+    deps = srcs + [os.path.join(_HERE, "csrc", h) for h in ("fuifgpu_internal.h", "maniac_decode.h", "maniac_encode.h", "transforms.h", "squeeze_arith.h")]
     deps.append(os.path.join(_HERE, "..", "include", "fuifgpu.h"))
     if os.environ.get("FUIF_AMD_LIB"):
         return _LIB_PATH
@@ -71,7 +71,7 @@ class ChannelDesc(C.Structure):
 
 class EncodeOptions(C.Structure):
     _fields_ = [("ycocg", C.c_int32), ("squeeze", C.c_int32), ("max_properties", C.c_int32), ("tree_mode", C.c_int32),
-                ("max_tree_nodes", C.c_int32), ("emit_index", C.c_int32), ("split_bits", C.c_int32), ("gpu_forward", C.c_int32)]
+                ("max_tree_nodes", C.c_int32), ("emit_index", C.c_int32), ("split_bits", C.c_int32), ("gpu_forward", C.c_int32), ("gpu_entropy", C.c_int32)]
 
 
 # every symbol include/fuifgpu.h declares (tests check that the library exports all of them)
@@ -379,14 +379,15 @@ DEFAULT_SPLIT_BITS = 0
 
 
 def encode_image(planes, bit_depth=8, ycocg=True, squeeze=True, max_properties=12, tree_mode=1, max_tree_nodes=4095, index=False,
-                 split_bits=None, gpu_forward=False):
+                 split_bits=None, gpu_forward=False, gpu_entropy=False):
     """(C,H,W) int32 planes -> lossless .fuif bytes (host C++ writer, csrc/writer.cpp).
     index=True appends the group index trailer (csrc/index.cpp) that unlocks one-wavefront-per-group decoding.
-    gpu_forward=True runs the forward YCoCg and Squeeze on the GPU (fuifgpu_fwd_*): same bytes."""
+    gpu_forward=True runs the forward YCoCg and Squeeze on the GPU (fuifgpu_fwd_*), gpu_entropy=True the MANIAC pixel loop of
+    every compressed group (csrc/maniac_encode.hip): same bytes either way."""
     split_bits = DEFAULT_SPLIT_BITS if split_bits is None else split_bits
     planes = np.ascontiguousarray(planes, dtype=np.int32)
     c, h, w = planes.shape
-    opt = EncodeOptions(int(ycocg), int(squeeze), max_properties, tree_mode, max_tree_nodes, int(index), int(split_bits), int(gpu_forward))
+    opt = EncodeOptions(int(ycocg), int(squeeze), max_properties, tree_mode, max_tree_nodes, int(index), int(split_bits), int(gpu_forward), int(gpu_entropy))
     out = C.c_void_p()
     n = C.c_size_t(0)
     _check(lib().fuifgpu_encode_image(planes.ctypes.data, w, h, c, bit_depth, C.byref(opt), C.byref(out), C.byref(n)))

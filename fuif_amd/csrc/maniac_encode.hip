@@ -1,0 +1,257 @@
+// fuif_amd/csrc/maniac_encode.hip -- the MANIAC pixel loop of the WRITER for gfx950.
+//
+// The reference encoder (encoding/encoding.cpp:74-207 with maniac/rac_enc.h:28-100, maniac/symbol_enc.h and the write side of
+// maniac/compound.h) walks the pixels of a channel group once: properties + prediction, tree walk to a leaf, then the residual
+// goes through that leaf's adaptive chances into the range coder.  On the encode side every sample is known in advance, so only
+// the last step is serial.  Two kernels per group:
+//
+//   k_enc_model  one lane per PIXEL: the 2k+13 properties and the prediction (context_predict.h:124-168, 233-289), the walk
+//                through the group's context tree (compound.h:142-153) -> per pixel {prediction, leaf}.  No dependency between
+//                pixels: this is the part that is serial in the decoder and parallel here.
+//   k_enc_rac    one wavefront per group: 64 pixels at a time are staged through LDS (residual, its range, leaf), lane 0 runs
+//                the symbol binarisation (symbol.h:154-185, write side), the chance updates (chance.h:77-79) and the 24-bit range
+//                coder with its delayed-byte carry handling (rac_enc.h:40-85), and appends the bytes.
+//
+// The tree itself and the group header are written by the host writer (csrc/writer.cpp) into the same range coder before the
+// pixels: the coder's state {range, low, delayed byte, pending 0xFF run} is handed in and handed back.  Output is byte-identical to
+// the host writer's (tests/test_zz_gpu_encoder.py), which tests/test_writer.py pins to the reference CLI.
+//
+// Round 3: first correct path, one group per launch pair, synchronous.  A 4K picture's longest group is a chain of 4.1 million
+// symbols on ONE lane, so a single picture is slower than on a CPU core; the point of the design is the batch (one wavefront per
+// group over many pictures, as k_maniac_decode does) -- not built yet, and NOT measured on hardware in round 3.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include "../../include/fuifgpu.h"
+#include "maniac_encode.h"
+
+namespace fuifgpu {
+
+namespace {
+
+#define DEV __device__ __forceinline__
+
+constexpr int CH_ZERO = 0, CH_SIGN = 1, CH_EXP = 2, CH_MANT = 16, CH_N = 31;   // symbol.h:97-113: zero, sign, 14 exponent, 15 mantissa chances
+
+DEV int e_iabs(int x) { return x < 0 ? -x : x; }
+DEV int e_ilog2(uint32_t l) { return l == 0 ? 0 : 31 - __builtin_clz(l); }
+DEV int e_slog(int x) {   // context_predict.h:52-60
+    if (x == 0) return 0;
+    if (x > 0) return 32 - __builtin_clz((unsigned)x);
+    return -(32 - __builtin_clz((unsigned)(-x)));
+}
+DEV int e_median3(int a, int b, int c) {
+    if (a < b) { if (b < c) return b; return a < c ? c : a; }
+    if (a < c) return a;
+    return b < c ? c : b;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// context model of every pixel, in parallel
+__global__ __launch_bounds__(256) void k_enc_model(EncGroup g, const EncNode *tree, int n_nodes, int32_t *guess_out, int32_t *leaf_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n = (int64_t)g.w * g.h;
+    if (i >= n) return;
+    const int w = g.w;
+    const int y = (int)(i / w), x = (int)(i - (int64_t)y * w);
+    int32_t p[kMaxProps];
+    int o = 0;
+    for (int k = 0; k < g.nrefs; k++) {   // context_predict.h:233-289, one pixel
+        const EncRef rc = g.refs[k];
+        int ry = (y << g.vshift) >> rc.vshift; if (ry >= rc.h) ry = rc.h - 1;
+        int rx = (x << g.hshift) >> rc.hshift; if (rx >= rc.w) rx = rc.w - 1;
+        const int v = rc.data[(int64_t)ry * rc.w + rx];
+        p[o++] = e_iabs(v); p[o++] = e_slog(v);
+    }
+    const int32_t *d = g.plane;
+    // context_predict.h:126-133
+    const int left = x ? d[i - 1] : g.zero;
+    const int top = y ? d[i - w] : g.zero;
+    const int topleft = (x && y) ? d[i - w - 1] : left;
+    const int topright = (x + 1 < w && y) ? d[i - w + 1] : top;
+    const int leftleft = x > 1 ? d[i - 2] : left;
+    const int toptop = y > 1 ? d[i - 2 * (int64_t)w] : top;
+    p[o++] = e_iabs(top); p[o++] = e_iabs(left); p[o++] = e_slog(top); p[o++] = e_slog(left);
+    p[o++] = y; p[o++] = x;
+    p[o++] = left + top - topleft; p[o++] = topleft + topright - top;
+    p[o++] = e_slog(left - topleft); p[o++] = e_slog(topleft - top); p[o++] = e_slog(top - topright);
+    p[o++] = e_slog(top - toptop); p[o++] = e_slog(left - leftleft);
+    int guess;
+    switch (g.predictor) {   // context_predict.h:157-166
+        case 0: guess = g.zero; break;
+        case 1: guess = (left + top) / 2; break;
+        case 3: guess = left; break;
+        case 4: guess = top; break;
+        case 5: guess = (left + topleft + top + topright) / 4; break;
+        case 6: { const int t = left + top - topleft; guess = t < g.minval ? g.minval : (t > g.maxval ? g.maxval : t); break; }
+        default: guess = e_median3(left + top - topleft, left, top); break;
+    }
+    int pos = 0;
+    EncNode nd = tree[0];
+    for (int depth = 0; depth < n_nodes && nd.prop >= 0; depth++) {   // compound.h:142-153 (a walk visits every node at most once)
+        pos = p[nd.prop & (kMaxProps - 1)] > nd.split ? nd.child : nd.child + 1;
+        pos = pos < n_nodes ? pos : 0;
+        nd = tree[pos];
+    }
+    guess_out[i] = guess;
+    leaf_out[i] = nd.leaf;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the serial part: one wavefront, lane 0 codes
+namespace {
+
+struct DevRac {   // rac_enc.h:28-100 (RacOutput24): the decoder is three bytes ahead, carries ripple into the delayed byte
+    uint32_t range, low;
+    int32_t delayed, pending;
+    uint8_t *out;
+    uint32_t cap, count;
+    DEV void emit(int b) { if (count < cap) out[count] = (uint8_t)b; count++; }
+    DEV void shift() {
+        const uint32_t byte = low >> 16;   // bit 8 = a carry into the bytes already generated
+        if (delayed < 0) delayed = (int32_t)byte;
+        else if (byte < 0xFF) { emit(delayed); for (; pending; pending--) emit(0xFF); delayed = (int32_t)byte; }
+        else if (byte > 0xFF) { emit(delayed + 1); for (; pending; pending--) emit(0x00); delayed = (int32_t)(byte & 0xFF); }
+        else pending++;
+        low = (low & 0xFFFF) << 8;
+        range <<= 8;
+    }
+    DEV void put12(uint32_t b12, int bit) {   // rac.h:43-52 chance_12bit_chance + rac_enc.h:60-72
+        const uint32_t chance = (((range & 0xFFFu) * b12 + 0x800u) >> 12) + ((range >> 12) * b12);
+        if (bit) { low += range - chance; range = chance; }
+        else range -= chance;
+        for (int k = 0; k < 4 && range <= 0x10000u; k++) shift();   // at most three shifts while range >= 1 (rac_enc.h:66-71 loops; bounded here so that no input can hang a wavefront)
+    }
+};
+
+DEV void dev_coder_write(DevRac &r, uint16_t *ch, int idx, const uint16_t *table, int bit) {
+    const uint32_t c = ch[idx];
+    r.put12(c, bit);
+    ch[idx] = table[c * 2 + bit];   // chance.h:77-79
+}
+
+// write side of symbol.h:154-185
+DEV void dev_write_symbol(DevRac &r, uint16_t *ch, const uint16_t *table, int min, int max, int value) {
+    if (value == 0) { dev_coder_write(r, ch, CH_ZERO, table, 1); return; }
+    dev_coder_write(r, ch, CH_ZERO, table, 0);
+    const int sign = value > 0;
+    if (min < 0 && max > 0) dev_coder_write(r, ch, CH_SIGN, table, sign);
+    const int a = e_iabs(value);
+    const int e = e_ilog2((uint32_t)a);
+    const int amax = sign ? max : -min;
+    const int emax = e_ilog2((uint32_t)amax);
+    for (int i = 0; i < emax; i++) {
+        dev_coder_write(r, ch, CH_EXP + i, table, i == e);
+        if (i == e) break;
+    }
+    int have = 1 << e;
+    for (int pos = e; pos > 0;) {
+        pos--;
+        const int minabs1 = have | (1 << pos);
+        if (minabs1 > amax) continue;
+        const int bit = (a >> pos) & 1;
+        dev_coder_write(r, ch, CH_MANT + pos, table, bit);
+        if (bit) have = minabs1;
+    }
+}
+
+}  // namespace
+
+// state[0..3] = RacEncState in / out, state[4] = bytes emitted (out), state[5] = 1 when `out` was too small
+__global__ __launch_bounds__(64) void k_enc_rac(const int32_t *plane, const int32_t *guess, const int32_t *leafidx, int64_t n, int minval, int maxval,
+                                                uint16_t *leaves, const uint16_t *table_g, uint32_t *state, uint8_t *out, uint32_t out_cap) {
+    __shared__ uint16_t table[8192];
+    __shared__ int32_t s_diff[64], s_min[64], s_max[64], s_leaf[64];
+    const int lane = threadIdx.x;
+    for (int k = lane; k < 8192; k += 64) table[k] = table_g[k];
+    DevRac r;
+    r.range = state[0]; r.low = state[1]; r.delayed = (int32_t)state[2]; r.pending = (int32_t)state[3];
+    r.out = out; r.cap = out_cap; r.count = 0;
+    __syncthreads();
+    for (int64_t x0 = 0; x0 < n; x0 += 64) {
+        const int nx = (int)(n - x0 < 64 ? n - x0 : 64);
+        if (lane < nx) {
+            const int gs = guess[x0 + lane];
+            s_diff[lane] = plane[x0 + lane] - gs;
+            s_min[lane] = minval - gs;
+            s_max[lane] = maxval - gs;
+            s_leaf[lane] = leafidx[x0 + lane];
+        }
+        __syncthreads();
+        if (lane == 0) {
+            for (int j = 0; j < nx; j++) {
+                const int mn = s_min[j], mx = s_max[j];
+                if (mn == mx) continue;   // compound.h:228: nothing to code
+                dev_write_symbol(r, leaves + (int64_t)s_leaf[j] * CH_N, table, mn, mx, s_diff[j]);   // (s_leaf < n_leaves: k_enc_model only hands out leaf numbers of the tree)
+            }
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        state[0] = r.range; state[1] = r.low; state[2] = (uint32_t)r.delayed; state[3] = (uint32_t)r.pending;
+        state[4] = r.count; state[5] = r.count > r.cap ? 1u : 0u;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+void EncScratch::release() {
+    hipFree(d_guess); hipFree(d_leaf); hipFree(d_bytes); hipFree(d_tree); hipFree(d_leaves); hipFree(d_table); hipFree(d_state);
+    *this = EncScratch();
+}
+
+int maniac_encode_group_gpu(const EncGroup &g, const EncNode *tree, int n_nodes, int n_leaves, const uint16_t *leaf_init, const uint16_t *pixel_table,
+                            RacEncState *state, std::vector<uint8_t> &out, EncScratch &s) {
+    if (!g.plane || !tree || n_nodes < 1 || n_leaves < 1 || !leaf_init || !pixel_table || !state || g.w < 1 || g.h < 1 || g.nrefs < 0 || g.nrefs > kMaxRefs)
+        return FUIFGPU_E_ARG;
+    const size_t n = (size_t)g.w * g.h;
+#define ECHK(call) do { if ((call) != hipSuccess) return FUIFGPU_E_HIP; } while (0)
+    if (n > s.pixel_cap) {
+        hipFree(s.d_guess); hipFree(s.d_leaf); s.d_guess = s.d_leaf = nullptr; s.pixel_cap = 0;
+        ECHK(hipMalloc((void **)&s.d_guess, n * 4)); ECHK(hipMalloc((void **)&s.d_leaf, n * 4));
+        s.pixel_cap = n;
+    }
+    // a symbol is at most 1 + 1 + 14 + 14 binary decisions, each well under a byte after renormalisation: 4 bytes per sample is generous
+    const size_t bytes_cap = std::min<size_t>(n * 4 + 1024, 0xFFFFFF00u);
+    if (bytes_cap > s.bytes_cap) {
+        hipFree(s.d_bytes); s.d_bytes = nullptr; s.bytes_cap = 0;
+        ECHK(hipMalloc((void **)&s.d_bytes, bytes_cap));
+        s.bytes_cap = bytes_cap;
+    }
+    if ((size_t)n_nodes > s.tree_cap) {
+        hipFree(s.d_tree); s.d_tree = nullptr; s.tree_cap = 0;
+        ECHK(hipMalloc((void **)&s.d_tree, sizeof(EncNode) * (size_t)n_nodes));
+        s.tree_cap = (size_t)n_nodes;
+    }
+    if ((size_t)n_leaves > s.leaves_cap) {
+        hipFree(s.d_leaves); s.d_leaves = nullptr; s.leaves_cap = 0;
+        ECHK(hipMalloc((void **)&s.d_leaves, sizeof(uint16_t) * CH_N * (size_t)n_leaves));
+        s.leaves_cap = (size_t)n_leaves;
+    }
+    if (!s.d_table) ECHK(hipMalloc((void **)&s.d_table, sizeof(uint16_t) * 8192));
+    if (!s.d_state) ECHK(hipMalloc((void **)&s.d_state, sizeof(uint32_t) * 8));
+    std::vector<uint16_t> leaves((size_t)n_leaves * CH_N);
+    for (int l = 0; l < n_leaves; l++) memcpy(&leaves[(size_t)l * CH_N], leaf_init, sizeof(uint16_t) * CH_N);
+    uint32_t st[8] = {state->range, state->low, (uint32_t)state->delayed, (uint32_t)state->pending, 0, 0, 0, 0};
+    ECHK(hipMemcpy(s.d_tree, tree, sizeof(EncNode) * (size_t)n_nodes, hipMemcpyHostToDevice));
+    ECHK(hipMemcpy(s.d_leaves, leaves.data(), sizeof(uint16_t) * leaves.size(), hipMemcpyHostToDevice));
+    ECHK(hipMemcpy(s.d_table, pixel_table, sizeof(uint16_t) * 8192, hipMemcpyHostToDevice));
+    ECHK(hipMemcpy(s.d_state, st, sizeof(st), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_enc_model, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, g, s.d_tree, n_nodes, s.d_guess, s.d_leaf);
+    hipLaunchKernelGGL(k_enc_rac, dim3(1), dim3(64), 0, nullptr, g.plane, s.d_guess, s.d_leaf, (int64_t)n, g.minval, g.maxval, s.d_leaves, s.d_table, s.d_state,
+                       s.d_bytes, (uint32_t)s.bytes_cap);
+    ECHK(hipGetLastError());
+    ECHK(hipMemcpy(st, s.d_state, sizeof(st), hipMemcpyDeviceToHost));   // synchronises with the null stream's kernels
+    if (st[5]) return FUIFGPU_E_NOMEM;
+    const size_t old = out.size();
+    out.resize(old + st[4]);
+    if (st[4]) ECHK(hipMemcpy(out.data() + old, s.d_bytes, st[4], hipMemcpyDeviceToHost));
+    state->range = st[0]; state->low = st[1]; state->delayed = (int32_t)st[2]; state->pending = (int32_t)st[3];
+#undef ECHK
+    return FUIFGPU_OK;
+}
+
+}  // namespace fuifgpu

@@ -223,8 +223,12 @@ typedef struct {
     int32_t emit_index;     /* 1: append the group index trailer (see fuifgpu_index_*) */
     int32_t split_bits;     /* learned trees: > 0 = a split must save this many bits (flat); 0 = the default rule, the description
                                length of the extra leaf ((k/2) log2 pixels), which follows the reference encoder's tree sizes */
-    int32_t gpu_forward;    /* 1: forward YCoCg and Squeeze run on the GPU (fuifgpu_fwd_*); the entropy coder is host code either way.
+    int32_t gpu_forward;    /* 1: forward YCoCg and Squeeze run on the GPU (fuifgpu_fwd_*).
                                Same bytes as with 0.  No GPU: FUIFGPU_E_HIP (no silent host route). */
+    int32_t gpu_entropy;    /* 1: the MANIAC pixel loop of every compressed channel group runs on the GPU (csrc/maniac_encode.hip: context
+                               model of all pixels in parallel, then one wavefront per group for symbol binarisation, chance updates and
+                               the range coder, maniac/rac_enc.h:28-100); group headers, tree learning and the tree itself stay host code.
+                               Same bytes as with 0.  No GPU: FUIFGPU_E_HIP. */
 } fuifgpu_encode_options;
 int fuifgpu_encode_image(const int32_t *planes, int w, int h, int nch, int bit_depth, const fuifgpu_encode_options *opt,
                          uint8_t **blob_out, size_t *size_out);

@@ -19,7 +19,7 @@ from conftest import ROOT
 EMU_DIR = os.path.join(ROOT, "tests", "_emu")
 EMU_LIB = os.path.join(EMU_DIR, "libfuifgpu_emu.so")
 CSRC = os.path.join(ROOT, "fuif_amd", "csrc")
-SOURCES = ["plan.cpp", "index.cpp", "writer.cpp", "maniac_decode.hip", "transforms.hip", "capi.hip"]
+SOURCES = ["plan.cpp", "index.cpp", "writer.cpp", "maniac_decode.hip", "maniac_encode.hip", "transforms.hip", "capi.hip"]
 
 
 def build_emulated_library(extra=(), name="libfuifgpu_emu.so"):
@@ -55,6 +55,7 @@ SELECTED = [
     "tests/test_gpu_transform_exports.py",
     "tests/test_gpu_synthetic.py::test_deep_trees_walk_through_chained_supernodes",
     "tests/test_gpu_synthetic.py::test_sibling_batch_pipelines_uploads",
+    "tests/test_zz_gpu_encoder.py",
 ]
 
 

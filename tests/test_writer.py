@@ -88,3 +88,16 @@ def test_jpeg_like_streams_port_and_reference_agree(gpulib, port, w, h, c, sub):
         a0, a1 = Ref().decode_both(blob)
         assert all(np.array_equal(x["data"], y["data"]) for x, y in zip(a0.channels, pre.channels))
         assert all(np.array_equal(x["data"], y["data"]) for x, y in zip(a1.channels, post.channels))
+
+
+def test_gpu_options_of_the_writer_fail_loudly_without_a_gpu(gpulib):
+    """gpu_forward / gpu_entropy ask for the GPU kernels of the writer (fuifgpu_fwd_*, csrc/maniac_encode.hip): on a host without
+    a HIP device that is an error, never a silent host route (the `-m gpu` tests compare both paths byte for byte)"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    img = photographic(64, 48, 3, 8, seed=1)
+    for kw in (dict(gpu_forward=True), dict(gpu_entropy=True)):
+        with pytest.raises(gpulib.FuifGpuError) as e:
+            gpulib.encode_image(img, 8, **kw)
+        assert "HIP" in str(e.value)

@@ -1,0 +1,38 @@
+"""GPU parity (-m gpu) of the writer's MANIAC pixel loop on the GPU (csrc/maniac_encode.hip, fuifgpu_encode_options::gpu_entropy):
+the context model of every pixel in parallel + one wavefront per group for the symbol coder and the range coder must write the
+very bytes the host writer writes -- which tests/test_writer.py pins to the reference CLI (`fuif -I 0`) and to the reference
+decoder.  (Named to run last: it covers a "next" row of SURVEY 8(f), not the decode path.)"""
+import os
+
+import numpy as np
+import pytest
+
+from fuif_amd.synth import photographic
+
+pytestmark = pytest.mark.gpu
+
+EMULATED = os.environ.get("FUIF_AMD_LIB", "").endswith("_emu.so")
+SHAPES = [(97, 61, 3, 8, True), (64, 48, 1, 8, True), (40, 30, 4, 14, False)] if EMULATED else \
+         [(97, 61, 3, 8, True), (640, 480, 3, 8, True), (333, 200, 1, 12, True), (256, 256, 4, 14, False)]
+
+
+@pytest.mark.parametrize("w,h,c,bits,ycocg", SHAPES)
+@pytest.mark.parametrize("tree_mode", [0, 1])
+def test_gpu_pixel_loop_writes_the_host_writers_bytes(gpulib, w, h, c, bits, ycocg, tree_mode):
+    img = photographic(w, h, c, bits, seed=7000 + w + tree_mode)
+    split = 2 if (tree_mode and w * h < 20000) else None       # small pictures: let the learner split at all
+    host = gpulib.encode_image(img, bits, ycocg=ycocg, tree_mode=tree_mode, index=True, split_bits=split)
+    dev = gpulib.encode_image(img, bits, ycocg=ycocg, tree_mode=tree_mode, index=True, split_bits=split, gpu_entropy=True)
+    assert dev == host
+    both = gpulib.encode_image(img, bits, ycocg=ycocg, tree_mode=tree_mode, index=True, split_bits=split, gpu_entropy=True, gpu_forward=True)
+    assert both == host
+
+
+def test_flat_and_tiny_planes(gpulib):
+    """constant channels (no coder at all), planes the writer stores uncompressed (the roll-back of encoding.cpp:545-551 runs
+    after the GPU attempt) and a picture too small for Squeeze"""
+    flat = np.full((3, 40, 56), 77, np.int32)
+    for img, kw in ((flat, {}), (photographic(5, 4, 3, 8, seed=3), {}), (photographic(31, 17, 1, 8, seed=4), dict(squeeze=False))):
+        host = gpulib.encode_image(img, 8, tree_mode=1, **kw)
+        dev = gpulib.encode_image(img, 8, tree_mode=1, gpu_entropy=True, **kw)
+        assert dev == host

@@ -7,5 +7,5 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; shift
 mkdir -p $ROOT/build
 cd $ROOT/fuif_amd/csrc
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-value "$@" -o $ROOT/build/libfuifgpu_$name.so plan.cpp index.cpp writer.cpp maniac_decode.hip transforms.hip capi.hip
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-value "$@" -o $ROOT/build/libfuifgpu_$name.so plan.cpp index.cpp writer.cpp maniac_decode.hip maniac_encode.hip transforms.hip capi.hip
 echo built $ROOT/build/libfuifgpu_$name.so
