@@ -18,7 +18,8 @@
 //
 // Round 3: first correct path, one group per launch pair, synchronous.  A 4K picture's longest group is a chain of 4.1 million
 // symbols on ONE lane, so a single picture is slower than on a CPU core; the point of the design is the batch (one wavefront per
-// group over many pictures, as k_maniac_decode does) -- not built yet, and NOT measured on hardware in round 3.
+// group over many pictures, as k_maniac_decode does) -- not built yet.  Parity was checked on the MI355X
+// (profiles/r3_gpu_encoder_tests.txt); no timing was taken in round 3.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
