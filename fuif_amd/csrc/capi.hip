@@ -69,6 +69,8 @@ struct fuifgpu_batch {
     // A sibling (fuifgpu_batch_create_sibling) owns only what an UPLOAD writes -- stream bytes, tile lists, per-image results -- and
     // decodes with the primary's slabs, decoder scratch, context arenas and transform arena (everything a LAUNCH uses)
     fuifgpu_batch *share = nullptr;
+    std::vector<fuifgpu_batch *> siblings;   // of a primary: told when it goes away
+    bool orphan = false;                      // a sibling whose primary was destroyed first: every call is refused
 };
 static inline const fuifgpu_batch *launch_res(const fuifgpu_batch *b) { return b->share ? b->share : b; }
 
@@ -184,6 +186,12 @@ int fuifgpu_plan_transform(const fuifgpu_plan *plan, int index, int32_t *id, int
 // -------------------------------------------------------------------------------------------------
 void fuifgpu_batch_destroy(fuifgpu_batch *b) {
     if (!b) return;
+    // the documented order is "sibling first"; the other order must not leave a sibling launching with freed memory
+    for (fuifgpu_batch *s : b->siblings) { s->share = nullptr; s->orphan = true; s->n_loaded = 0; s->d_coef = nullptr; s->d_out = nullptr; }
+    if (b->share) {
+        auto &v = b->share->siblings;
+        v.erase(std::remove(v.begin(), v.end(), b), v.end());
+    }
     hipFree(b->d_blobs); hipFree(b->d_jobs); hipFree(b->d_geom); hipFree(b->d_meta); hipFree(b->d_status); hipFree(b->d_consumed);
     hipFree(b->d_tables); hipFree(b->d_scratch); hipFree(b->d_tmp); hipFree(b->d_list); hipFree(b->d_prof); hipFree(b->d_tile_log);
     hipFree(b->d_tiles); hipFree(b->d_progress); hipFree(b->d_group_start); hipFree(b->d_sched); hipFree(b->d_layout); hipFree(b->d_ctx);
@@ -266,11 +274,14 @@ int fuifgpu_batch_create(const fuifgpu_plan *plan, int n_images, size_t blob_cap
 
 int fuifgpu_batch_create_sibling(fuifgpu_batch *primary, size_t blob_capacity_bytes, fuifgpu_batch **out) {
     if (!primary || primary->share) return FUIFGPU_E_ARG;
-    return batch_create_impl(primary->plan, primary->n, blob_capacity_bytes, primary->d_coef, primary->d_out, primary->tmp_images, primary, out);
+    const int rc = batch_create_impl(primary->plan, primary->n, blob_capacity_bytes, primary->d_coef, primary->d_out, primary->tmp_images, primary, out);
+    if (rc == FUIFGPU_OK) primary->siblings.push_back(*out);
+    return rc;
 }
 
 int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const size_t *sizes, int n_images, int preview, void *stream) {
     if (!b || !blobs || !sizes || n_images < 1 || n_images > b->n || preview < -1 || preview > 4) return FUIFGPU_E_ARG;
+    if (b->orphan) { g_last_error = "sibling batch: its primary has been destroyed"; return FUIFGPU_E_ARG; }
     hipStream_t st = (hipStream_t)stream;
     b->jobs.assign(n_images, StreamJob{});
     size_t off = 0;
@@ -589,18 +600,18 @@ int fuifgpu_batch_channel_meta(fuifgpu_batch *b, int image, int32_t *meta4) {
     return FUIFGPU_OK;
 }
 
-int32_t *fuifgpu_batch_coef_ptr(fuifgpu_batch *b, int image) { return (b && image >= 0 && image < b->n) ? b->d_coef + (int64_t)image * b->plan.coef_elems : nullptr; }
-int32_t *fuifgpu_batch_out_ptr(fuifgpu_batch *b, int image) { return (b && image >= 0 && image < b->n) ? b->d_out + (int64_t)image * b->plan.out_elems : nullptr; }
+int32_t *fuifgpu_batch_coef_ptr(fuifgpu_batch *b, int image) { return (b && !b->orphan && image >= 0 && image < b->n) ? b->d_coef + (int64_t)image * b->plan.coef_elems : nullptr; }
+int32_t *fuifgpu_batch_out_ptr(fuifgpu_batch *b, int image) { return (b && !b->orphan && image >= 0 && image < b->n) ? b->d_out + (int64_t)image * b->plan.out_elems : nullptr; }
 
 int fuifgpu_batch_download_coef(fuifgpu_batch *b, int image, int32_t *host, void *stream) {
-    if (!b || image < 0 || image >= b->n || !host) return FUIFGPU_E_ARG;
+    if (!b || image < 0 || image >= b->n || !host || b->orphan) return FUIFGPU_E_ARG;
     if (b->coef_consumed) { g_last_error = "fuifgpu_batch_download_coef: the coefficients were consumed by fuifgpu_batch_undo_transforms"; return FUIFGPU_E_ARG; }
     HIPCHK(hipMemcpyAsync(host, fuifgpu_batch_coef_ptr(b, image), sizeof(int32_t) * (size_t)b->plan.coef_elems, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     return FUIFGPU_OK;
 }
 int fuifgpu_batch_download_out(fuifgpu_batch *b, int image, int32_t *host, void *stream) {
-    if (!b || image < 0 || image >= b->n || !host) return FUIFGPU_E_ARG;
+    if (!b || image < 0 || image >= b->n || !host || b->orphan) return FUIFGPU_E_ARG;
     HIPCHK(hipMemcpyAsync(host, fuifgpu_batch_out_ptr(b, image), sizeof(int32_t) * (size_t)b->plan.out_elems, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     return FUIFGPU_OK;

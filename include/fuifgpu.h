@@ -88,7 +88,7 @@ void fuifgpu_batch_destroy(fuifgpu_batch *batch);
  * (stream bytes, tile lists, per-image status / consumed / metadata) and launches with the primary's coefficient and output
  * slabs, decoder scratch, context arenas and transform arena -- ~12 MB per 4K stream instead of a second 45 GB of launch state.
  * Rules: upload the primary once before the sibling's first upload (its scratch serves both); decode / undo_transforms of the
- * two on ONE stream (they share the slabs); destroy the sibling first.  The pattern, per step k: thread U uploads into batch
+ * two on ONE stream (they share the slabs); destroy the sibling first (a sibling that outlives its primary refuses every call).  The pattern, per step k: thread U uploads into batch
  * (k+1)%2 on the copy stream while the caller runs decode + undo_transforms of batch k%2; join; consume; repeat
  * (bench.py's `value_incl_h2d`, tests/test_gpu_synthetic.py).  The reference has no counterpart: it reads one file at a time
  * (encoding/encoding.cpp:745-753). */

@@ -55,6 +55,7 @@ SELECTED = [
     "tests/test_gpu_transform_exports.py",
     "tests/test_gpu_synthetic.py::test_deep_trees_walk_through_chained_supernodes",
     "tests/test_gpu_synthetic.py::test_sibling_batch_pipelines_uploads",
+    "tests/test_gpu_synthetic.py::test_sibling_outliving_its_primary_is_refused_not_dangling",
     "tests/test_zz_gpu_encoder.py",
 ]
 

@@ -230,3 +230,21 @@ def test_sibling_batch_pipelines_uploads(gpulib):
     finally:
         other.close()
         primary.close()
+
+
+def test_sibling_outliving_its_primary_is_refused_not_dangling(gpulib):
+    """the documented order is "destroy the sibling first"; the other order must leave a sibling that refuses every call
+    instead of one that launches with freed slabs"""
+    img = photographic(96, 64, 3, 8, seed=9)
+    blob = gpulib.encode_image(img, 8, tree_mode=1, index=True)
+    plan = gpulib.Plan(blob)
+    primary = gpulib.Batch(plan, 1, len(blob))
+    primary.upload([blob])
+    other = primary.sibling(len(blob))
+    other.upload([blob])
+    primary.close()
+    with pytest.raises(gpulib.FuifGpuError):
+        other.upload([blob])
+    with pytest.raises(gpulib.FuifGpuError):
+        other.decode()
+    other.close()
