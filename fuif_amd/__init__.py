@@ -78,7 +78,7 @@ class EncodeOptions(C.Structure):
 ABI_SYMBOLS = [
     "fuifgpu_strerror", "fuifgpu_last_error", "fuifgpu_abi_version", "fuifgpu_plan_create", "fuifgpu_plan_destroy",
     "fuifgpu_plan_info", "fuifgpu_plan_coded_channel", "fuifgpu_plan_output_channel", "fuifgpu_plan_transform",
-    "fuifgpu_build_chance_table", "fuifgpu_batch_create", "fuifgpu_batch_create_sibling", "fuifgpu_batch_destroy", "fuifgpu_batch_upload",
+    "fuifgpu_build_chance_table", "fuifgpu_batch_create", "fuifgpu_batch_create_sibling", "fuifgpu_dev_mem_info", "fuifgpu_batch_destroy", "fuifgpu_batch_upload",
     "fuifgpu_batch_decode", "fuifgpu_batch_undo_transforms", "fuifgpu_batch_sync", "fuifgpu_batch_status",
     "fuifgpu_batch_channel_meta", "fuifgpu_batch_coef_ptr", "fuifgpu_batch_out_ptr", "fuifgpu_batch_download_coef",
     "fuifgpu_batch_download_out", "fuifgpu_batch_last_timing", "fuifgpu_batch_profile", "fuifgpu_batch_tile_log", "fuifgpu_batch_sched_stats", "fuifgpu_inv_hsqueeze", "fuifgpu_inv_vsqueeze",

@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -262,31 +263,60 @@ int fuif_decode_files(const char *const *filenames, int n_files, Image *images, 
         fuifgpu_plan *plan = plans[idx[0]];
         fuifgpu_image_info info;
         fuifgpu_plan_info(plan, &info);
-        size_t total = 0;
-        std::vector<const uint8_t *> ptr;
-        std::vector<size_t> len;
-        for (int i : idx) { ptr.push_back(bytes[i].data()); len.push_back(bytes[i].size()); total += bytes[i].size(); }
+        // How many of the group's files fit on the device at once: per picture its coefficient and output slabs (int32), its
+        // stream and a context arena; a quarter of the free memory (at most 40 GiB) stays for the decoder scratch and the
+        // transform arena.  A larger group goes through ONE batch object chunk by chunk (FUIFGPU_BOUNDARY_CHUNK: tests).
+        const int n = (int)idx.size();
+        size_t max_stream = 0;
+        for (int i : idx) max_stream = std::max(max_stream, bytes[i].size());
+        int chunk = n;
+        {
+            size_t free_b = 0, total_b = 0;
+            if (fuifgpu_dev_mem_info(&free_b, &total_b) == FUIFGPU_OK && free_b) {
+                const size_t reserve = std::min<size_t>(free_b / 4, (size_t)40 << 30);
+                const size_t per_image = 4 * (size_t)(info.coef_elems + info.out_elems) + max_stream + ((size_t)16 << 20);
+                chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, (free_b - reserve) / std::max<size_t>(per_image, 1)));
+            }
+            if (const char *e = getenv("FUIFGPU_BOUNDARY_CHUNK")) chunk = std::max(1, std::min(n, atoi(e)));
+        }
+        size_t cap = 0;
+        for (int c0 = 0; c0 < n; c0 += chunk) {
+            size_t t = 0;
+            for (int k = c0; k < std::min(n, c0 + chunk); k++) t += bytes[idx[k]].size();
+            cap = std::max(cap, t);
+        }
         fuifgpu_batch *batch = nullptr;
-        int rc = fuifgpu_batch_create(plan, (int)idx.size(), total, nullptr, nullptr, 0, &batch);
-        if (rc == FUIFGPU_OK) rc = fuifgpu_batch_upload(batch, ptr.data(), len.data(), (int)idx.size(), options.preview, nullptr);
-        if (rc == FUIFGPU_OK) rc = fuifgpu_batch_decode(batch, nullptr);
-        if (rc == FUIFGPU_OK) rc = fuifgpu_batch_undo_transforms(batch, nullptr);
-        if (rc == FUIFGPU_OK) rc = fuifgpu_batch_sync(batch, nullptr);
+        int rc = fuifgpu_batch_create(plan, chunk, cap, nullptr, nullptr, 0, &batch);
+        int n_chunks = 0;
+        for (int c0 = 0; c0 < n && rc == FUIFGPU_OK; c0 += chunk, n_chunks++) {
+            const int cnt = std::min(chunk, n - c0);
+            std::vector<const uint8_t *> ptr;
+            std::vector<size_t> len;
+            for (int k = c0; k < c0 + cnt; k++) { ptr.push_back(bytes[idx[k]].data()); len.push_back(bytes[idx[k]].size()); }
+            rc = fuifgpu_batch_upload(batch, ptr.data(), len.data(), cnt, options.preview, nullptr);
+            if (rc == FUIFGPU_OK) rc = fuifgpu_batch_decode(batch, nullptr);
+            if (rc == FUIFGPU_OK) rc = fuifgpu_batch_undo_transforms(batch, nullptr);
+            if (rc == FUIFGPU_OK) rc = fuifgpu_batch_sync(batch, nullptr);
+            if (rc != FUIFGPU_OK) break;
+            std::vector<int32_t> status((size_t)cnt, 0);
+            fuifgpu_batch_status(batch, status.data(), nullptr);
+            for (int k = 0; k < cnt; k++) {
+                const int i = idx[c0 + k];
+                if (status[k] & FUIFGPU_ST_UNSUPPORTED) { cpu_route[i] = 1; continue; }
+                if (status[k] & FUIFGPU_ST_CORRUPT) { e_printf("%s: corruption detected.\n", filenames[i]); continue; }
+                image_from_outputs(images[i], plan, batch, k, info);
+                ok[i] = 1;
+            }
+        }
         if (rc != FUIFGPU_OK) {
             e_printf("fuifgpu: %s (%s)\n", fuifgpu_strerror(rc), fuifgpu_last_error());
             if (batch) fuifgpu_batch_destroy(batch);
             continue;
         }
-        std::vector<int32_t> status(idx.size(), 0);
-        fuifgpu_batch_status(batch, status.data(), nullptr);
-        for (size_t k = 0; k < idx.size(); k++) {
-            const int i = idx[k];
-            if (status[k] & FUIFGPU_ST_UNSUPPORTED) { cpu_route[i] = 1; continue; }
-            if (status[k] & FUIFGPU_ST_CORRUPT) { e_printf("%s: corruption detected.\n", filenames[i]); continue; }
-            image_from_outputs(images[i], plan, batch, (int)k, info);
-            ok[i] = 1;
+        if (verbose) {
+            if (n_chunks <= 1) fprintf(stderr, "fuifgpu: %d file(s) of %dx%d decoded in one batch on the GPU\n", n, info.w, info.h);
+            else fprintf(stderr, "fuifgpu: %d file(s) of %dx%d decoded in %d batches of up to %d on the GPU\n", n, info.w, info.h, n_chunks, chunk);
         }
-        if (verbose) fprintf(stderr, "fuifgpu: %d file(s) of %dx%d decoded in one batch on the GPU\n", (int)idx.size(), info.w, info.h);
         fuifgpu_batch_destroy(batch);
     }
     for (int i = 0; i < n_files; i++) {

@@ -729,6 +729,13 @@ void *fuifgpu_dev_alloc(size_t bytes) {
     return p;
 }
 void fuifgpu_dev_free(void *p) { if (p) hipFree(p); }
+int fuifgpu_dev_mem_info(size_t *free_bytes, size_t *total_bytes) {
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return FUIFGPU_OK;
+}
 int fuifgpu_dev_upload(void *dst_device, const void *src_host, size_t bytes) {
     if ((!dst_device || !src_host) && bytes) return FUIFGPU_E_ARG;
     if (bytes) HIPCHK(hipMemcpy(dst_device, src_host, bytes, hipMemcpyHostToDevice));

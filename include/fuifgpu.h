@@ -176,6 +176,7 @@ int fuifgpu_batch_set_group_parallel(fuifgpu_batch *batch, int enable);
 /* ---- device memory for hosts that are not HIP programs (the boundary layer is plain g++ code) ------------- */
 void *fuifgpu_dev_alloc(size_t bytes);                       /* NULL on failure (fuifgpu_last_error) */
 void fuifgpu_dev_free(void *device_ptr);
+int fuifgpu_dev_mem_info(size_t *free_bytes, size_t *total_bytes);   /* hipMemGetInfo: what a host sizes its batches with */
 int fuifgpu_dev_upload(void *dst_device, const void *src_host, size_t bytes);
 int fuifgpu_dev_download(void *dst_host, const void *src_device, size_t bytes);   /* waits for the null stream */
 

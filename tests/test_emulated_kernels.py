@@ -167,6 +167,15 @@ def test_reference_cli_through_the_boundary_writes_the_reference_files(tmp_path)
             rb = subprocess.run([ref_cli, "-d", src, b], env=env, capture_output=True, text=True, timeout=600)
             assert rb.returncode == 0
             assert open(str(outdir / (n + ".pam")), "rb").read() == open(b, "rb").read(), n
+        # a group larger than what the device holds goes through one Batch object chunk by chunk (here forced to one file per chunk)
+        outdir2 = tmp_path / "batch_chunked"
+        outdir2.mkdir()
+        rc = subprocess.run([batch_cli, str(outdir2)] + files + [str(dup)], env=dict(env_gpu, FUIFGPU_VERBOSE="1", FUIFGPU_BOUNDARY_CHUNK="1"),
+                            capture_output=True, text=True, timeout=900)
+        assert rc.returncode == 0, rc.stderr[-600:]
+        assert "2 file(s) of 97x61 decoded in 2 batches of up to 1 on the GPU" in rc.stderr
+        for n in picks + ["rgb8_97x61_again"]:
+            assert open(str(outdir2 / (n + ".pam")), "rb").read() == open(str(outdir / (n + ".pam")), "rb").read(), n
     # `-d x.fuif out.yuv` keeps the colour transform and the chroma subsampling: Image::undo_transforms(2) (fuif.cpp:230),
     # i.e. Transform::apply(image, true) per transform -- Squeeze, Quantization and DCT inverses through the boundary's binding to
     # fuifgpu_inv_hsqueeze / fuifgpu_inv_vsqueeze / fuifgpu_inv_quantize / fuifgpu_idct8x8
