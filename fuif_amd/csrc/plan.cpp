@@ -662,8 +662,8 @@ struct Builder {
     // inverse chain, becomes ONE op: the full-size Co and Cg planes are never written and read back, and the YCoCg pass over
     // six planes disappears (C2: 331 -> 198 MB of plane traffic per 4K image for these three ops).
     void fuse_chroma_hsqueeze_ycocg() {
-        static const int enabled = [] { const char *e = getenv("FUIFGPU_FUSE_YCOCG"); return e ? atoi(e) : 1; }();
-        if (!enabled) return;
+        const char *e = getenv("FUIFGPU_FUSE_YCOCG");   // read per plan: A/B measurements and tests switch it inside one process
+        if (e && atoi(e) == 0) return;
         std::vector<Op> &ops = plan.ops;
         for (size_t k = 2; k < ops.size(); k++) {
             const Op &c = ops[k], &h1 = ops[k - 2], &h2 = ops[k - 1];

@@ -56,6 +56,7 @@ SELECTED = [
     "tests/test_gpu_synthetic.py::test_deep_trees_walk_through_chained_supernodes",
     "tests/test_gpu_synthetic.py::test_sibling_batch_pipelines_uploads",
     "tests/test_gpu_synthetic.py::test_sibling_outliving_its_primary_is_refused_not_dangling",
+    "tests/test_gpu_synthetic.py::test_unsqueeze_kernels_on_geometries_around_their_tile_edges",
     "tests/test_zz_gpu_encoder.py",
 ]
 

@@ -248,3 +248,28 @@ def test_sibling_outliving_its_primary_is_refused_not_dangling(gpulib):
     with pytest.raises(gpulib.FuifGpuError):
         other.decode()
     other.close()
+
+
+@pytest.mark.parametrize("w,h", [(33, 5), (34, 64), (35, 65), (47, 1), (64, 63), (65, 66), (66, 2), (97, 130), (129, 64), (130, 67), (257, 9), (260, 70)])
+def test_unsqueeze_kernels_on_geometries_around_their_tile_edges(gpulib, w, h):
+    """the tiled horizontal unsqueeze (64-row tiles of 32 pairs), the fused chroma unsqueeze + YCoCg (16 pairs) and the vertical
+    kernel (8 row pairs per step) on pictures whose plane sizes sit on both sides of every tile / step boundary: lossless
+    YCoCg + Squeeze streams must decode to their source pixels, with the fused op and with the three separate ops
+    (FUIFGPU_FUSE_YCOCG is read when a plan is made)"""
+    import os
+    img = photographic(w, h, 3, 8, seed=8000 + 7 * w + h)
+    blob = gpulib.encode_image(img, 8, tree_mode=0, index=True)
+    for fuse in ("1", "0"):
+        old = os.environ.get("FUIFGPU_FUSE_YCOCG")
+        os.environ["FUIFGPU_FUSE_YCOCG"] = fuse
+        try:
+            pre, post, st, used = gpu_decode(gpulib, [blob, blob])
+        finally:
+            if old is None:
+                os.environ.pop("FUIFGPU_FUSE_YCOCG", None)
+            else:
+                os.environ["FUIFGPU_FUSE_YCOCG"] = old
+        assert not st.any()
+        for planes in post:
+            for k in range(3):
+                assert np.array_equal(planes[k], img[k]), (fuse, k)
