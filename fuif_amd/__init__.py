@@ -78,7 +78,7 @@ class EncodeOptions(C.Structure):
 ABI_SYMBOLS = [
     "fuifgpu_strerror", "fuifgpu_last_error", "fuifgpu_abi_version", "fuifgpu_plan_create", "fuifgpu_plan_destroy",
     "fuifgpu_plan_info", "fuifgpu_plan_coded_channel", "fuifgpu_plan_output_channel", "fuifgpu_plan_transform",
-    "fuifgpu_build_chance_table", "fuifgpu_batch_create", "fuifgpu_batch_create_sibling", "fuifgpu_dev_mem_info", "fuifgpu_batch_destroy", "fuifgpu_batch_upload",
+    "fuifgpu_build_chance_table", "fuifgpu_batch_create", "fuifgpu_batch_create_sibling", "fuifgpu_dev_mem_info", "fuifgpu_encode_images", "fuifgpu_batch_destroy", "fuifgpu_batch_upload",
     "fuifgpu_batch_decode", "fuifgpu_batch_undo_transforms", "fuifgpu_batch_sync", "fuifgpu_batch_status",
     "fuifgpu_batch_channel_meta", "fuifgpu_batch_coef_ptr", "fuifgpu_batch_out_ptr", "fuifgpu_batch_download_coef",
     "fuifgpu_batch_download_out", "fuifgpu_batch_last_timing", "fuifgpu_batch_profile", "fuifgpu_batch_tile_log", "fuifgpu_batch_sched_stats", "fuifgpu_inv_hsqueeze", "fuifgpu_inv_vsqueeze",
@@ -158,6 +158,7 @@ def lib():
     L.fuifgpu_fwd_hsqueeze.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.fuifgpu_fwd_vsqueeze.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.fuifgpu_encode_image.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(EncodeOptions), C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.fuifgpu_encode_images.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(EncodeOptions), C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.fuifgpu_free_blob.argtypes = [vp]; L.fuifgpu_free_blob.restype = None
     L.fuifgpu_index_parse.argtypes = [C.c_char_p, C.c_size_t, vp, vp, C.c_int, C.POINTER(C.c_int)]
     L.fuifgpu_index_append.argtypes = [C.c_char_p, C.c_size_t, vp, vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -394,6 +395,28 @@ def encode_image(planes, bit_depth=8, ycocg=True, squeeze=True, max_properties=1
     blob = C.string_at(out.value, n.value)
     lib().fuifgpu_free_blob(out)
     return blob
+
+
+def encode_images(images, bit_depth=8, ycocg=True, squeeze=True, max_properties=12, tree_mode=1, max_tree_nodes=4095, index=False,
+                  split_bits=None, gpu_forward=False):
+    """a batch of equally sized (C,H,W) pictures -> list of .fuif byte strings, what encode_image writes for each of them; the
+    MANIAC pixel loops of ALL their channel groups run in one launch pair on the GPU (fuifgpu_encode_images)"""
+    split_bits = DEFAULT_SPLIT_BITS if split_bits is None else split_bits
+    arrs = [np.ascontiguousarray(im, dtype=np.int32) for im in images]
+    c, h, w = arrs[0].shape
+    if any(a.shape != (c, h, w) for a in arrs):
+        raise FuifGpuError(4, "encode_images: all pictures of a batch must have one shape")
+    n = len(arrs)
+    opt = EncodeOptions(int(ycocg), int(squeeze), max_properties, tree_mode, max_tree_nodes, int(index), int(split_bits), int(gpu_forward), 1)
+    ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+    outs = (C.c_void_p * n)()
+    sizes = (C.c_size_t * n)()
+    _check(lib().fuifgpu_encode_images(ptrs, n, w, h, c, bit_depth, C.byref(opt), outs, sizes))
+    blobs = []
+    for k in range(n):
+        blobs.append(C.string_at(outs[k], sizes[k]))
+        lib().fuifgpu_free_blob(C.c_void_p(outs[k]))
+    return blobs
 
 
 def index_parse(blob):

@@ -28,6 +28,29 @@ struct RacEncState {       // RacOutput24 between two symbols: range, low, the d
     int32_t delayed, pending;
 };
 
+// ---- many groups in one launch pair (a batch of pictures) ----------------------------------------------------------------
+struct EncJobDev {         // what the kernels see of one job; all pointers are device pointers
+    EncGroup g;
+    const EncNode *tree;
+    int32_t n_nodes, pad;
+    int32_t *guess, *leaf; // per pixel, written by k_enc_model_jobs, read by k_enc_rac_jobs
+    uint16_t *leaves;      // n_leaves x 31 chances
+    uint32_t *state;       // 8 words: RacEncState in / out, bytes emitted, overflow flag
+    uint8_t *out;
+    uint32_t out_cap, pad2;
+    int64_t n;             // pixels
+};
+struct EncJob {            // host side of one job
+    EncGroup g;                        // device pointers of the planes
+    std::vector<EncNode> tree;
+    int n_leaves = 1;
+    uint16_t leaf_init[31];
+    RacEncState state;                 // in: behind the tree; out: behind the last symbol
+    std::vector<uint8_t> body;         // out: the bytes the coder emitted for the pixels
+};
+// Runs every job's context model (one launch, blockIdx.y = job) and then every job's coder (one wavefront per job).
+int maniac_encode_jobs_gpu(std::vector<EncJob> &jobs, const uint16_t *pixel_table);
+
 // grow-only device buffers of one encode call
 struct EncScratch {
     int32_t *d_guess = nullptr, *d_leaf = nullptr;

@@ -16,10 +16,12 @@
 // pixels: the coder's state {range, low, delayed byte, pending 0xFF run} is handed in and handed back.  Output is byte-identical to
 // the host writer's (tests/test_zz_gpu_encoder.py), which tests/test_writer.py pins to the reference CLI.
 //
-// Round 3: first correct path, one group per launch pair, synchronous.  A 4K picture's longest group is a chain of 4.1 million
-// symbols on ONE lane, so a single picture is slower than on a CPU core; the point of the design is the batch (one wavefront per
-// group over many pictures, as k_maniac_decode does) -- not built yet.  Parity was checked on the MI355X
-// (profiles/r3_gpu_encoder_tests.txt); no timing was taken in round 3.
+// Round 3: first correct path.  A 4K picture's longest group is a chain of 4.1 million symbols on ONE lane, so a single picture
+// (maniac_encode_group_gpu: one group per launch pair, synchronous) is slower than on a CPU core; the point of the design is the
+// batch: maniac_encode_jobs_gpu runs one wavefront per group over many pictures, as k_maniac_decode does.  Parity of the
+// single-group kernels was checked on the MI355X (profiles/r3_gpu_encoder_tests.txt); the job-list kernels share their device code
+// and are emulator-verified; nothing was timed in round 3.  Known cost: leaf chances live in global memory (a dependent read
+// and a write per binary decision) -- the decoder's "current leaf in a register" is the obvious next step.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -53,8 +55,8 @@ DEV int e_median3(int a, int b, int c) {
 
 // ---------------------------------------------------------------------------------------------
 // context model of every pixel, in parallel
-__global__ __launch_bounds__(256) void k_enc_model(EncGroup g, const EncNode *tree, int n_nodes, int32_t *guess_out, int32_t *leaf_out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+namespace {
+DEV void enc_model_pixel(const EncGroup &g, const EncNode *tree, int n_nodes, int64_t i, int32_t *guess_out, int32_t *leaf_out) {
     const int64_t n = (int64_t)g.w * g.h;
     if (i >= n) return;
     const int w = g.w;
@@ -100,6 +102,16 @@ __global__ __launch_bounds__(256) void k_enc_model(EncGroup g, const EncNode *tr
     }
     guess_out[i] = guess;
     leaf_out[i] = nd.leaf;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_enc_model(EncGroup g, const EncNode *tree, int n_nodes, int32_t *guess_out, int32_t *leaf_out) {
+    enc_model_pixel(g, tree, n_nodes, (int64_t)blockIdx.x * 256 + threadIdx.x, guess_out, leaf_out);
+}
+// the same for a list of groups (of many pictures) in one launch: blockIdx.y = job
+__global__ __launch_bounds__(256) void k_enc_model_jobs(const EncJobDev *jobs) {
+    const EncJobDev &j = jobs[blockIdx.y];
+    enc_model_pixel(j.g, j.tree, j.n_nodes, (int64_t)blockIdx.x * 256 + threadIdx.x, j.guess, j.leaf);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -162,9 +174,10 @@ DEV void dev_write_symbol(DevRac &r, uint16_t *ch, const uint16_t *table, int mi
 
 }  // namespace
 
+namespace {
 // state[0..3] = RacEncState in / out, state[4] = bytes emitted (out), state[5] = 1 when `out` was too small
-__global__ __launch_bounds__(64) void k_enc_rac(const int32_t *plane, const int32_t *guess, const int32_t *leafidx, int64_t n, int minval, int maxval,
-                                                uint16_t *leaves, const uint16_t *table_g, uint32_t *state, uint8_t *out, uint32_t out_cap) {
+DEV void enc_rac_run(const int32_t *plane, const int32_t *guess, const int32_t *leafidx, int64_t n, int minval, int maxval, uint16_t *leaves,
+                     const uint16_t *table_g, uint32_t *state, uint8_t *out, uint32_t out_cap) {
     __shared__ uint16_t table[8192];
     __shared__ int32_t s_diff[64], s_min[64], s_max[64], s_leaf[64];
     const int lane = threadIdx.x;
@@ -196,6 +209,17 @@ __global__ __launch_bounds__(64) void k_enc_rac(const int32_t *plane, const int3
         state[0] = r.range; state[1] = r.low; state[2] = (uint32_t)r.delayed; state[3] = (uint32_t)r.pending;
         state[4] = r.count; state[5] = r.count > r.cap ? 1u : 0u;
     }
+}
+}  // namespace
+
+__global__ __launch_bounds__(64) void k_enc_rac(const int32_t *plane, const int32_t *guess, const int32_t *leafidx, int64_t n, int minval, int maxval,
+                                                uint16_t *leaves, const uint16_t *table_g, uint32_t *state, uint8_t *out, uint32_t out_cap) {
+    enc_rac_run(plane, guess, leafidx, n, minval, maxval, leaves, table_g, state, out, out_cap);
+}
+// one wavefront per job: the groups of a whole batch of pictures code side by side, as k_maniac_decode's tiles decode
+__global__ __launch_bounds__(64) void k_enc_rac_jobs(const EncJobDev *jobs, const uint16_t *table_g) {
+    const EncJobDev &j = jobs[blockIdx.x];
+    enc_rac_run(j.g.plane, j.guess, j.leaf, j.n, j.g.minval, j.g.maxval, j.leaves, table_g, j.state, j.out, j.out_cap);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -253,6 +277,74 @@ int maniac_encode_group_gpu(const EncGroup &g, const EncNode *tree, int n_nodes,
     state->range = st[0]; state->low = st[1]; state->delayed = (int32_t)st[2]; state->pending = (int32_t)st[3];
 #undef ECHK
     return FUIFGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A batch: one device arena for all jobs, one k_enc_model_jobs launch, one k_enc_rac_jobs launch with a wavefront per job.
+int maniac_encode_jobs_gpu(std::vector<EncJob> &jobs, const uint16_t *pixel_table) {
+    if (!pixel_table) return FUIFGPU_E_ARG;
+    if (jobs.empty()) return FUIFGPU_OK;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    size_t total = up(sizeof(EncJobDev) * jobs.size()) + up(sizeof(uint16_t) * 8192), max_n = 0;
+    for (const EncJob &j : jobs) {
+        if (!j.g.plane || j.tree.empty() || j.n_leaves < 1 || j.g.w < 1 || j.g.h < 1 || j.g.nrefs < 0 || j.g.nrefs > kMaxRefs) return FUIFGPU_E_ARG;
+        const size_t n = (size_t)j.g.w * j.g.h;
+        max_n = std::max(max_n, n);
+        total += 2 * up(n * 4) + up(std::min<size_t>(n * 4 + 1024, 0xFFFFFF00u)) + up(sizeof(EncNode) * j.tree.size()) +
+                 up(sizeof(uint16_t) * CH_N * (size_t)j.n_leaves) + up(32);
+    }
+    uint8_t *arena = nullptr;
+    if (hipMalloc((void **)&arena, total) != hipSuccess) return FUIFGPU_E_HIP;
+    int rc = FUIFGPU_OK;
+    std::vector<EncJobDev> dev(jobs.size());
+#define ECHK(call) do { if (rc == FUIFGPU_OK && (call) != hipSuccess) rc = FUIFGPU_E_HIP; } while (0)
+    size_t off = up(sizeof(EncJobDev) * jobs.size());
+    uint16_t *d_table = reinterpret_cast<uint16_t *>(arena + off); off += up(sizeof(uint16_t) * 8192);
+    ECHK(hipMemcpy(d_table, pixel_table, sizeof(uint16_t) * 8192, hipMemcpyHostToDevice));
+    for (size_t k = 0; k < jobs.size() && rc == FUIFGPU_OK; k++) {
+        EncJob &j = jobs[k];
+        EncJobDev &d = dev[k];
+        const size_t n = (size_t)j.g.w * j.g.h;
+        d.g = j.g; d.n = (int64_t)n; d.n_nodes = (int32_t)j.tree.size(); d.pad = 0; d.pad2 = 0;
+        d.guess = reinterpret_cast<int32_t *>(arena + off); off += up(n * 4);
+        d.leaf = reinterpret_cast<int32_t *>(arena + off); off += up(n * 4);
+        d.out_cap = (uint32_t)std::min<size_t>(n * 4 + 1024, 0xFFFFFF00u);
+        d.out = arena + off; off += up(d.out_cap);
+        EncNode *d_tree = reinterpret_cast<EncNode *>(arena + off); off += up(sizeof(EncNode) * j.tree.size());
+        d.tree = d_tree;
+        d.leaves = reinterpret_cast<uint16_t *>(arena + off); off += up(sizeof(uint16_t) * CH_N * (size_t)j.n_leaves);
+        d.state = reinterpret_cast<uint32_t *>(arena + off); off += up(32);
+        std::vector<uint16_t> leaves((size_t)j.n_leaves * CH_N);
+        for (int l = 0; l < j.n_leaves; l++) memcpy(&leaves[(size_t)l * CH_N], j.leaf_init, sizeof(uint16_t) * CH_N);
+        const uint32_t st[8] = {j.state.range, j.state.low, (uint32_t)j.state.delayed, (uint32_t)j.state.pending, 0, 0, 0, 0};
+        ECHK(hipMemcpy(d_tree, j.tree.data(), sizeof(EncNode) * j.tree.size(), hipMemcpyHostToDevice));
+        ECHK(hipMemcpy(d.leaves, leaves.data(), sizeof(uint16_t) * leaves.size(), hipMemcpyHostToDevice));
+        ECHK(hipMemcpy(d.state, st, sizeof(st), hipMemcpyHostToDevice));
+    }
+    EncJobDev *d_jobs = reinterpret_cast<EncJobDev *>(arena);
+    ECHK(hipMemcpy(d_jobs, dev.data(), sizeof(EncJobDev) * dev.size(), hipMemcpyHostToDevice));
+    if (rc == FUIFGPU_OK) {
+        // grid.y is limited to 65535: launch the jobs in slices
+        for (size_t j0 = 0; j0 < jobs.size(); j0 += 32768) {
+            const unsigned cnt = (unsigned)std::min<size_t>(32768, jobs.size() - j0);
+            hipLaunchKernelGGL(k_enc_model_jobs, dim3((unsigned)((max_n + 255) / 256), cnt), dim3(256), 0, nullptr, d_jobs + j0);
+        }
+        hipLaunchKernelGGL(k_enc_rac_jobs, dim3((unsigned)jobs.size()), dim3(64), 0, nullptr, d_jobs, d_table);
+        ECHK(hipGetLastError());
+        ECHK(hipDeviceSynchronize());
+    }
+    for (size_t k = 0; k < jobs.size() && rc == FUIFGPU_OK; k++) {
+        uint32_t st[8];
+        ECHK(hipMemcpy(st, dev[k].state, sizeof(st), hipMemcpyDeviceToHost));
+        if (rc != FUIFGPU_OK) break;
+        if (st[5]) { rc = FUIFGPU_E_NOMEM; break; }
+        jobs[k].body.resize(st[4]);
+        if (st[4]) ECHK(hipMemcpy(jobs[k].body.data(), dev[k].out, st[4], hipMemcpyDeviceToHost));
+        jobs[k].state = RacEncState{st[0], st[1], (int32_t)st[2], (int32_t)st[3]};
+    }
+#undef ECHK
+    hipFree(arena);
+    return rc;
 }
 
 }  // namespace fuifgpu

@@ -233,6 +233,14 @@ typedef struct {
 } fuifgpu_encode_options;
 int fuifgpu_encode_image(const int32_t *planes, int w, int h, int nch, int bit_depth, const fuifgpu_encode_options *opt,
                          uint8_t **blob_out, size_t *size_out);
+/* A batch of pictures of one size (planes[m]: nch planes of w*h samples): the host prepares every channel group of every picture
+ * (header, learned tree, the coder's state behind it), then the MANIAC pixel loops of ALL groups run in one launch pair -- the
+ * context model of every pixel in parallel, one wavefront per group for the range coder (csrc/maniac_encode.hip; the way
+ * k_maniac_decode runs one wavefront per group of a batch) -- and the host assembles the streams.  blobs_out[m] / sizes_out[m]
+ * are what fuifgpu_encode_image writes for picture m, byte for byte (gpu_entropy is implied; opt NULL = CLI defaults).
+ * Replaces N runs of the reference's `fuif_encode_file` (encoding/encoding.cpp:727-735). */
+int fuifgpu_encode_images(const int32_t *const *planes, int n_images, int w, int h, int nch, int bit_depth, const fuifgpu_encode_options *opt,
+                          uint8_t **blobs_out, size_t *sizes_out);
 /* channels already in a transform domain (e.g. the quantised DCT coefficient planes import/read_jpeg.h:56-184
  * builds): geometry + q + samples per channel, `transforms` = flat words {id, nparams, params...} of the
  * transforms that produced them; opt->squeeze adds the default Squeeze of the first nb_channels channels */

@@ -36,3 +36,16 @@ def test_flat_and_tiny_planes(gpulib):
         host = gpulib.encode_image(img, 8, tree_mode=1, **kw)
         dev = gpulib.encode_image(img, 8, tree_mode=1, gpu_entropy=True, **kw)
         assert dev == host
+
+
+def test_batch_of_pictures_in_one_launch_pair(gpulib):
+    """fuifgpu_encode_images: every channel group of every picture of the batch gets its own wavefront in ONE coder launch; each
+    stream must be the bytes the one-picture writer produces (learned trees and the single-leaf mode)"""
+    w, h = (72, 56) if EMULATED else (480, 360)
+    imgs = [photographic(w, h, 3, 8, seed=7100 + i) for i in range(5)]
+    imgs.append(np.full((3, h, w), 9, np.int32))            # a flat picture: only trivial channels, no job at all
+    for tree_mode in (1, 0):
+        split = 2 if (tree_mode and w * h < 20000) else None
+        want = [gpulib.encode_image(im, 8, tree_mode=tree_mode, index=True, split_bits=split) for im in imgs]
+        got = gpulib.encode_images(imgs, 8, tree_mode=tree_mode, index=True, split_bits=split)
+        assert got == want
