@@ -31,7 +31,7 @@ def timed(label, fn):
     t0 = time.perf_counter()
     out = fn()
     dt = time.perf_counter() - t0
-    print("%-9s %d x %dx%d tree_mode %d: %.2f s -> %.2f Mpixels/s" % (label, n, w, h, tree_mode, dt, mpx / dt), flush=True)
+    print("%-9s %d x %dx%d tree_mode %d: %.2f s -> %.2f Mpixels/s" % (label, len(out), w, h, tree_mode, dt, len(out) * w * h / 1e6 / dt), flush=True)
     return out
 
 
