@@ -280,68 +280,106 @@ int maniac_encode_group_gpu(const EncGroup &g, const EncNode *tree, int n_nodes,
 }
 
 // ---------------------------------------------------------------------------------------------
-// A batch: one device arena for all jobs, one k_enc_model_jobs launch, one k_enc_rac_jobs launch with a wavefront per job.
+// the bodies of all jobs, packed back to back (one block per job copies out[0 .. state[4]) to dst + offset[job])
+__global__ __launch_bounds__(256) void k_enc_gather(const EncJobDev *jobs, const uint64_t *offset, uint8_t *dst) {
+    const EncJobDev &j = jobs[blockIdx.x];
+    const uint32_t n = j.state[4] < j.out_cap ? j.state[4] : j.out_cap;
+    uint8_t *d = dst + offset[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < n; i += 256) d[i] = j.out[i];
+}
+
+// A batch: one device arena for all jobs.  Its head -- job table, chance table, every job's tree, leaf chances and coder state --
+// is assembled on the host and uploaded in ONE copy; the states come back in one copy, the bodies are packed by k_enc_gather
+// and come back in one more (a 1024-picture batch has ~62 000 jobs: per-job copies would cost seconds).
 int maniac_encode_jobs_gpu(std::vector<EncJob> &jobs, const uint16_t *pixel_table) {
     if (!pixel_table) return FUIFGPU_E_ARG;
     if (jobs.empty()) return FUIFGPU_OK;
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-    size_t total = up(sizeof(EncJobDev) * jobs.size()) + up(sizeof(uint16_t) * 8192), max_n = 0;
-    for (const EncJob &j : jobs) {
+    const size_t nj = jobs.size();
+    // layout of the head: [EncJobDev x nj][table][states: 32 bytes x nj][per job: tree, leaves]; then per job: guess, leaf, out;
+    // then the offsets and the packed bodies
+    const size_t off_table = up(sizeof(EncJobDev) * nj), off_states = off_table + up(sizeof(uint16_t) * 8192);
+    size_t head = off_states + up(32 * nj), max_n = 0;
+    std::vector<size_t> off_tree(nj), off_leaves(nj);
+    for (size_t k = 0; k < nj; k++) {
+        const EncJob &j = jobs[k];
         if (!j.g.plane || j.tree.empty() || j.n_leaves < 1 || j.g.w < 1 || j.g.h < 1 || j.g.nrefs < 0 || j.g.nrefs > kMaxRefs) return FUIFGPU_E_ARG;
-        const size_t n = (size_t)j.g.w * j.g.h;
-        max_n = std::max(max_n, n);
-        total += 2 * up(n * 4) + up(std::min<size_t>(n * 4 + 1024, 0xFFFFFF00u)) + up(sizeof(EncNode) * j.tree.size()) +
-                 up(sizeof(uint16_t) * CH_N * (size_t)j.n_leaves) + up(32);
+        max_n = std::max(max_n, (size_t)j.g.w * j.g.h);
+        off_tree[k] = head; head += up(sizeof(EncNode) * j.tree.size());
+        off_leaves[k] = head; head += up(sizeof(uint16_t) * CH_N * (size_t)j.n_leaves);
     }
+    size_t total = head;
+    std::vector<size_t> off_guess(nj), off_leaf(nj), off_out(nj);
+    std::vector<uint32_t> cap(nj);
+    for (size_t k = 0; k < nj; k++) {
+        const size_t n = (size_t)jobs[k].g.w * jobs[k].g.h;
+        // a symbol is at most 1 + 1 + 14 + 14 binary decisions, each well under a byte after renormalisation: 4 bytes per sample is generous
+        cap[k] = (uint32_t)std::min<size_t>(n * 4 + 1024, 0xFFFFFF00u);
+        off_guess[k] = total; total += up(n * 4);
+        off_leaf[k] = total; total += up(n * 4);
+        off_out[k] = total; total += up(cap[k]);
+    }
+    const size_t off_offsets = total; total += up(sizeof(uint64_t) * nj);
     uint8_t *arena = nullptr;
     if (hipMalloc((void **)&arena, total) != hipSuccess) return FUIFGPU_E_HIP;
     int rc = FUIFGPU_OK;
-    std::vector<EncJobDev> dev(jobs.size());
 #define ECHK(call) do { if (rc == FUIFGPU_OK && (call) != hipSuccess) rc = FUIFGPU_E_HIP; } while (0)
-    size_t off = up(sizeof(EncJobDev) * jobs.size());
-    uint16_t *d_table = reinterpret_cast<uint16_t *>(arena + off); off += up(sizeof(uint16_t) * 8192);
-    ECHK(hipMemcpy(d_table, pixel_table, sizeof(uint16_t) * 8192, hipMemcpyHostToDevice));
-    for (size_t k = 0; k < jobs.size() && rc == FUIFGPU_OK; k++) {
-        EncJob &j = jobs[k];
-        EncJobDev &d = dev[k];
-        const size_t n = (size_t)j.g.w * j.g.h;
-        d.g = j.g; d.n = (int64_t)n; d.n_nodes = (int32_t)j.tree.size(); d.pad = 0; d.pad2 = 0;
-        d.guess = reinterpret_cast<int32_t *>(arena + off); off += up(n * 4);
-        d.leaf = reinterpret_cast<int32_t *>(arena + off); off += up(n * 4);
-        d.out_cap = (uint32_t)std::min<size_t>(n * 4 + 1024, 0xFFFFFF00u);
-        d.out = arena + off; off += up(d.out_cap);
-        EncNode *d_tree = reinterpret_cast<EncNode *>(arena + off); off += up(sizeof(EncNode) * j.tree.size());
-        d.tree = d_tree;
-        d.leaves = reinterpret_cast<uint16_t *>(arena + off); off += up(sizeof(uint16_t) * CH_N * (size_t)j.n_leaves);
-        d.state = reinterpret_cast<uint32_t *>(arena + off); off += up(32);
-        std::vector<uint16_t> leaves((size_t)j.n_leaves * CH_N);
-        for (int l = 0; l < j.n_leaves; l++) memcpy(&leaves[(size_t)l * CH_N], j.leaf_init, sizeof(uint16_t) * CH_N);
+    std::vector<uint8_t> host(head, 0);
+    EncJobDev *h_jobs = reinterpret_cast<EncJobDev *>(host.data());
+    memcpy(host.data() + off_table, pixel_table, sizeof(uint16_t) * 8192);
+    for (size_t k = 0; k < nj; k++) {
+        const EncJob &j = jobs[k];
+        EncJobDev &d = h_jobs[k];
+        d.g = j.g; d.n = (int64_t)j.g.w * j.g.h; d.n_nodes = (int32_t)j.tree.size(); d.pad = 0; d.pad2 = 0;
+        d.tree = reinterpret_cast<const EncNode *>(arena + off_tree[k]);
+        d.leaves = reinterpret_cast<uint16_t *>(arena + off_leaves[k]);
+        d.state = reinterpret_cast<uint32_t *>(arena + off_states + 32 * k);
+        d.guess = reinterpret_cast<int32_t *>(arena + off_guess[k]);
+        d.leaf = reinterpret_cast<int32_t *>(arena + off_leaf[k]);
+        d.out = arena + off_out[k];
+        d.out_cap = cap[k];
+        memcpy(host.data() + off_tree[k], j.tree.data(), sizeof(EncNode) * j.tree.size());
+        for (int l = 0; l < j.n_leaves; l++) memcpy(host.data() + off_leaves[k] + sizeof(uint16_t) * CH_N * (size_t)l, j.leaf_init, sizeof(uint16_t) * CH_N);
         const uint32_t st[8] = {j.state.range, j.state.low, (uint32_t)j.state.delayed, (uint32_t)j.state.pending, 0, 0, 0, 0};
-        ECHK(hipMemcpy(d_tree, j.tree.data(), sizeof(EncNode) * j.tree.size(), hipMemcpyHostToDevice));
-        ECHK(hipMemcpy(d.leaves, leaves.data(), sizeof(uint16_t) * leaves.size(), hipMemcpyHostToDevice));
-        ECHK(hipMemcpy(d.state, st, sizeof(st), hipMemcpyHostToDevice));
+        memcpy(host.data() + off_states + 32 * k, st, sizeof(st));
     }
-    EncJobDev *d_jobs = reinterpret_cast<EncJobDev *>(arena);
-    ECHK(hipMemcpy(d_jobs, dev.data(), sizeof(EncJobDev) * dev.size(), hipMemcpyHostToDevice));
+    ECHK(hipMemcpy(arena, host.data(), head, hipMemcpyHostToDevice));
+    const EncJobDev *d_jobs = reinterpret_cast<const EncJobDev *>(arena);
+    const uint16_t *d_table = reinterpret_cast<const uint16_t *>(arena + off_table);
     if (rc == FUIFGPU_OK) {
         // grid.y is limited to 65535: launch the jobs in slices
-        for (size_t j0 = 0; j0 < jobs.size(); j0 += 32768) {
-            const unsigned cnt = (unsigned)std::min<size_t>(32768, jobs.size() - j0);
+        for (size_t j0 = 0; j0 < nj; j0 += 32768) {
+            const unsigned cnt = (unsigned)std::min<size_t>(32768, nj - j0);
             hipLaunchKernelGGL(k_enc_model_jobs, dim3((unsigned)((max_n + 255) / 256), cnt), dim3(256), 0, nullptr, d_jobs + j0);
         }
-        hipLaunchKernelGGL(k_enc_rac_jobs, dim3((unsigned)jobs.size()), dim3(64), 0, nullptr, d_jobs, d_table);
+        hipLaunchKernelGGL(k_enc_rac_jobs, dim3((unsigned)nj), dim3(64), 0, nullptr, d_jobs, d_table);
         ECHK(hipGetLastError());
-        ECHK(hipDeviceSynchronize());
     }
-    for (size_t k = 0; k < jobs.size() && rc == FUIFGPU_OK; k++) {
-        uint32_t st[8];
-        ECHK(hipMemcpy(st, dev[k].state, sizeof(st), hipMemcpyDeviceToHost));
-        if (rc != FUIFGPU_OK) break;
-        if (st[5]) { rc = FUIFGPU_E_NOMEM; break; }
-        jobs[k].body.resize(st[4]);
-        if (st[4]) ECHK(hipMemcpy(jobs[k].body.data(), dev[k].out, st[4], hipMemcpyDeviceToHost));
-        jobs[k].state = RacEncState{st[0], st[1], (int32_t)st[2], (int32_t)st[3]};
+    std::vector<uint32_t> states(8 * nj);
+    ECHK(hipMemcpy(states.data(), arena + off_states, 32 * nj, hipMemcpyDeviceToHost));   // synchronises with the null stream's kernels
+    std::vector<uint64_t> offsets(nj);
+    uint64_t packed = 0;
+    for (size_t k = 0; k < nj && rc == FUIFGPU_OK; k++) {
+        if (states[8 * k + 5]) rc = FUIFGPU_E_NOMEM;
+        offsets[k] = packed;
+        packed += states[8 * k + 4];
     }
+    if (rc == FUIFGPU_OK && packed) {
+        uint8_t *d_packed = nullptr;
+        if (hipMalloc((void **)&d_packed, packed) != hipSuccess) rc = FUIFGPU_E_HIP;
+        ECHK(hipMemcpy(arena + off_offsets, offsets.data(), sizeof(uint64_t) * nj, hipMemcpyHostToDevice));
+        if (rc == FUIFGPU_OK) {
+            hipLaunchKernelGGL(k_enc_gather, dim3((unsigned)nj), dim3(256), 0, nullptr, d_jobs, reinterpret_cast<const uint64_t *>(arena + off_offsets), d_packed);
+            ECHK(hipGetLastError());
+        }
+        std::vector<uint8_t> all(packed);
+        ECHK(hipMemcpy(all.data(), d_packed, packed, hipMemcpyDeviceToHost));
+        if (rc == FUIFGPU_OK)
+            for (size_t k = 0; k < nj; k++) jobs[k].body.assign(all.begin() + offsets[k], all.begin() + offsets[k] + states[8 * k + 4]);
+        hipFree(d_packed);
+    }
+    for (size_t k = 0; k < nj && rc == FUIFGPU_OK; k++)
+        jobs[k].state = RacEncState{states[8 * k], states[8 * k + 1], (int32_t)states[8 * k + 2], (int32_t)states[8 * k + 3]};
 #undef ECHK
     hipFree(arena);
     return rc;
