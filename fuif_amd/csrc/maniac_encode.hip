@@ -20,8 +20,10 @@
 // (maniac_encode_group_gpu: one group per launch pair, synchronous) is slower than on a CPU core; the point of the design is the
 // batch: maniac_encode_jobs_gpu runs one wavefront per group over many pictures, as k_maniac_decode does.  Parity of the
 // single-group kernels was checked on the MI355X (profiles/r3_gpu_encoder_tests.txt); the job-list kernels share their device code
-// and are emulator-verified; nothing was timed in round 3.  Known cost: leaf chances live in global memory (a dependent read
-// and a write per binary decision) -- the decoder's "current leaf in a register" is the obvious next step.
+// and are emulator-verified; nothing was timed in round 3.  The single-group coder keeps leaf chances in global memory (a
+// dependent read and a write per binary decision, by lane 0); the batch coder (enc_rac_run_wave) runs the scalar code on the whole
+// wavefront and keeps the current leaf in a register with the next one prefetched, as the decoder does.  Its 16 KB chance table in
+// LDS limits a CU to 9 such wavefronts: the first thing to look at once it can be timed.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -216,10 +218,129 @@ __global__ __launch_bounds__(64) void k_enc_rac(const int32_t *plane, const int3
                                                 uint16_t *leaves, const uint16_t *table_g, uint32_t *state, uint8_t *out, uint32_t out_cap) {
     enc_rac_run(plane, guess, leafidx, n, minval, maxval, leaves, table_g, state, out, out_cap);
 }
+// ---- the coder as the batch runs it: the whole wavefront executes the scalar code (uniform control flow, scalars made uniform with
+// readfirstlane), so the lanes can hold state: lane i (< 31) keeps chance i of the CURRENT leaf in a register, as k_maniac_decode
+// does.  A binary decision reads its chance with v_readlane and updates one lane; memory is touched only when the leaf changes
+// (31 lanes store the old one, load the new one: two 62-byte accesses per switch instead of a dependent global read and a write
+// per decision) -- and because the encoder knows the NEXT pixel's leaf already, that load is issued one symbol early.
+// A lane's own earlier store to the same leaf is seen by its later load (single-thread order), the current leaf is never the
+// prefetched one.
+namespace {
+DEV int e_rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+struct WaveRac {   // DevRac with uniform state in every lane; only lane 0 stores bytes
+    uint32_t range, low;
+    int32_t delayed, pending;
+    uint8_t *out;
+    uint32_t cap, count;
+    int lane;
+    DEV void emit(int b) { if (lane == 0 && count < cap) out[count] = (uint8_t)b; count++; }
+    DEV void shift() {
+        const uint32_t byte = low >> 16;
+        if (delayed < 0) delayed = (int32_t)byte;
+        else if (byte < 0xFF) { emit(delayed); for (; pending; pending--) emit(0xFF); delayed = (int32_t)byte; }
+        else if (byte > 0xFF) { emit(delayed + 1); for (; pending; pending--) emit(0x00); delayed = (int32_t)(byte & 0xFF); }
+        else pending++;
+        low = (low & 0xFFFF) << 8;
+        range <<= 8;
+    }
+    DEV void put12(uint32_t b12, int bit) {
+        const uint32_t chance = (((range & 0xFFFu) * b12 + 0x800u) >> 12) + ((range >> 12) * b12);
+        if (bit) { low += range - chance; range = chance; }
+        else range -= chance;
+        for (int k = 0; k < 4 && range <= 0x10000u; k++) shift();
+    }
+};
+
+DEV void wave_coder_write(WaveRac &r, int &leafv, int idx, const uint16_t *table, int bit) {
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane(leafv, idx) & 0xFFFFu;
+    r.put12(c, bit);
+    const int nc = (int)table[c * 2 + bit];   // chance.h:77-79 (every lane reads the same LDS word)
+    if (r.lane == idx) leafv = nc;
+}
+
+// write side of symbol.h:154-185, uniform over the wavefront
+DEV void wave_write_symbol(WaveRac &r, int &leafv, const uint16_t *table, int min, int max, int value) {
+    if (value == 0) { wave_coder_write(r, leafv, CH_ZERO, table, 1); return; }
+    wave_coder_write(r, leafv, CH_ZERO, table, 0);
+    const int sign = value > 0;
+    if (min < 0 && max > 0) wave_coder_write(r, leafv, CH_SIGN, table, sign);
+    const int a = e_iabs(value);
+    const int e = e_ilog2((uint32_t)a);
+    const int amax = sign ? max : -min;
+    const int emax = e_ilog2((uint32_t)amax);
+    for (int i = 0; i < emax; i++) {
+        wave_coder_write(r, leafv, CH_EXP + i, table, i == e);
+        if (i == e) break;
+    }
+    int have = 1 << e;
+    for (int pos = e; pos > 0;) {
+        pos--;
+        const int minabs1 = have | (1 << pos);
+        if (minabs1 > amax) continue;
+        const int bit = (a >> pos) & 1;
+        wave_coder_write(r, leafv, CH_MANT + pos, table, bit);
+        if (bit) have = minabs1;
+    }
+}
+
+DEV void enc_rac_run_wave(const int32_t *plane, const int32_t *guess, const int32_t *leafidx, int64_t n, int minval, int maxval, uint16_t *leaves,
+                          const uint16_t *table_g, uint32_t *state, uint8_t *out, uint32_t out_cap) {
+    __shared__ uint16_t table[8192];
+    __shared__ int32_t s_diff[64], s_min[64], s_max[64], s_leaf[64];
+    const int lane = threadIdx.x;
+    for (int k = lane; k < 8192; k += 64) table[k] = table_g[k];
+    WaveRac r;
+    r.range = (uint32_t)e_rfl((int)state[0]); r.low = (uint32_t)e_rfl((int)state[1]); r.delayed = e_rfl((int)state[2]); r.pending = e_rfl((int)state[3]);
+    r.out = out; r.cap = out_cap; r.count = 0; r.lane = lane;
+    int cur = -1, leafv = 0;         // the current leaf and, in lane i < 31, its chance i
+    int pre = -1, prev = 0;          // a prefetched leaf (its number, its chances)
+    __syncthreads();
+    for (int64_t x0 = 0; x0 < n; x0 += 64) {
+        const int nx = (int)(n - x0 < 64 ? n - x0 : 64);
+        if (lane < nx) {
+            const int gs = guess[x0 + lane];
+            s_diff[lane] = plane[x0 + lane] - gs;
+            s_min[lane] = minval - gs;
+            s_max[lane] = maxval - gs;
+            s_leaf[lane] = leafidx[x0 + lane];
+        }
+        __syncthreads();
+        for (int j = 0; j < nx; j++) {
+            const int mn = e_rfl(s_min[j]), mx = e_rfl(s_max[j]);
+            if (mn == mx) continue;   // compound.h:228: nothing to code
+            const int lf = e_rfl(s_leaf[j]);
+            if (lf != cur) {
+                if (cur >= 0 && lane < CH_N) leaves[(int64_t)cur * CH_N + lane] = (uint16_t)leafv;
+                if (lf == pre) leafv = prev;
+                else if (lane < CH_N) leafv = leaves[(int64_t)lf * CH_N + lane];
+                cur = lf;
+                pre = -1;
+            }
+            // the next pixel's leaf is known already: fetch its chances while this symbol is coded
+            if (j + 1 < nx) {
+                const int nl = e_rfl(s_leaf[j + 1]);
+                if (nl != cur && nl != pre) {
+                    if (lane < CH_N) prev = leaves[(int64_t)nl * CH_N + lane];
+                    pre = nl;
+                }
+            }
+            wave_write_symbol(r, leafv, table, mn, mx, e_rfl(s_diff[j]));
+        }
+        __syncthreads();
+    }
+    if (cur >= 0 && lane < CH_N) leaves[(int64_t)cur * CH_N + lane] = (uint16_t)leafv;
+    if (lane == 0) {
+        state[0] = r.range; state[1] = r.low; state[2] = (uint32_t)r.delayed; state[3] = (uint32_t)r.pending;
+        state[4] = r.count; state[5] = r.count > r.cap ? 1u : 0u;
+    }
+}
+}  // namespace
+
 // one wavefront per job: the groups of a whole batch of pictures code side by side, as k_maniac_decode's tiles decode
 __global__ __launch_bounds__(64) void k_enc_rac_jobs(const EncJobDev *jobs, const uint16_t *table_g) {
     const EncJobDev &j = jobs[blockIdx.x];
-    enc_rac_run(j.g.plane, j.guess, j.leaf, j.n, j.g.minval, j.g.maxval, j.leaves, table_g, j.state, j.out, j.out_cap);
+    enc_rac_run_wave(j.g.plane, j.guess, j.leaf, j.n, j.g.minval, j.g.maxval, j.leaves, table_g, j.state, j.out, j.out_cap);
 }
 
 // ---------------------------------------------------------------------------------------------
