@@ -189,7 +189,7 @@ static inline int coder_read(fo_rac *r, uint16_t *ch, const uint16_t *table) {
 }
 
 static int g_stats;
-static struct fo_stats_s { uint64_t sym, walked, steps, predepth, same_leaf, zero, nsign, edec, mdec, ehist[16], prehist[24]; } g_st;
+static struct fo_stats_s { uint64_t sym, walked, steps, predepth, same_leaf, zero, nsign, edec, mdec, ehist[16], prehist[24], spec_exits, spec_inner, spec_hist[6]; } g_st;
 /* maniac/symbol.h:154-185 reader<bits>(coder,min,max) */
 static int read_symbol(fo_rac *r, uint16_t *ch, const uint16_t *table, int min, int max) {
     if (min == max) return min;
@@ -715,6 +715,19 @@ static int corrupt_or_truncated(fo_io *io, fo_channel *c, size_t btl) {
     return 0;
 }
 
+/* FO_STATS: the walk of a pixel whose left neighbour is not decoded yet -- nodes that test a left-dependent property fork; how
+ * many exits of the 6-level root supernode stay reachable (leaves above level 6 count as exits), and how many of them are inner
+ * nodes (= a second-level supernode would have to be fetched) */
+static int fo_left_dependent(int kl, int y) { return kl == 1 || kl == 3 || kl == 12 || (y ? (kl == 6 || kl == 8) : (kl == 7 || kl == 9)); }
+static void fo_spec_walk(const fo_node *n, int pos, int depth, const int32_t *props, int nref, int y, int *exits, int *inner) {
+    if (n[pos].property == -1) { (*exits)++; return; }
+    if (depth == 6) { (*exits)++; (*inner)++; return; }
+    if (fo_left_dependent(n[pos].property - nref, y)) {
+        fo_spec_walk(n, n[pos].childID, depth + 1, props, nref, y, exits, inner);
+        fo_spec_walk(n, n[pos].childID + 1, depth + 1, props, nref, y, exits, inner);
+    } else fo_spec_walk(n, props[n[pos].property] > n[pos].splitval ? n[pos].childID : n[pos].childID + 1, depth + 1, props, nref, y, exits, inner);
+}
+
 /* optional per-group stream statistics (FO_STATS=1, printed to stderr): what the HIP kernel's per-symbol phases see
  * (walk depth, depth of the first left-dependent test, leaf repeats, exponent lengths); not part of the decode semantics */
 /* (g_stats / g_st are declared next to read_symbol) */
@@ -960,6 +973,10 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
                             else pos = tree.n[pos].childID + 1;
                         }
                         if (g_stats > 0) {
+                            int se = 0, si = 0;
+                            fo_spec_walk(tree.n, 0, 0, props, nref, y, &se, &si);
+                            g_st.spec_exits += se; g_st.spec_inner += si;
+                            g_st.spec_hist[se <= 1 ? 0 : se == 2 ? 1 : se <= 4 ? 2 : se <= 8 ? 3 : se <= 16 ? 4 : 5]++;
                             if (pre < 0) pre = depth;
                             g_st.walked++; g_st.steps += depth; g_st.predepth += pre; g_st.prehist[pre > 23 ? 23 : pre]++;
                             if ((int)tree.n[pos].childID == st_prev_leaf) g_st.same_leaf++;
@@ -988,6 +1005,9 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
         for (int k = 0; k < 12; k++) fprintf(stderr, " %.3f", g_st.walked ? (double)g_st.ehist[k] / g_st.walked : 0.0);
         fprintf(stderr, "\n  prehist");
         for (int k = 0; k < 16; k++) fprintf(stderr, " %.3f", g_st.walked ? (double)g_st.prehist[k] / g_st.walked : 0.0);
+        fprintf(stderr, "\n  spec: reachable root exits %.2f (inner %.2f) per walk; 1 / 2 / 3-4 / 5-8 / 9-16 / more:", g_st.walked ? (double)g_st.spec_exits / g_st.walked : 0.0,
+                g_st.walked ? (double)g_st.spec_inner / g_st.walked : 0.0);
+        for (int k = 0; k < 6; k++) fprintf(stderr, " %.3f", g_st.walked ? (double)g_st.spec_hist[k] / g_st.walked : 0.0);
         fprintf(stderr, "\n");
     }
     img->stat_rac_decisions += rac.decisions;
