@@ -200,6 +200,36 @@ DEV uint2 global_load_node(const void *p) {
 }
 #endif
 
+#ifdef FUIF_SPEC_WALK
+// -DFUIF_SPEC_WALK (experiment, not the release build): the two LDS supernode slots of the dense configuration hold
+// SPECULATIVELY FETCHED second-level supernodes instead of the first two in breadth-first order (which 0.9 % of the walks
+// enter, profiles/r2_walk_locality.txt).  While pixel x is decoded, the root round of pixel x+1 is evaluated on the properties
+// that do not depend on x; every node that tests a left-dependent property is taken both ways, and the (up to two) second-level
+// supernodes that stay reachable are moved into the slots by LDS-DMA (global_load_lds_dwordx4: 32 lanes x 16 bytes, no
+// registers, nothing waited for).  The real walk of x+1 then finds its supernode in LDS for most symbols of the large groups
+// (1.9-2.0 reachable exits on average, profiles/r3_first_left_dependent_test.txt) and the supernode fetch leaves the
+// per-symbol dependency chain.  M0 and EXEC are restored inside the statement (see the leaf-slot experiment of round 3 for why
+// this is inline asm and not __builtin_amdgcn_global_load_lds).
+#ifdef FUIF_EMU
+DEV void dma_supernode(const uint2 *snodes, uint32_t sn, uint32_t lds_byte_addr, int lane) {
+    if (lane < 32) memcpy(const_cast<char *>(emu_lds_base) + lds_byte_addr + 16 * lane, reinterpret_cast<const char *>(snodes) + (size_t)sn * 512 + 16 * lane, 16);
+}
+DEV void wait_dma() {}
+#else
+DEV void dma_supernode(const uint2 *snodes, uint32_t sn, uint32_t lds_byte_addr, int lane) {
+    uint32_t keep_m0;
+    unsigned long long keep_exec;
+    const uint32_t voff = sn * 512u + (uint32_t)lane * 16u;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\t"
+                 "s_mov_b64 %1, exec\n\ts_mov_b64 exec, 0xffffffff\n\t"
+                 "global_load_lds_dwordx4 %2, %3\n\t"
+                 "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep_m0), "=&s"(keep_exec) : "v"(voff), "s"(snodes), "s"(lds_byte_addr) : "memory");
+}
+DEV void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+#endif
+
 struct Frame {  // one pending inner node of the pre-order tree parse
     int32_t p, oldmin, oldmax, splitval, child, stage;
 };
@@ -678,6 +708,11 @@ template <int kLdsSuper, bool kHandOff>
 __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParams P) {
     __shared__ Shared<kLdsSuper> sh;
     constexpr int kChunk = Shared<kLdsSuper>::kChunk;
+#ifdef FUIF_SPEC_WALK
+    constexpr bool kSpec = (kLdsSuper == kLdsDense);   // the dense configuration's two LDS slots hold speculatively fetched supernodes
+#else
+    constexpr bool kSpec = false;
+#endif
     const int lane = threadIdx.x;
 
     const uint16_t *tree_table = P.tables;          // cut 2, alpha 0xFFFFFFFF/19 (compound.h:262)
@@ -1110,10 +1145,11 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         int predictability = 2048;
         Rac rac;
         int tree_size = 1, n_super = 1, cur_leaf = 0;
+        uint32_t pf_tag0 = 0, pf_tag1 = 0, pf_victim = 0;   // FUIF_SPEC_WALK: which supernodes the two LDS slots hold (0 = none), which slot goes next
         if (resumed) {
             rac.range = rflu(rec->range); rac.low = rflu(rec->low);
             tree_size = rfl((int)rec->tree_size); n_super = rfl((int)rec->n_super); cur_leaf = rfl((int)rec->cur_leaf);
-            for (int sn = 1; sn <= kLdsSuper && sn < n_super; sn++) sh.snodes[(sn - 1) * 64 + lane] = snodes_g[(size_t)sn * 64 + lane];
+            if (!kSpec) for (int sn = 1; sn <= kLdsSuper && sn < n_super; sn++) sh.snodes[(sn - 1) * 64 + lane] = snodes_g[(size_t)sn * 64 + lane];
             __syncthreads();
         }
         if (!resumed) {
@@ -1337,7 +1373,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 out.x = (uint32_t)(is_raw_slog_prop(st_prop[lane] - nrefprops) && st_split[lane] != 0x7FFFFFFF ? slog_threshold(st_split[lane]) : st_split[lane]);
                 out.y = ((uint32_t)st_prop[lane] & 0xFFu) | (tgt << 8);
                 snodes_g[(size_t)sn * 64 + lane] = out;
-                if (sn >= 1 && sn <= kLdsSuper) sh.snodes[(sn - 1) * 64 + lane] = out;   // the root (0) lives in registers: LDS holds 1..kLdsSuper
+                if (!kSpec && sn >= 1 && sn <= kLdsSuper) sh.snodes[(sn - 1) * 64 + lane] = out;   // the root (0) lives in registers: LDS holds 1..kLdsSuper
                 __syncthreads();
             }
         }
@@ -1459,6 +1495,12 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                         const bool f_abs = (kloc == 1);
                         const int c_left = ((kloc == 1) | (kloc == 3) | (kloc == 12) | (y ? ((kloc == 6) | (kloc == 8)) : ((kloc == 7) | (kloc == 9)))) ? 1 : 0;
                         const int c_ll = (kloc == 12) ? -1 : 0;
+                        uint32_t unk_lo = 0, unk_hi = 0;   // FUIF_SPEC_WALK: the root supernode's nodes that test a left-dependent property (in this row)
+                        if (kSpec) {
+                            const int dn = __builtin_amdgcn_ds_bpermute((int)((root_nd.y & 0xFFu) << 2), (c_left | (c_ll != 0)) ? 1 : 0);
+                            const unsigned long long u = __ballot(dn != 0);
+                            unk_lo = (uint32_t)u; unk_hi = (uint32_t)(u >> 32);
+                        }
                         for (int x0 = 0; x0 < w; x0 += kChunk) {
                             const int nx = min(kChunk, w - x0);
                             // ---- vector phase: lane j prepares pixel x0+j ------------------------
@@ -1541,13 +1583,24 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                     uint32_t tgt = walk_round(root_nd);
                                     EMU_COUNT(0);
                                     while (!(tgt & (kLeafFlag | kSlowFlag))) {
-                                        EMU_COUNT(tgt <= (uint32_t)kLdsSuper ? 1 : 2);
+                                        if (!kSpec) EMU_COUNT(tgt <= (uint32_t)kLdsSuper ? 1 : 2);
                                         // LDS-resident supernodes are the common case; the load is issued unconditionally
                                         // (index clamped) and replaced in the rare deep case
                                         // (supernode i sits in LDS slot i-1: the -512 folds into the base address)
+                                        uint2 nd;
+#ifdef FUIF_SPEC_WALK
+                                        if (kSpec) {
+                                            // a slot holds this supernode if the speculative walk of the previous pixel fetched it
+                                            const bool h0 = tgt == pf_tag0, h1 = tgt == pf_tag1;
+                                            if (h0 | h1) { wait_dma(); nd = lds_load_node(lds_nodes_addr + (h0 ? 0u : 512u) + (uint32_t)lane * 8u); EMU_COUNT(1); }
+                                            else { nd = global_load_node(&snodes_g[(size_t)tgt * 64 + lane]); EMU_COUNT(2); }
+                                        } else
+#endif
+                                        {
                                         const uint32_t li = tgt <= (uint32_t)kLdsSuper ? tgt : (uint32_t)kLdsSuper;
-                                        uint2 nd = lds_load_node(lds_nodes_addr + (li - 1u) * 512u + (uint32_t)lane * 8u);
+                                        nd = lds_load_node(lds_nodes_addr + (li - 1u) * 512u + (uint32_t)lane * 8u);
                                         if (UNLIKELY(tgt > (uint32_t)kLdsSuper)) nd = global_load_node(&snodes_g[(size_t)tgt * 64 + lane]);
+                                        }
                                         tgt = walk_round(nd);
                                     }
                                     if (UNLIKELY(tgt & kSlowFlag)) {
@@ -1572,6 +1625,30 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                     prof_acc[7] += (unsigned)rdlane(L.leafv, 0) & 0u;  // force the leaf load to complete inside this lap
 #endif
                                     PROF_LAP(3);
+#ifdef FUIF_SPEC_WALK
+                                    if (kSpec && j + 1 < nx) {
+                                        // root round of pixel j+1 on the properties that do not depend on pixel j; unknown nodes go both ways
+                                        const int pvn = sh.cprops[(j + 1) * kPropPitch + (lane & 31)];
+                                        const int valn = __builtin_amdgcn_ds_bpermute((int)((root_nd.y & 0xFFu) << 2), pvn);
+                                        const unsigned long long mm = __ballot(valn > (int)root_nd.x);
+                                        const uint32_t klo = (uint32_t)mm, khi = (uint32_t)(mm >> 32);
+                                        const bool reach = ((((klo ^ exp_lo) & msk_lo & ~unk_lo) | ((khi ^ exp_hi) & msk_hi & ~unk_hi)) == 0u);
+                                        unsigned long long cand = __ballot(reach);
+#pragma unroll
+                                        for (int k = 0; k < 2; k++) {
+                                            if (cand) {
+                                                const int e = __builtin_ctzll(cand);
+                                                cand &= cand - 1;
+                                                const uint32_t t = (uint32_t)rdlane((int)root_nd.y, e) >> 8;
+                                                if (!(t & (kLeafFlag | kSlowFlag)) && t != pf_tag0 && t != pf_tag1) {
+                                                    dma_supernode(snodes_g, t, lds_nodes_addr + pf_victim * 512u, lane);
+                                                    if (pf_victim) pf_tag1 = t; else pf_tag0 = t;
+                                                    pf_victim ^= 1u;
+                                                }
+                                            }
+                                        }
+                                    }
+#endif
                                     if (PRED0 && sym_fast && LIKELY(s.pos + 64u <= s.size)) {
                                         // the symbol's bytes (at most 62) are in the stream; keep them in the window registers
                                         // (the reload starts at a 4-byte boundary; the 256 bytes it reads lie inside the allocation)

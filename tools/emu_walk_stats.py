@@ -2,7 +2,10 @@
 """Where do the tree-walk rounds behind the root supernode get their supernode from -- LDS or scratch memory?
 Emulator builds count it (fuifgpu_emu_walk_stats).  Used to judge supernode numbering schemes without a GPU:
 
-  FUIF_AMD_LIB=<emulated library> python tools/emu_walk_stats.py [w h]"""
+  FUIF_AMD_LIB=<emulated library> python tools/emu_walk_stats.py [w h] [--deep]
+
+With a -DFUIF_SPEC_WALK build of the emulated library "from LDS" means: found in a slot the speculative walk of the previous pixel
+had filled."""
 import ctypes as C
 import os
 import sys
@@ -15,9 +18,11 @@ sys.path.insert(0, ROOT)
 import fuif_amd  # noqa: E402
 from fuif_amd.synth import photographic  # noqa: E402
 
-w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (640, 360)
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+w, h = (int(argv[0]), int(argv[1])) if len(argv) > 1 else (640, 360)
+split = 2 if "--deep" in sys.argv else None    # --deep: a split only has to save 2 bits, so that small pictures get trees of several supernode levels
 img = photographic(w, h, 3, 8, seed=1000)
-blob = fuif_amd.encode_image(img, 8, tree_mode=1, index=True)
+blob = fuif_amd.encode_image(img, 8, tree_mode=1, index=True, split_bits=split)
 L = fuif_amd.lib()
 st = (C.c_ulonglong * 4)()
 for parallel, name in ((False, "wide  (58 supernodes in LDS, one tile per image)"), (True, "dense ( 2 supernodes in LDS, one tile per group)")):

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Round 4, experiment prepared at the end of round 3 (no GPU minutes were left to run it): the speculative early walk,
+# -DFUIF_SPEC_WALK (fuif_amd/csrc/maniac_decode.hip; profiles/r3_first_left_dependent_test.txt).
+# The release kernel is bit-identical with and without the macro's code in the source (checked on the ISA); the variant is
+# parity-green on the wavefront emulator and served 50.7 % of the walk rounds behind the root from LDS there (24.4 % with the
+# static residents) on a deep-tree picture.  What is NOT known: whether it is faster.
+#   gpurun --timeout 600 -- bash tools/experiments/r4_1_spec_walk.sh
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $ROOT
+OUT=gpurun_out/r4_spec_walk
+mkdir -p $OUT
+[ -f build/libfuifgpu_spec.so ] || bash tools/build_variant.sh spec -DFUIF_SPEC_WALK
+{
+for lib in fuif_amd/libfuifgpu.so build/libfuifgpu_spec.so; do
+  FUIF_AMD_LIB=$ROOT/$lib timeout 120 python tools/time_decode.py 128 3840 2160 --reps 2 --check
+  FUIF_AMD_LIB=$ROOT/$lib timeout 200 python tools/time_decode.py 1024 3840 2160 --reps 3 --check
+done
+FUIF_AMD_LIB=$ROOT/build/libfuifgpu_spec.so timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_group_parallel.py -m gpu -x -q
+} 2>&1 | grep -v amdgpu | tee $OUT/times.txt
