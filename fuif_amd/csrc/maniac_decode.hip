@@ -1626,7 +1626,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
 #endif
                                     PROF_LAP(3);
 #ifdef FUIF_SPEC_WALK
-                                    if (kSpec && j + 1 < nx) {
+                                    if (kSpec && n_super > 1 && j + 1 < nx) {   // (a tree that fits the root supernode has nothing to fetch)
                                         // root round of pixel j+1 on the properties that do not depend on pixel j; unknown nodes go both ways
                                         const int pvn = sh.cprops[(j + 1) * kPropPitch + (lane & 31)];
                                         const int valn = __builtin_amdgcn_ds_bpermute((int)((root_nd.y & 0xFFu) << 2), pvn);
