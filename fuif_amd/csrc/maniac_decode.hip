@@ -220,7 +220,7 @@ DEV void dma_supernode(const uint2 *snodes, uint32_t sn, uint32_t lds_byte_addr,
     uint32_t keep_m0;
     unsigned long long keep_exec;
     const uint32_t voff = sn * 512u + (uint32_t)lane * 16u;
-    const unsigned long long lower32 = 0xFFFFFFFFull;   // an SGPR pair, not a literal: `s_mov_b64 exec, 0xffffffff` may assemble to the inline constant -1 = all 64 lanes
+    unsigned long long lower32 = 0xFFFFFFFFull;   // an SGPR pair, not a literal: `s_mov_b64 exec, 0xffffffff` may assemble to the inline constant -1 = all 64 lanes
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\t"
                  "s_mov_b64 %1, exec\n\ts_mov_b64 exec, %5\n\t"
                  "global_load_lds_dwordx4 %2, %3\n\t"
