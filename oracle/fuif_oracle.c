@@ -189,7 +189,7 @@ static inline int coder_read(fo_rac *r, uint16_t *ch, const uint16_t *table) {
 }
 
 static int g_stats;
-static struct fo_stats_s { uint64_t sym, walked, steps, predepth, same_leaf, zero, nsign, edec, mdec, ehist[16], prehist[24], spec_exits, spec_inner, spec_hist[6]; } g_st;
+static struct fo_stats_s { uint64_t sym, walked, steps, predepth, same_leaf, zero, nsign, edec, mdec, ehist[16], prehist[24], spec_exits, spec_inner, spec_hist[6], spec_round2, spec_hit; } g_st;
 /* maniac/symbol.h:154-185 reader<bits>(coder,min,max) */
 static int read_symbol(fo_rac *r, uint16_t *ch, const uint16_t *table, int min, int max) {
     if (min == max) return min;
@@ -728,6 +728,18 @@ static void fo_spec_walk(const fo_node *n, int pos, int depth, const int32_t *pr
     } else fo_spec_walk(n, props[n[pos].property] > n[pos].splitval ? n[pos].childID : n[pos].childID + 1, depth + 1, props, nref, y, exits, inner);
 }
 
+/* the -DFUIF_SPEC_WALK policy of the HIP kernel, simulated: the inner exits reachable with an unknown left neighbour, in the order
+ * the kernel takes them (exit lanes ascending = the "<=" branch first); the first two that are not in a slot yet go to the two LDS
+ * slots alternately; the first pixel of a 32-pixel chunk is not speculated for */
+static void fo_spec_list(const fo_node *n, int pos, int depth, const int32_t *props, int nref, int y, int *list, int *cnt, int cap) {
+    if (n[pos].property == -1) return;
+    if (depth == 6) { if (*cnt < cap) list[(*cnt)++] = pos; return; }
+    if (fo_left_dependent(n[pos].property - nref, y)) {
+        fo_spec_list(n, n[pos].childID + 1, depth + 1, props, nref, y, list, cnt, cap);
+        fo_spec_list(n, n[pos].childID, depth + 1, props, nref, y, list, cnt, cap);
+    } else fo_spec_list(n, props[n[pos].property] > n[pos].splitval ? n[pos].childID : n[pos].childID + 1, depth + 1, props, nref, y, list, cnt, cap);
+}
+
 /* optional per-group stream statistics (FO_STATS=1, printed to stderr): what the HIP kernel's per-symbol phases see
  * (walk depth, depth of the first left-dependent test, leaf repeats, exponent lengths); not part of the decode semantics */
 /* (g_stats / g_st are declared next to read_symbol) */
@@ -920,6 +932,7 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
     if (g_leafsim < 0) g_leafsim = getenv("FO_LEAFSIM") ? 1 : 0;
     if (g_stats <= 0 && g_stats != -2) g_stats = getenv("FO_STATS") ? 1 : -2;
     int st_prev_leaf = -1;
+    int st_tag[2] = {-1, -1}, st_victim = 0;
     if (g_stats > 0) memset(&g_st, 0, sizeof(g_st));
     const uint64_t st_dec0 = rac.decisions;
     int *ls_ids = NULL, ls_prev = -1;
@@ -961,7 +974,14 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
                         /* find_leaf: compound.h:142-153 */
                         int pos = 0;
                         int depth = 0, pre = -1;
+                        if (g_stats > 0 && (x & 31)) {   /* what the kernel fetched for this pixel while the previous one was decoded */
+                            int cl[4], cn = 0;
+                            fo_spec_list(tree.n, 0, 0, props, nref, y, cl, &cn, 2);
+                            for (int k = 0; k < cn; k++)
+                                if (cl[k] != st_tag[0] && cl[k] != st_tag[1]) { st_tag[st_victim] = cl[k]; st_victim ^= 1; }
+                        }
                         while (tree.n[pos].property != -1) {
+                            if (g_stats > 0 && depth == 6) { g_st.spec_round2++; if (pos == st_tag[0] || pos == st_tag[1]) g_st.spec_hit++; }
                             img->stat_tree_steps++;
                             if (g_stats > 0 && pre < 0) {
                                 const int kl = tree.n[pos].property - nref;  /* local properties that read `left` */
@@ -1008,7 +1028,8 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
         fprintf(stderr, "\n  spec: reachable root exits %.2f (inner %.2f) per walk; 1 / 2 / 3-4 / 5-8 / 9-16 / more:", g_st.walked ? (double)g_st.spec_exits / g_st.walked : 0.0,
                 g_st.walked ? (double)g_st.spec_inner / g_st.walked : 0.0);
         for (int k = 0; k < 6; k++) fprintf(stderr, " %.3f", g_st.walked ? (double)g_st.spec_hist[k] / g_st.walked : 0.0);
-        fprintf(stderr, "\n");
+        fprintf(stderr, "\n  spec policy (2 slots, first 2 candidates): %.3f second-level rounds per walk, %.1f %% of them found in a slot\n",
+                g_st.walked ? (double)g_st.spec_round2 / g_st.walked : 0.0, g_st.spec_round2 ? 100.0 * g_st.spec_hit / g_st.spec_round2 : 0.0);
     }
     img->stat_rac_decisions += rac.decisions;
     free(ls_ids); free(sn_rank); free(lf_slot); free(lf_root);
