@@ -189,7 +189,7 @@ static inline int coder_read(fo_rac *r, uint16_t *ch, const uint16_t *table) {
 }
 
 static int g_stats;
-static struct fo_stats_s { uint64_t sym, walked, steps, predepth, same_leaf, zero, nsign, edec, mdec, ehist[16], prehist[24], spec_exits, spec_inner, spec_hist[6], spec_round2, spec_hit; } g_st;
+static struct fo_stats_s { uint64_t sym, walked, steps, predepth, same_leaf, zero, nsign, edec, mdec, ehist[16], prehist[24], spec_exits, spec_inner, spec_hist[6], spec_round2, spec_hit, rounds_behind; } g_st;
 /* maniac/symbol.h:154-185 reader<bits>(coder,min,max) */
 static int read_symbol(fo_rac *r, uint16_t *ch, const uint16_t *table, int min, int max) {
     if (min == max) return min;
@@ -982,6 +982,7 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
                         }
                         while (tree.n[pos].property != -1) {
                             if (g_stats > 0 && depth == 6) { g_st.spec_round2++; if (pos == st_tag[0] || pos == st_tag[1]) g_st.spec_hit++; }
+                            if (g_stats > 0 && depth && depth % 6 == 0) g_st.rounds_behind++;
                             img->stat_tree_steps++;
                             if (g_stats > 0 && pre < 0) {
                                 const int kl = tree.n[pos].property - nref;  /* local properties that read `left` */
@@ -1028,8 +1029,9 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
         fprintf(stderr, "\n  spec: reachable root exits %.2f (inner %.2f) per walk; 1 / 2 / 3-4 / 5-8 / 9-16 / more:", g_st.walked ? (double)g_st.spec_exits / g_st.walked : 0.0,
                 g_st.walked ? (double)g_st.spec_inner / g_st.walked : 0.0);
         for (int k = 0; k < 6; k++) fprintf(stderr, " %.3f", g_st.walked ? (double)g_st.spec_hist[k] / g_st.walked : 0.0);
-        fprintf(stderr, "\n  spec policy (2 slots, first 2 candidates): %.3f second-level rounds per walk, %.1f %% of them found in a slot\n",
-                g_st.walked ? (double)g_st.spec_round2 / g_st.walked : 0.0, g_st.spec_round2 ? 100.0 * g_st.spec_hit / g_st.spec_round2 : 0.0);
+        fprintf(stderr, "\n  spec policy (2 slots, first 2 candidates): %.3f second-level rounds per walk, %.1f %% of them found in a slot; all rounds behind the root %llu, hits %llu\n",
+                g_st.walked ? (double)g_st.spec_round2 / g_st.walked : 0.0, g_st.spec_round2 ? 100.0 * g_st.spec_hit / g_st.spec_round2 : 0.0,
+                (unsigned long long)g_st.rounds_behind, (unsigned long long)g_st.spec_hit);
     }
     img->stat_rac_decisions += rac.decisions;
     free(ls_ids); free(sn_rank); free(lf_slot); free(lf_root);
