@@ -1497,6 +1497,15 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                         const int c_left = ((kloc == 1) | (kloc == 3) | (kloc == 12) | (y ? ((kloc == 6) | (kloc == 8)) : ((kloc == 7) | (kloc == 9)))) ? 1 : 0;
                         const int c_ll = (kloc == 12) ? -1 : 0;
                         uint32_t unk_lo = 0, unk_hi = 0;   // FUIF_SPEC_WALK: the root supernode's nodes that test a left-dependent property (in this row)
+                        bool spec_row = kSpec;
+#if defined(FUIF_SPEC_WALK) && (FUIF_SPEC_WALK + 0) >= 2
+                        // -DFUIF_SPEC_WALK=2: speculate only while this SIMD holds few wavefronts (the tail of a launch): with all six
+                        // resident the scalar pipe is the contended resource and the ~30 extra instructions per symbol are not free
+#ifndef FUIF_SPEC_MAX_ALIVE
+#define FUIF_SPEC_MAX_ALIVE 4
+#endif
+                        if (kSpec && P.cu_alive) spec_row = rflu(ld_agent(&P.cu_alive[simd_key])) <= (uint32_t)FUIF_SPEC_MAX_ALIVE;
+#endif
                         if (kSpec) {
                             const int dn = __builtin_amdgcn_ds_bpermute((int)((root_nd.y & 0xFFu) << 2), (c_left | (c_ll != 0)) ? 1 : 0);
                             const unsigned long long u = __ballot(dn != 0);
@@ -1627,7 +1636,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
 #endif
                                     PROF_LAP(3);
 #ifdef FUIF_SPEC_WALK
-                                    if (kSpec && n_super > 1 && j + 1 < nx) {   // (a tree that fits the root supernode has nothing to fetch)
+                                    if (kSpec && spec_row && n_super > 1 && j + 1 < nx) {   // (a tree that fits the root supernode has nothing to fetch)
                                         // root round of pixel j+1 on the properties that do not depend on pixel j; unknown nodes go both ways
                                         const int pvn = sh.cprops[(j + 1) * kPropPitch + (lane & 31)];
                                         const int valn = __builtin_amdgcn_ds_bpermute((int)((root_nd.y & 0xFFu) << 2), pvn);

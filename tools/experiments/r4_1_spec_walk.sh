@@ -11,8 +11,9 @@ cd $ROOT
 OUT=gpurun_out/r4_spec_walk
 mkdir -p $OUT
 [ -f build/libfuifgpu_spec.so ] || bash tools/build_variant.sh spec -DFUIF_SPEC_WALK
+[ -f build/libfuifgpu_spec2.so ] || bash tools/build_variant.sh spec2 -DFUIF_SPEC_WALK=2     # speculate only while <= 4 wavefronts are alive on the SIMD (the tail)
 {
-for lib in fuif_amd/libfuifgpu.so build/libfuifgpu_spec.so; do
+for lib in fuif_amd/libfuifgpu.so build/libfuifgpu_spec.so build/libfuifgpu_spec2.so; do
   FUIF_AMD_LIB=$ROOT/$lib timeout 120 python tools/time_decode.py 128 3840 2160 --reps 2 --check
   FUIF_AMD_LIB=$ROOT/$lib timeout 200 python tools/time_decode.py 1024 3840 2160 --reps 3 --check
 done
