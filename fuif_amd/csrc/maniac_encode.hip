@@ -110,10 +110,18 @@ DEV void enc_model_pixel(const EncGroup &g, const EncNode *tree, int n_nodes, in
 __global__ __launch_bounds__(256) void k_enc_model(EncGroup g, const EncNode *tree, int n_nodes, int32_t *guess_out, int32_t *leaf_out) {
     enc_model_pixel(g, tree, n_nodes, (int64_t)blockIdx.x * 256 + threadIdx.x, guess_out, leaf_out);
 }
-// the same for a list of groups (of many pictures) in one launch: blockIdx.y = job
-__global__ __launch_bounds__(256) void k_enc_model_jobs(const EncJobDev *jobs) {
-    const EncJobDev &j = jobs[blockIdx.y];
-    enc_model_pixel(j.g, j.tree, j.n_nodes, (int64_t)blockIdx.x * 256 + threadIdx.x, j.guess, j.leaf);
+// the same for a list of groups (of many pictures) in one launch: the blocks of all jobs are numbered through, first_block[k] is
+// the first block of job k (first_block[n_jobs] = all blocks), a block finds its job by bisection -- no empty blocks, whatever
+// the mix of group sizes (a 4K picture has groups of 40 and of 4 million pixels)
+__global__ __launch_bounds__(256) void k_enc_model_jobs(const EncJobDev *jobs, const uint32_t *first_block, int n_jobs) {
+    const uint32_t blk = blockIdx.x;
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {                       // the last job whose first block is <= blk
+        const int mid = (lo + hi + 1) >> 1;
+        if (first_block[mid] <= blk) lo = mid; else hi = mid - 1;
+    }
+    const EncJobDev &j = jobs[lo];
+    enc_model_pixel(j.g, j.tree, j.n_nodes, (int64_t)(blk - first_block[lo]) * 256 + threadIdx.x, j.guess, j.leaf);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -420,12 +428,11 @@ int maniac_encode_jobs_gpu(std::vector<EncJob> &jobs, const uint16_t *pixel_tabl
     // layout of the head: [EncJobDev x nj][table][states: 32 bytes x nj][per job: tree, leaves]; then per job: guess, leaf, out;
     // then the offsets and the packed bodies
     const size_t off_table = up(sizeof(EncJobDev) * nj), off_states = off_table + up(sizeof(uint16_t) * 8192);
-    size_t head = off_states + up(32 * nj), max_n = 0;
+    size_t head = off_states + up(32 * nj);
     std::vector<size_t> off_tree(nj), off_leaves(nj);
     for (size_t k = 0; k < nj; k++) {
         const EncJob &j = jobs[k];
         if (!j.g.plane || j.tree.empty() || j.n_leaves < 1 || j.g.w < 1 || j.g.h < 1 || j.g.nrefs < 0 || j.g.nrefs > kMaxRefs) return FUIFGPU_E_ARG;
-        max_n = std::max(max_n, (size_t)j.g.w * j.g.h);
         off_tree[k] = head; head += up(sizeof(EncNode) * j.tree.size());
         off_leaves[k] = head; head += up(sizeof(uint16_t) * CH_N * (size_t)j.n_leaves);
     }
@@ -441,6 +448,7 @@ int maniac_encode_jobs_gpu(std::vector<EncJob> &jobs, const uint16_t *pixel_tabl
         off_out[k] = total; total += up(cap[k]);
     }
     const size_t off_offsets = total; total += up(sizeof(uint64_t) * nj);
+    const size_t off_first = total; total += up(sizeof(uint32_t) * (nj + 1));
     uint8_t *arena = nullptr;
     if (hipMalloc((void **)&arena, total) != hipSuccess) return FUIFGPU_E_HIP;
     int rc = FUIFGPU_OK;
@@ -468,11 +476,14 @@ int maniac_encode_jobs_gpu(std::vector<EncJob> &jobs, const uint16_t *pixel_tabl
     const EncJobDev *d_jobs = reinterpret_cast<const EncJobDev *>(arena);
     const uint16_t *d_table = reinterpret_cast<const uint16_t *>(arena + off_table);
     if (rc == FUIFGPU_OK) {
-        // grid.y is limited to 65535: launch the jobs in slices
-        for (size_t j0 = 0; j0 < nj; j0 += 32768) {
-            const unsigned cnt = (unsigned)std::min<size_t>(32768, nj - j0);
-            hipLaunchKernelGGL(k_enc_model_jobs, dim3((unsigned)((max_n + 255) / 256), cnt), dim3(256), 0, nullptr, d_jobs + j0);
-        }
+        std::vector<uint32_t> first(nj + 1);
+        uint64_t blocks = 0;
+        for (size_t k = 0; k < nj; k++) { first[k] = (uint32_t)blocks; blocks += ((uint64_t)jobs[k].g.w * jobs[k].g.h + 255) / 256; }
+        first[nj] = (uint32_t)blocks;
+        if (blocks > 0x7FFFFFFFull) rc = FUIFGPU_E_ARG;   // > 5 * 10^11 pixels in one batch: split it
+        ECHK(hipMemcpy(arena + off_first, first.data(), sizeof(uint32_t) * (nj + 1), hipMemcpyHostToDevice));
+        if (rc == FUIFGPU_OK)
+            hipLaunchKernelGGL(k_enc_model_jobs, dim3((unsigned)blocks), dim3(256), 0, nullptr, d_jobs, reinterpret_cast<const uint32_t *>(arena + off_first), (int)nj);
         hipLaunchKernelGGL(k_enc_rac_jobs, dim3((unsigned)nj), dim3(64), 0, nullptr, d_jobs, d_table);
         ECHK(hipGetLastError());
     }
