@@ -238,6 +238,8 @@ int fuifgpu_encode_image(const int32_t *planes, int w, int h, int nch, int bit_d
  * context model of every pixel in parallel, one wavefront per group for the range coder (csrc/maniac_encode.hip; the way
  * k_maniac_decode runs one wavefront per group of a batch) -- and the host assembles the streams.  blobs_out[m] / sizes_out[m]
  * are what fuifgpu_encode_image writes for picture m, byte for byte (gpu_entropy is implied; opt NULL = CLI defaults).
+ * A picture in flight holds its channels on the host and on the device plus 12 bytes of coder scratch per sample (~0.5 GB per 4K
+ * RGB picture): the caller sizes its batches to the device (fuifgpu_dev_mem_info) and chunks larger sets.
  * Replaces N runs of the reference's `fuif_encode_file` (encoding/encoding.cpp:727-735). */
 int fuifgpu_encode_images(const int32_t *const *planes, int n_images, int w, int h, int nch, int bit_depth, const fuifgpu_encode_options *opt,
                           uint8_t **blobs_out, size_t *sizes_out);
