@@ -189,7 +189,7 @@ static inline int coder_read(fo_rac *r, uint16_t *ch, const uint16_t *table) {
 }
 
 static int g_stats;
-static struct fo_stats_s { uint64_t sym, walked, steps, predepth, same_leaf, zero, nsign, edec, mdec, ehist[16], prehist[24], spec_exits, spec_inner, spec_hist[6], spec_round2, spec_hit, rounds_behind; } g_st;
+static struct fo_stats_s { uint64_t sym, walked, steps, predepth, same_leaf, zero, nsign, edec, mdec, ehist[16], prehist[24], spec_exits, spec_inner, spec_hist[6], spec_round2, spec_hit, rounds_behind, leaf_sw, leaf_hit[3]; } g_st;
 /* maniac/symbol.h:154-185 reader<bits>(coder,min,max) */
 static int read_symbol(fo_rac *r, uint16_t *ch, const uint16_t *table, int min, int max) {
     if (min == max) return min;
@@ -740,6 +740,17 @@ static void fo_spec_list(const fo_node *n, int pos, int depth, const int32_t *pr
     } else fo_spec_list(n, props[n[pos].property] > n[pos].splitval ? n[pos].childID : n[pos].childID + 1, depth + 1, props, nref, y, list, cnt, cap);
 }
 
+/* second speculative step: the leaves reachable (unknown left) within the 6 levels below node `pos` -- what a speculative round on a
+ * supernode that is already in LDS could name, so that their chances can be fetched before the pixel's own walk gets there */
+static void fo_spec_leaves(const fo_node *n, int pos, int depth, int maxdepth, const int32_t *props, int nref, int y, int *list, int *cnt, int cap) {
+    if (n[pos].property == -1) { if (*cnt < cap) list[(*cnt)++] = n[pos].childID; return; }
+    if (depth == maxdepth) return;
+    if (fo_left_dependent(n[pos].property - nref, y)) {
+        fo_spec_leaves(n, n[pos].childID + 1, depth + 1, maxdepth, props, nref, y, list, cnt, cap);
+        fo_spec_leaves(n, n[pos].childID, depth + 1, maxdepth, props, nref, y, list, cnt, cap);
+    } else fo_spec_leaves(n, props[n[pos].property] > n[pos].splitval ? n[pos].childID : n[pos].childID + 1, depth + 1, maxdepth, props, nref, y, list, cnt, cap);
+}
+
 /* optional per-group stream statistics (FO_STATS=1, printed to stderr): what the HIP kernel's per-symbol phases see
  * (walk depth, depth of the first left-dependent test, leaf repeats, exponent lengths); not part of the decode semantics */
 /* (g_stats / g_st are declared next to read_symbol) */
@@ -933,6 +944,8 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
     if (g_stats <= 0 && g_stats != -2) g_stats = getenv("FO_STATS") ? 1 : -2;
     int st_prev_leaf = -1;
     int st_tag[2] = {-1, -1}, st_victim = 0;
+    int st_ltag[3][8], st_lvict[3] = {0, 0, 0};
+    for (int b = 0; b < 3; b++) for (int q = 0; q < 8; q++) st_ltag[b][q] = -1;
     if (g_stats > 0) memset(&g_st, 0, sizeof(g_st));
     const uint64_t st_dec0 = rac.decisions;
     int *ls_ids = NULL, ls_prev = -1;
@@ -979,6 +992,19 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
                             fo_spec_list(tree.n, 0, 0, props, nref, y, cl, &cn, 2);
                             for (int k = 0; k < cn; k++)
                                 if (cl[k] != st_tag[0] && cl[k] != st_tag[1]) { st_tag[st_victim] = cl[k]; st_victim ^= 1; }
+                            /* leaf speculation, three slot budgets (2 / 4 / 8 leaf slots, round robin): leaves that hang off the root supernode
+                             * and leaves below the (up to two) candidate second-level supernodes, first come first served */
+                            int ll[16], ln = 0;
+                            fo_spec_leaves(tree.n, 0, 0, 6, props, nref, y, ll, &ln, 8);
+                            for (int k = 0; k < cn && ln < 16; k++) fo_spec_leaves(tree.n, cl[k], 6, 12, props, nref, y, ll, &ln, ln + 4 > 16 ? 16 : ln + 4);
+                            for (int b = 0; b < 3; b++) {
+                                const int slots = 2 << b;
+                                for (int k = 0; k < ln && k < slots; k++) {
+                                    int have = 0;
+                                    for (int q = 0; q < slots; q++) if (st_ltag[b][q] == ll[k]) have = 1;
+                                    if (!have) { st_ltag[b][st_lvict[b]] = ll[k]; st_lvict[b] = (st_lvict[b] + 1) % slots; }
+                                }
+                            }
                         }
                         while (tree.n[pos].property != -1) {
                             if (g_stats > 0 && depth == 6) { g_st.spec_round2++; if (pos == st_tag[0] || pos == st_tag[1]) g_st.spec_hit++; }
@@ -992,6 +1018,10 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
                             depth++;
                             if (props[tree.n[pos].property] > tree.n[pos].splitval) pos = tree.n[pos].childID;
                             else pos = tree.n[pos].childID + 1;
+                        }
+                        if (g_stats > 0 && (int)tree.n[pos].childID != st_prev_leaf) {
+                            g_st.leaf_sw++;
+                            for (int b = 0; b < 3; b++) for (int q = 0; q < (2 << b); q++) if (st_ltag[b][q] == (int)tree.n[pos].childID) { g_st.leaf_hit[b]++; break; }
                         }
                         if (g_stats > 0) {
                             int se = 0, si = 0;
@@ -1032,6 +1062,9 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
         fprintf(stderr, "\n  spec policy (2 slots, first 2 candidates): %.3f second-level rounds per walk, %.1f %% of them found in a slot; all rounds behind the root %llu, hits %llu\n",
                 g_st.walked ? (double)g_st.spec_round2 / g_st.walked : 0.0, g_st.spec_round2 ? 100.0 * g_st.spec_hit / g_st.spec_round2 : 0.0,
                 (unsigned long long)g_st.rounds_behind, (unsigned long long)g_st.spec_hit);
+        fprintf(stderr, "  leaf speculation: %.3f leaf switches per walk; found among the speculated leaves with 2 / 4 / 8 slots: %.1f %% / %.1f %% / %.1f %%\n",
+                g_st.walked ? (double)g_st.leaf_sw / g_st.walked : 0.0, g_st.leaf_sw ? 100.0 * g_st.leaf_hit[0] / g_st.leaf_sw : 0.0,
+                g_st.leaf_sw ? 100.0 * g_st.leaf_hit[1] / g_st.leaf_sw : 0.0, g_st.leaf_sw ? 100.0 * g_st.leaf_hit[2] / g_st.leaf_sw : 0.0);
     }
     img->stat_rac_decisions += rac.decisions;
     free(ls_ids); free(sn_rank); free(lf_slot); free(lf_root);
