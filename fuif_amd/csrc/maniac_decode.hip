@@ -181,7 +181,7 @@ struct Node {  // maniac/compound.h:41-51; property -1 = leaf, child = leaf id
 // loads (it sinks the splitval load behind the leaf test), doubling the per-level latency.
 #ifdef FUIF_EMU
 // emulator-only statistics (tools/emu_walk_stats.py): where the walk rounds behind the root supernode are served from
-extern unsigned long long g_emu_stats[4];   // symbols with a walk, rounds from LDS, rounds from scratch memory, suspended tiles
+extern unsigned long long g_emu_stats[6];   // symbols with a walk, rounds from LDS, rounds from scratch memory, suspended tiles, (FUIF_SPEC_LEAF) leaf switches, of them served from a speculated LDS slot
 #define EMU_COUNT(k) do { if (lane == 0) __atomic_fetch_add(&g_emu_stats[k], 1ull, __ATOMIC_RELAXED); } while (0)
 static thread_local const char *emu_lds_base;   // LDS byte addresses are offsets from the supernode array in the emulator
 DEV uint2 lds_load_node(uint32_t lds_byte_addr) { return *reinterpret_cast<const uint2 *>(emu_lds_base + lds_byte_addr); }
@@ -220,6 +220,7 @@ DEV void dma_supernode(const uint2 *snodes, uint32_t sn, uint32_t lds_byte_addr,
     uint32_t keep_m0;
     unsigned long long keep_exec;
     const uint32_t voff = sn * 512u + (uint32_t)lane * 16u;
+    lds_byte_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_byte_addr);   // uniform, but the compiler cannot always see it: M0 needs an SGPR
     unsigned long long lower32 = 0xFFFFFFFFull;   // an SGPR pair, not a literal: `s_mov_b64 exec, 0xffffffff` may assemble to the inline constant -1 = all 64 lanes
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\t"
                  "s_mov_b64 %1, exec\n\ts_mov_b64 exec, %5\n\t"
@@ -228,6 +229,41 @@ DEV void dma_supernode(const uint2 *snodes, uint32_t sn, uint32_t lds_byte_addr,
                  : "=&s"(keep_m0), "=&s"(keep_exec) : "v"(voff), "s"(snodes), "s"(lds_byte_addr), "s"(lower32) : "memory");
 }
 DEV void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+#endif
+
+#ifdef FUIF_SPEC_LEAF
+// -DFUIF_SPEC_LEAF (experiment, not the release build; the WIDE configuration = streams without a group index, one wavefront per
+// image): there the second-level supernodes are resident in LDS, so while pixel x waits for ITS leaf the walk of pixel x+1 can
+// be carried two rounds deep on the properties that do not depend on x (unknown nodes taken both ways) and the chances of the
+// leaves it can end in are fetched into a few LDS leaf slots by LDS-DMA.  Simulated on the CPU restatement with the bench's tree
+// shapes: 43-58 % of the leaf switches find their leaf in one of four slots (profiles/r3_first_left_dependent_test.txt).
+// A copy is used at most once (a leaf changes only while it is the current one), is never taken of the current leaf nor of the
+// one whose write-back was just issued.
+constexpr int kSpecLeafSlots = 4;
+#ifdef FUIF_EMU
+DEV void dma_leaf(const uint16_t *leaves, uint32_t leaf, void *lds_slot, int lane) {
+    if (lane < 4) memcpy(static_cast<char *>(lds_slot) + 16 * lane, reinterpret_cast<const char *>(leaves) + (size_t)leaf * 64 + 16 * lane, 16);
+}
+#ifndef FUIF_SPEC_WALK
+DEV void wait_dma() {}
+#endif
+#else
+DEV void dma_leaf(const uint16_t *leaves, uint32_t leaf, void *lds_slot, int lane) {
+    uint32_t keep_m0;
+    unsigned long long keep_exec;
+    const uint32_t voff = leaf * 64u + (uint32_t)lane * 16u;
+    const uint32_t lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)lds_slot);   // uniform, but the compiler cannot see it: M0 needs an SGPR
+    unsigned long long four = 0xFull;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\t"
+                 "s_mov_b64 %1, exec\n\ts_mov_b64 exec, %5\n\t"
+                 "global_load_lds_dwordx4 %2, %3\n\t"
+                 "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep_m0), "=&s"(keep_exec) : "v"(voff), "s"(leaves), "s"(lds), "s"(four) : "memory");
+}
+#ifndef FUIF_SPEC_WALK
+DEV void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
 #endif
 #endif
 
@@ -686,6 +722,9 @@ struct Shared {
     uint16_t meta_ctx[3][32];            // three SimpleSymbolCoder contexts of the tree coder
     int32_t lo[kMaxProps], hi[kMaxProps];
     RefChan refs[kMaxRefs];
+#ifdef FUIF_SPEC_LEAF
+    uint16_t spec_leaf[kSpecLeafSlots * kLeafStride];   // speculatively fetched leaf chances (64 bytes each)
+#endif
 };
 
 // kHandOff = false: every image is one tile, nothing a tile writes is read by another one before the
@@ -709,6 +748,11 @@ template <int kLdsSuper, bool kHandOff>
 __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParams P) {
     __shared__ Shared<kLdsSuper> sh;
     constexpr int kChunk = Shared<kLdsSuper>::kChunk;
+#ifdef FUIF_SPEC_LEAF
+    constexpr bool kSpecLeaf = (kLdsSuper != kLdsDense);   // the wide configuration speculates on leaves
+#else
+    constexpr bool kSpecLeaf = false;
+#endif
 #ifdef FUIF_SPEC_WALK
     constexpr bool kSpec = (kLdsSuper == kLdsDense);   // the dense configuration's two LDS slots hold speculatively fetched supernodes
 #else
@@ -1146,6 +1190,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         int predictability = 2048;
         Rac rac;
         int tree_size = 1, n_super = 1, cur_leaf = 0;
+        uint32_t lf_t0 = 0xFFFFFFFFu, lf_t1 = 0xFFFFFFFFu, lf_t2 = 0xFFFFFFFFu, lf_t3 = 0xFFFFFFFFu, lf_victim = 0, lf_prev_wb = 0xFFFFFFFFu;   // FUIF_SPEC_LEAF: leaves in the LDS leaf slots, the leaf written back last
         uint32_t pf_tag0 = 0, pf_tag1 = 0, pf_victim = 0;   // FUIF_SPEC_WALK: which supernodes the two LDS slots hold (0 = none), which slot goes next
         if (resumed) {
             rac.range = rflu(rec->range); rac.low = rflu(rec->low);
@@ -1394,6 +1439,26 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         L.leafv = (lane < 32) ? (int)leaves[(int64_t)cur_leaf * kLeafStride + lane] : 0;
         L.touched = 0; L.bits = 0;
         auto switch_leaf = [&](int id) {
+#ifdef FUIF_SPEC_LEAF
+            if (kSpecLeaf) {
+                if (LIKELY(id != cur_leaf)) {
+                    EMU_COUNT(4);
+                    if (lane < 32) leaves[(int64_t)cur_leaf * kLeafStride + lane] = (uint16_t)L.leafv;
+                    lf_prev_wb = (uint32_t)cur_leaf;
+                    const uint32_t uid = (uint32_t)id;
+                    const int slot = uid == lf_t0 ? 0 : uid == lf_t1 ? 1 : uid == lf_t2 ? 2 : uid == lf_t3 ? 3 : -1;
+                    if (slot >= 0) {
+                        // the copy was fetched after the leaf's last write-back and the leaf has not been current since: use it once
+                        wait_dma();
+                        if (lane < 32) L.leafv = (int)sh.spec_leaf[slot * kLeafStride + lane];
+                        if (slot == 0) lf_t0 = 0xFFFFFFFFu; else if (slot == 1) lf_t1 = 0xFFFFFFFFu; else if (slot == 2) lf_t2 = 0xFFFFFFFFu; else lf_t3 = 0xFFFFFFFFu;
+                        EMU_COUNT(5);
+                    } else if (lane < 32) L.leafv = (int)leaves[(int64_t)id * kLeafStride + lane];
+                    cur_leaf = id;
+                }
+                return;
+            }
+#endif
             if (LIKELY(id != cur_leaf)) {
 #ifndef FUIF_EXP_NOLEAFLOAD   // (experiments: what the leaf traffic costs -- FUIF_EXP_NOLEAFLOAD / _NOLEAFSTORE / _NOLEAFFETCH decode garbage)
                 if (lane < 32) {
@@ -1635,6 +1700,51 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                     prof_acc[7] += (unsigned)rdlane(L.leafv, 0) & 0u;  // force the leaf load to complete inside this lap
 #endif
                                     PROF_LAP(3);
+#ifdef FUIF_SPEC_LEAF
+                                    if (kSpecLeaf && tree_size > 1 && j + 1 < nx) {
+                                        const int depflag = (c_left | (c_ll != 0)) ? 1 : 0;   // per property lane: depends on the pixel being decoded
+                                        const int pvn = sh.cprops[(j + 1) * kPropPitch + (lane & 31)];
+                                        auto prefetch_leaf = [&](uint32_t lf) {
+                                            if (lf == (uint32_t)cur_leaf || lf == lf_prev_wb || lf == lf_t0 || lf == lf_t1 || lf == lf_t2 || lf == lf_t3) return;
+                                            dma_leaf(leaves, lf, &sh.spec_leaf[lf_victim * kLeafStride], lane);
+                                            if (lf_victim == 0) lf_t0 = lf; else if (lf_victim == 1) lf_t1 = lf; else if (lf_victim == 2) lf_t2 = lf; else lf_t3 = lf;
+                                            lf_victim = (lf_victim + 1u) & 3u;
+                                        };
+                                        // candidates of one supernode: the exits its KNOWN decisions leave reachable, lowest lane first
+                                        auto spec_cands = [&](const uint2 nd) -> unsigned long long {
+                                            const int sel = (int)((nd.y & 0xFFu) << 2);
+                                            const unsigned long long unk = __ballot(__builtin_amdgcn_ds_bpermute(sel, depflag) != 0);
+                                            const unsigned long long mm = __ballot(__builtin_amdgcn_ds_bpermute(sel, pvn) > (int)nd.x);
+                                            const uint32_t klo = (uint32_t)mm & ~(uint32_t)unk, khi = (uint32_t)(mm >> 32) & ~(uint32_t)(unk >> 32);
+                                            const uint32_t elo = exp_lo & ~(uint32_t)unk, ehi = exp_hi & ~(uint32_t)(unk >> 32);
+                                            const bool reach = ((((klo ^ elo) & msk_lo) | ((khi ^ ehi) & msk_hi)) == 0u);
+                                            return __ballot(reach);
+                                        };
+                                        unsigned long long c1 = spec_cands(root_nd);
+#pragma unroll
+                                        for (int k = 0; k < 2; k++) {
+                                            if (c1) {
+                                                const int e = __builtin_ctzll(c1);
+                                                c1 &= c1 - 1;
+                                                const uint32_t t = (uint32_t)rdlane((int)root_nd.y, e) >> 8;
+                                                if (t & kLeafFlag) prefetch_leaf(t & (kLeafFlag - 1u));
+                                                else if (!(t & kSlowFlag) && t <= (uint32_t)kLdsSuper) {
+                                                    const uint2 nd2 = lds_load_node(lds_nodes_addr + (t - 1u) * 512u + (uint32_t)lane * 8u);
+                                                    unsigned long long c2 = spec_cands(nd2);
+#pragma unroll
+                                                    for (int q = 0; q < 2; q++) {
+                                                        if (c2) {
+                                                            const int e2 = __builtin_ctzll(c2);
+                                                            c2 &= c2 - 1;
+                                                            const uint32_t t2 = (uint32_t)rdlane((int)nd2.y, e2) >> 8;
+                                                            if (t2 & kLeafFlag) prefetch_leaf(t2 & (kLeafFlag - 1u));
+                                                        }
+                                                    }
+                                                }
+                                            }
+                                        }
+                                    }
+#endif
 #ifdef FUIF_SPEC_WALK
                                     if (kSpec && spec_row && n_super > 1 && j + 1 < nx) {   // (a tree that fits the root supernode has nothing to fetch)
                                         // root round of pixel j+1 on the properties that do not depend on pixel j; unknown nodes go both ways
@@ -1811,9 +1921,9 @@ void launch_maniac_decode(const DecodeParams &P, int n_waves, int dense, int han
 
 
 #ifdef FUIF_EMU
-namespace fuifgpu { namespace { unsigned long long g_emu_stats[4]; } }
+namespace fuifgpu { namespace { unsigned long long g_emu_stats[6]; } }
 // emulator builds only (tools/emu_walk_stats.py): {symbols that walked the tree, rounds served from LDS, rounds from scratch}
-extern "C" void fuifgpu_emu_walk_stats(unsigned long long *out4, int reset) {
-    for (int k = 0; k < 4; k++) { out4[k] = fuifgpu::g_emu_stats[k]; if (reset) fuifgpu::g_emu_stats[k] = 0; }
+extern "C" void fuifgpu_emu_walk_stats(unsigned long long *out6, int reset) {
+    for (int k = 0; k < 6; k++) { out6[k] = fuifgpu::g_emu_stats[k]; if (reset) fuifgpu::g_emu_stats[k] = 0; }
 }
 #endif

@@ -189,7 +189,7 @@ static inline int coder_read(fo_rac *r, uint16_t *ch, const uint16_t *table) {
 }
 
 static int g_stats;
-static struct fo_stats_s { uint64_t sym, walked, steps, predepth, same_leaf, zero, nsign, edec, mdec, ehist[16], prehist[24], spec_exits, spec_inner, spec_hist[6], spec_round2, spec_hit, rounds_behind, leaf_sw, leaf_hit[3]; } g_st;
+static struct fo_stats_s { uint64_t sym, walked, steps, predepth, same_leaf, zero, nsign, edec, mdec, ehist[16], prehist[24], spec_exits, spec_inner, spec_hist[6], spec_round2, spec_hit, rounds_behind, leaf_sw, leaf_hit[3], wl_hit[2], wl_cand; } g_st;
 /* maniac/symbol.h:154-185 reader<bits>(coder,min,max) */
 static int read_symbol(fo_rac *r, uint16_t *ch, const uint16_t *table, int min, int max) {
     if (min == max) return min;
@@ -740,6 +740,16 @@ static void fo_spec_list(const fo_node *n, int pos, int depth, const int32_t *pr
     } else fo_spec_list(n, props[n[pos].property] > n[pos].splitval ? n[pos].childID : n[pos].childID + 1, depth + 1, props, nref, y, list, cnt, cap);
 }
 
+/* root exits reachable with an unknown left neighbour, in kernel order, with their kind (leaf: its number; inner: its node) */
+static void fo_spec_exits(const fo_node *n, int pos, int depth, const int32_t *props, int nref, int y, int *node, int *leaf, int *cnt, int cap) {
+    if (*cnt >= cap) return;
+    if (n[pos].property == -1) { node[*cnt] = -1; leaf[(*cnt)++] = n[pos].childID; return; }
+    if (depth == 6) { node[*cnt] = pos; leaf[(*cnt)++] = -1; return; }
+    if (fo_left_dependent(n[pos].property - nref, y)) {
+        fo_spec_exits(n, n[pos].childID + 1, depth + 1, props, nref, y, node, leaf, cnt, cap);
+        fo_spec_exits(n, n[pos].childID, depth + 1, props, nref, y, node, leaf, cnt, cap);
+    } else fo_spec_exits(n, props[n[pos].property] > n[pos].splitval ? n[pos].childID : n[pos].childID + 1, depth + 1, props, nref, y, node, leaf, cnt, cap);
+}
 /* second speculative step: the leaves reachable (unknown left) within the 6 levels below node `pos` -- what a speculative round on a
  * supernode that is already in LDS could name, so that their chances can be fetched before the pixel's own walk gets there */
 static void fo_spec_leaves(const fo_node *n, int pos, int depth, int maxdepth, const int32_t *props, int nref, int y, int *list, int *cnt, int cap) {
@@ -945,6 +955,8 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
     int st_prev_leaf = -1;
     int st_tag[2] = {-1, -1}, st_victim = 0;
     int st_ltag[3][8], st_lvict[3] = {0, 0, 0};
+    int st_wtag[2][8], st_wvict[2] = {0, 0}, st_prev2_leaf = -1;
+    for (int b = 0; b < 2; b++) for (int q = 0; q < 8; q++) st_wtag[b][q] = -1;
     for (int b = 0; b < 3; b++) for (int q = 0; q < 8; q++) st_ltag[b][q] = -1;
     if (g_stats > 0) memset(&g_st, 0, sizeof(g_st));
     const uint64_t st_dec0 = rac.decisions;
@@ -992,6 +1004,31 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
                             fo_spec_list(tree.n, 0, 0, props, nref, y, cl, &cn, 2);
                             for (int k = 0; k < cn; k++)
                                 if (cl[k] != st_tag[0] && cl[k] != st_tag[1]) { st_tag[st_victim] = cl[k]; st_victim ^= 1; }
+                        }
+                        if (g_stats > 0 && (x & 63)) {
+                            /* -DFUIF_SPEC_LEAF policy of the WIDE configuration (second-level supernodes resident in LDS): the first two root
+                             * exits; a leaf exit names its leaf, an inner exit the first two leaves a speculative round on it reaches; leaves
+                             * equal to the current leaf or to the one just written back are skipped; 4 / 8 slots, round robin */
+                            int en[2], el[2], ec = 0, wl[4], wn = 0;
+                            fo_spec_exits(tree.n, 0, 0, props, nref, y, en, el, &ec, 2);
+                            for (int k = 0; k < ec; k++) {
+                                if (en[k] < 0) { if (wn < 4) wl[wn++] = el[k]; }
+                                else { int cap2 = wn + 2 > 4 ? 4 : wn + 2; fo_spec_leaves(tree.n, en[k], 6, 12, props, nref, y, wl, &wn, cap2); }
+                            }
+                            for (int k = 0; k < wn; k++) {
+                                if (wl[k] == st_prev_leaf || wl[k] == st_prev2_leaf) continue;
+                                g_st.wl_cand++;
+                                for (int b = 0; b < 2; b++) {
+                                    const int slots = 4 << b;
+                                    int have = 0;
+                                    for (int q = 0; q < slots; q++) if (st_wtag[b][q] == wl[k]) have = 1;
+                                    if (!have) { st_wtag[b][st_wvict[b]] = wl[k]; st_wvict[b] = (st_wvict[b] + 1) % slots; }
+                                }
+                            }
+                        }
+                        if (g_stats > 0 && (x & 31)) {
+                            int cl[4], cn = 0;
+                            fo_spec_list(tree.n, 0, 0, props, nref, y, cl, &cn, 2);
                             /* leaf speculation, three slot budgets (2 / 4 / 8 leaf slots, round robin): leaves that hang off the root supernode
                              * and leaves below the (up to two) candidate second-level supernodes, first come first served */
                             int ll[16], ln = 0;
@@ -1020,6 +1057,8 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
                             else pos = tree.n[pos].childID + 1;
                         }
                         if (g_stats > 0 && (int)tree.n[pos].childID != st_prev_leaf) {
+                            for (int b = 0; b < 2; b++) for (int q = 0; q < (4 << b); q++)
+                                if (st_wtag[b][q] == (int)tree.n[pos].childID) { g_st.wl_hit[b]++; st_wtag[b][q] = -1; break; }   /* used: the copy is not valid any longer */
                             g_st.leaf_sw++;
                             for (int b = 0; b < 3; b++) for (int q = 0; q < (2 << b); q++) if (st_ltag[b][q] == (int)tree.n[pos].childID) { g_st.leaf_hit[b]++; break; }
                         }
@@ -1031,6 +1070,7 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
                             if (pre < 0) pre = depth;
                             g_st.walked++; g_st.steps += depth; g_st.predepth += pre; g_st.prehist[pre > 23 ? 23 : pre]++;
                             if ((int)tree.n[pos].childID == st_prev_leaf) g_st.same_leaf++;
+                            if ((int)tree.n[pos].childID != st_prev_leaf) st_prev2_leaf = st_prev_leaf;
                             st_prev_leaf = tree.n[pos].childID;
                         }
                         if (g_leafsim) { leafsim_access(ls_ids[tree.n[pos].childID], &ls_prev); g_depth_hist[depth > 31 ? 31 : depth]++;
@@ -1062,6 +1102,9 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
         fprintf(stderr, "\n  spec policy (2 slots, first 2 candidates): %.3f second-level rounds per walk, %.1f %% of them found in a slot; all rounds behind the root %llu, hits %llu\n",
                 g_st.walked ? (double)g_st.spec_round2 / g_st.walked : 0.0, g_st.spec_round2 ? 100.0 * g_st.spec_hit / g_st.spec_round2 : 0.0,
                 (unsigned long long)g_st.rounds_behind, (unsigned long long)g_st.spec_hit);
+        fprintf(stderr, "  wide configuration, leaf speculation (first 2 root exits, 2 leaves each): %.2f candidates fetched per walk; leaf switches served from 4 / 8 slots: %.1f %% / %.1f %% (switches %llu, served from 4 slots %llu)\n",
+                g_st.walked ? (double)g_st.wl_cand / g_st.walked : 0.0, g_st.leaf_sw ? 100.0 * g_st.wl_hit[0] / g_st.leaf_sw : 0.0, g_st.leaf_sw ? 100.0 * g_st.wl_hit[1] / g_st.leaf_sw : 0.0,
+                (unsigned long long)g_st.leaf_sw, (unsigned long long)g_st.wl_hit[0]);
         fprintf(stderr, "  leaf speculation: %.3f leaf switches per walk; found among the speculated leaves with 2 / 4 / 8 slots: %.1f %% / %.1f %% / %.1f %%\n",
                 g_st.walked ? (double)g_st.leaf_sw / g_st.walked : 0.0, g_st.leaf_sw ? 100.0 * g_st.leaf_hit[0] / g_st.leaf_sw : 0.0,
                 g_st.leaf_sw ? 100.0 * g_st.leaf_hit[1] / g_st.leaf_sw : 0.0, g_st.leaf_sw ? 100.0 * g_st.leaf_hit[2] / g_st.leaf_sw : 0.0);

@@ -24,7 +24,7 @@ split = 2 if "--deep" in sys.argv else None    # --deep: a split only has to sav
 img = photographic(w, h, 3, 8, seed=1000)
 blob = fuif_amd.encode_image(img, 8, tree_mode=1, index=True, split_bits=split)
 L = fuif_amd.lib()
-st = (C.c_ulonglong * 4)()
+st = (C.c_ulonglong * 6)()
 for parallel, name in ((False, "wide  (58 supernodes in LDS, one tile per image)"), (True, "dense ( 2 supernodes in LDS, one tile per group)")):
     plan = fuif_amd.Plan(blob)
     b = fuif_amd.Batch(plan, 1, len(blob))
@@ -38,3 +38,5 @@ for parallel, name in ((False, "wide  (58 supernodes in LDS, one tile per image)
     sym, lds, glob = st[0], st[1], st[2]
     print("%s: %d symbols, %.3f rounds/symbol behind the root, %.1f %% of them from LDS, %.3f scratch fetches per symbol (lossless %s)" % (
         name, sym, (lds + glob) / max(sym, 1), 100.0 * lds / max(lds + glob, 1), glob / max(sym, 1), ok))
+    if st[4]:
+        print("    -DFUIF_SPEC_LEAF: %d leaf switches, %.1f %% of them served from a speculated LDS leaf slot" % (st[4], 100.0 * st[5] / st[4]))

@@ -4,7 +4,7 @@
 # The release kernel is bit-identical with and without the macro's code in the source (checked on the ISA); the variant is
 # parity-green on the wavefront emulator and served 50.7 % of the walk rounds behind the root from LDS there (24.4 % with the
 # static residents) on a deep-tree picture.  What is NOT known: whether it is faster.
-#   gpurun --timeout 600 -- bash tools/experiments/r4_1_spec_walk.sh
+#   gpurun --timeout 900 -- bash tools/experiments/r4_1_spec_walk.sh
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
@@ -17,5 +17,12 @@ for lib in fuif_amd/libfuifgpu.so build/libfuifgpu_spec.so build/libfuifgpu_spec
   FUIF_AMD_LIB=$ROOT/$lib timeout 120 python tools/time_decode.py 128 3840 2160 --reps 2 --check
   FUIF_AMD_LIB=$ROOT/$lib timeout 200 python tools/time_decode.py 1024 3840 2160 --reps 3 --check
 done
-FUIF_AMD_LIB=$ROOT/build/libfuifgpu_spec.so timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_group_parallel.py -m gpu -x -q
+# streams WITHOUT a group index (one wavefront per image, the wide configuration): -DFUIF_SPEC_LEAF speculates on the leaf
+[ -f build/libfuifgpu_specleaf.so ] || bash tools/build_variant.sh specleaf -DFUIF_SPEC_LEAF
+for lib in fuif_amd/libfuifgpu.so build/libfuifgpu_specleaf.so; do
+  FUIF_AMD_LIB=$ROOT/$lib timeout 200 python tools/time_decode.py 1024 3840 2160 --no-index --reps 2 --check
+done
+for lib in build/libfuifgpu_spec.so build/libfuifgpu_specleaf.so; do
+  FUIF_AMD_LIB=$ROOT/$lib timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_group_parallel.py -m gpu -x -q
+done
 } 2>&1 | grep -v amdgpu | tee $OUT/times.txt
