@@ -189,7 +189,7 @@ static inline int coder_read(fo_rac *r, uint16_t *ch, const uint16_t *table) {
 }
 
 static int g_stats;
-static struct fo_stats_s { uint64_t sym, walked, steps, predepth, same_leaf, zero, nsign, edec, mdec, ehist[16], prehist[24], spec_exits, spec_inner, spec_hist[6], spec_round2, spec_hit, rounds_behind, leaf_sw, leaf_hit[3], wl_hit[2], wl_cand; } g_st;
+static struct fo_stats_s { uint64_t sym, walked, steps, predepth, same_leaf, zero, nsign, edec, mdec, ehist[16], prehist[24], spec_exits, spec_inner, spec_hist[6], spec_round2, spec_hit, rounds_behind, leaf_sw, leaf_hit[3], wl_hit[2], wl_cand, dl_hit, dl_cand; } g_st;
 /* maniac/symbol.h:154-185 reader<bits>(coder,min,max) */
 static int read_symbol(fo_rac *r, uint16_t *ch, const uint16_t *table, int min, int max) {
     if (min == max) return min;
@@ -956,6 +956,7 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
     int st_tag[2] = {-1, -1}, st_victim = 0;
     int st_ltag[3][8], st_lvict[3] = {0, 0, 0};
     int st_wtag[2][8], st_wvict[2] = {0, 0}, st_prev2_leaf = -1;
+    int st_dtag[4] = {-1, -1, -1, -1}, st_dvict = 0;
     for (int b = 0; b < 2; b++) for (int q = 0; q < 8; q++) st_wtag[b][q] = -1;
     for (int b = 0; b < 3; b++) for (int q = 0; q < 8; q++) st_ltag[b][q] = -1;
     if (g_stats > 0) memset(&g_st, 0, sizeof(g_st));
@@ -1002,6 +1003,22 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
                         if (g_stats > 0 && (x & 31)) {   /* what the kernel fetched for this pixel while the previous one was decoded */
                             int cl[4], cn = 0;
                             fo_spec_list(tree.n, 0, 0, props, nref, y, cl, &cn, 2);
+                            {   /* dense configuration + FUIF_SPEC_WALK: leaf speculation only through candidates that are resident ALREADY (no waiting),
+                                 * plus leaves hanging off the root; first two root exits, two leaves each, four slots, same skip / use-once rules */
+                                int en[2], el[2], ec = 0, dl[4], dn = 0;
+                                fo_spec_exits(tree.n, 0, 0, props, nref, y, en, el, &ec, 2);
+                                for (int k = 0; k < ec; k++) {
+                                    if (en[k] < 0) { if (dn < 4) dl[dn++] = el[k]; }
+                                    else if (en[k] == st_tag[0] || en[k] == st_tag[1]) { int cap2 = dn + 2 > 4 ? 4 : dn + 2; fo_spec_leaves(tree.n, en[k], 6, 12, props, nref, y, dl, &dn, cap2); }
+                                }
+                                for (int k = 0; k < dn; k++) {
+                                    if (dl[k] == st_prev_leaf || dl[k] == st_prev2_leaf) continue;
+                                    g_st.dl_cand++;
+                                    int have = 0;
+                                    for (int q = 0; q < 4; q++) if (st_dtag[q] == dl[k]) have = 1;
+                                    if (!have) { st_dtag[st_dvict] = dl[k]; st_dvict = (st_dvict + 1) & 3; }
+                                }
+                            }
                             for (int k = 0; k < cn; k++)
                                 if (cl[k] != st_tag[0] && cl[k] != st_tag[1]) { st_tag[st_victim] = cl[k]; st_victim ^= 1; }
                         }
@@ -1059,6 +1076,7 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
                         if (g_stats > 0 && (int)tree.n[pos].childID != st_prev_leaf) {
                             for (int b = 0; b < 2; b++) for (int q = 0; q < (4 << b); q++)
                                 if (st_wtag[b][q] == (int)tree.n[pos].childID) { g_st.wl_hit[b]++; st_wtag[b][q] = -1; break; }   /* used: the copy is not valid any longer */
+                            for (int q = 0; q < 4; q++) if (st_dtag[q] == (int)tree.n[pos].childID) { g_st.dl_hit++; st_dtag[q] = -1; break; }
                             g_st.leaf_sw++;
                             for (int b = 0; b < 3; b++) for (int q = 0; q < (2 << b); q++) if (st_ltag[b][q] == (int)tree.n[pos].childID) { g_st.leaf_hit[b]++; break; }
                         }
@@ -1105,6 +1123,8 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
         fprintf(stderr, "  wide configuration, leaf speculation (first 2 root exits, 2 leaves each): %.2f candidates fetched per walk; leaf switches served from 4 / 8 slots: %.1f %% / %.1f %% (switches %llu, served from 4 slots %llu)\n",
                 g_st.walked ? (double)g_st.wl_cand / g_st.walked : 0.0, g_st.leaf_sw ? 100.0 * g_st.wl_hit[0] / g_st.leaf_sw : 0.0, g_st.leaf_sw ? 100.0 * g_st.wl_hit[1] / g_st.leaf_sw : 0.0,
                 (unsigned long long)g_st.leaf_sw, (unsigned long long)g_st.wl_hit[0]);
+        fprintf(stderr, "  dense configuration, leaf speculation through candidates that are already resident: %.2f leaf fetches per walk, %.1f %% of the leaf switches served\n",
+                g_st.walked ? (double)g_st.dl_cand / g_st.walked : 0.0, g_st.leaf_sw ? 100.0 * g_st.dl_hit / g_st.leaf_sw : 0.0);
         fprintf(stderr, "  leaf speculation: %.3f leaf switches per walk; found among the speculated leaves with 2 / 4 / 8 slots: %.1f %% / %.1f %% / %.1f %%\n",
                 g_st.walked ? (double)g_st.leaf_sw / g_st.walked : 0.0, g_st.leaf_sw ? 100.0 * g_st.leaf_hit[0] / g_st.leaf_sw : 0.0,
                 g_st.leaf_sw ? 100.0 * g_st.leaf_hit[1] / g_st.leaf_sw : 0.0, g_st.leaf_sw ? 100.0 * g_st.leaf_hit[2] / g_st.leaf_sw : 0.0);
