@@ -182,7 +182,7 @@ def test_sibling_batch_pipelines_uploads(gpulib):
     import os
     import threading
     n = 4
-    emulated = os.environ.get("FUIF_AMD_LIB", "").endswith("_emu.so")
+    emulated = ("_emu" in os.path.basename(os.environ.get("FUIF_AMD_LIB", "")))
     w, h = (96, 64) if emulated else (640, 480)      # (the wavefront emulator of tests/test_emulated_kernels.py runs this test too)
     sets = [[photographic(w, h, 3, 8, seed=6000 + 10 * s + i) for i in range(n)] for s in range(3)]
     blobs = [[gpulib.encode_image(im, 8, tree_mode=1, index=True) for im in st] for st in sets]

@@ -11,7 +11,7 @@ from fuif_amd.synth import photographic
 
 pytestmark = pytest.mark.gpu
 
-EMULATED = os.environ.get("FUIF_AMD_LIB", "").endswith("_emu.so")
+EMULATED = ("_emu" in os.path.basename(os.environ.get("FUIF_AMD_LIB", "")))
 SHAPES = [(97, 61, 3, 8, True), (64, 48, 1, 8, True), (40, 30, 4, 14, False)] if EMULATED else \
          [(97, 61, 3, 8, True), (640, 480, 3, 8, True), (333, 200, 1, 12, True), (256, 256, 4, 14, False)]
 
