@@ -17,6 +17,12 @@ for lib in fuif_amd/libfuifgpu.so build/libfuifgpu_spec.so build/libfuifgpu_spec
   FUIF_AMD_LIB=$ROOT/$lib timeout 120 python tools/time_decode.py 128 3840 2160 --reps 2 --check
   FUIF_AMD_LIB=$ROOT/$lib timeout 200 python tools/time_decode.py 1024 3840 2160 --reps 3 --check
 done
+# per-phase cycles of both kernels (tree walk is where the supernode fetch sits): 8 streams (alone), 128 and 1024
+[ -f build/libfuifgpu_prof.so ] || bash tools/build_variant.sh prof -DFUIF_PROF
+[ -f build/libfuifgpu_spec_prof.so ] || bash tools/build_variant.sh spec_prof -DFUIF_PROF -DFUIF_SPEC_WALK
+for lib in build/libfuifgpu_prof.so build/libfuifgpu_spec_prof.so; do for n in 8 1024; do
+  echo "== $lib, $n streams"; FUIF_AMD_LIB=$ROOT/$lib timeout 300 python tools/prof_kernel.py $n 3840 2160
+done; done
 # streams WITHOUT a group index (one wavefront per image, the wide configuration): -DFUIF_SPEC_LEAF speculates on the leaf
 [ -f build/libfuifgpu_specleaf.so ] || bash tools/build_variant.sh specleaf -DFUIF_SPEC_LEAF
 for lib in fuif_amd/libfuifgpu.so build/libfuifgpu_specleaf.so; do
