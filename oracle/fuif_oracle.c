@@ -189,7 +189,7 @@ static inline int coder_read(fo_rac *r, uint16_t *ch, const uint16_t *table) {
 }
 
 static int g_stats;
-static struct fo_stats_s { uint64_t sym, walked, steps, predepth, same_leaf, zero, nsign, edec, mdec, ehist[16], prehist[24], spec_exits, spec_inner, spec_hist[6], spec_round2, spec_hit, rounds_behind, leaf_sw, leaf_hit[3], wl_hit[2], wl_cand, dl_hit, dl_cand; } g_st;
+static struct fo_stats_s { uint64_t sym, walked, steps, predepth, same_leaf, zero, nsign, edec, mdec, ehist[16], prehist[24], spec_exits, spec_inner, spec_hist[6], spec_round2, spec_hit, rounds_behind, leaf_sw, leaf_hit[3], wl_hit[2], wl_cand, dl_hit, dl_cand, r3_rounds, r3_hit[2]; } g_st;
 /* maniac/symbol.h:154-185 reader<bits>(coder,min,max) */
 static int read_symbol(fo_rac *r, uint16_t *ch, const uint16_t *table, int min, int max) {
     if (min == max) return min;
@@ -750,6 +750,15 @@ static void fo_spec_exits(const fo_node *n, int pos, int depth, const int32_t *p
         fo_spec_exits(n, n[pos].childID, depth + 1, props, nref, y, node, leaf, cnt, cap);
     } else fo_spec_exits(n, props[n[pos].property] > n[pos].splitval ? n[pos].childID : n[pos].childID + 1, depth + 1, props, nref, y, node, leaf, cnt, cap);
 }
+/* third-level supernodes reachable (unknown left) below the second-level supernode rooted at `pos` (depth 6): inner nodes at depth 12 */
+static void fo_spec_third(const fo_node *n, int pos, int depth, const int32_t *props, int nref, int y, int *list, int *cnt, int cap) {
+    if (n[pos].property == -1) return;
+    if (depth == 12) { if (*cnt < cap) list[(*cnt)++] = pos; return; }
+    if (fo_left_dependent(n[pos].property - nref, y)) {
+        fo_spec_third(n, n[pos].childID + 1, depth + 1, props, nref, y, list, cnt, cap);
+        fo_spec_third(n, n[pos].childID, depth + 1, props, nref, y, list, cnt, cap);
+    } else fo_spec_third(n, props[n[pos].property] > n[pos].splitval ? n[pos].childID : n[pos].childID + 1, depth + 1, props, nref, y, list, cnt, cap);
+}
 /* second speculative step: the leaves reachable (unknown left) within the 6 levels below node `pos` -- what a speculative round on a
  * supernode that is already in LDS could name, so that their chances can be fetched before the pixel's own walk gets there */
 static void fo_spec_leaves(const fo_node *n, int pos, int depth, int maxdepth, const int32_t *props, int nref, int y, int *list, int *cnt, int cap) {
@@ -957,6 +966,7 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
     int st_ltag[3][8], st_lvict[3] = {0, 0, 0};
     int st_wtag[2][8], st_wvict[2] = {0, 0}, st_prev2_leaf = -1;
     int st_dtag[4] = {-1, -1, -1, -1}, st_dvict = 0;
+    int st_t3[2][2] = {{-1, -1}, {-1, -1}}, st_t3v = 0;
     for (int b = 0; b < 2; b++) for (int q = 0; q < 8; q++) st_wtag[b][q] = -1;
     for (int b = 0; b < 3; b++) for (int q = 0; q < 8; q++) st_ltag[b][q] = -1;
     if (g_stats > 0) memset(&g_st, 0, sizeof(g_st));
@@ -1019,6 +1029,17 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
                                     if (!have) { st_dtag[st_dvict] = dl[k]; st_dvict = (st_dvict + 1) & 3; }
                                 }
                             }
+                            {   /* a third (fourth) slot for third-level supernodes: a speculative round on every candidate that is resident already */
+                                for (int k = 0; k < cn; k++) {
+                                    if (cl[k] != st_tag[0] && cl[k] != st_tag[1]) continue;
+                                    int t3[2], tn = 0;
+                                    fo_spec_third(tree.n, cl[k], 6, props, nref, y, t3, &tn, 2);
+                                    for (int q = 0; q < tn; q++) {
+                                        if (t3[q] != st_t3[0][0]) st_t3[0][0] = (q == 0 && k == 0) ? t3[q] : st_t3[0][0];          /* one slot: the first candidate only */
+                                        if (t3[q] != st_t3[1][0] && t3[q] != st_t3[1][1]) { st_t3[1][st_t3v] = t3[q]; st_t3v ^= 1; }   /* two slots, round robin */
+                                    }
+                                }
+                            }
                             for (int k = 0; k < cn; k++)
                                 if (cl[k] != st_tag[0] && cl[k] != st_tag[1]) { st_tag[st_victim] = cl[k]; st_victim ^= 1; }
                         }
@@ -1063,6 +1084,7 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
                         while (tree.n[pos].property != -1) {
                             if (g_stats > 0 && depth == 6) { g_st.spec_round2++; if (pos == st_tag[0] || pos == st_tag[1]) g_st.spec_hit++; }
                             if (g_stats > 0 && depth && depth % 6 == 0) g_st.rounds_behind++;
+                            if (g_stats > 0 && depth == 12) { g_st.r3_rounds++; if (pos == st_t3[0][0]) g_st.r3_hit[0]++; if (pos == st_t3[1][0] || pos == st_t3[1][1]) g_st.r3_hit[1]++; }
                             img->stat_tree_steps++;
                             if (g_stats > 0 && pre < 0) {
                                 const int kl = tree.n[pos].property - nref;  /* local properties that read `left` */
@@ -1123,6 +1145,8 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
         fprintf(stderr, "  wide configuration, leaf speculation (first 2 root exits, 2 leaves each): %.2f candidates fetched per walk; leaf switches served from 4 / 8 slots: %.1f %% / %.1f %% (switches %llu, served from 4 slots %llu)\n",
                 g_st.walked ? (double)g_st.wl_cand / g_st.walked : 0.0, g_st.leaf_sw ? 100.0 * g_st.wl_hit[0] / g_st.leaf_sw : 0.0, g_st.leaf_sw ? 100.0 * g_st.wl_hit[1] / g_st.leaf_sw : 0.0,
                 (unsigned long long)g_st.leaf_sw, (unsigned long long)g_st.wl_hit[0]);
+        fprintf(stderr, "  third-level rounds: %.3f per walk; found in an extra slot filled through resident candidates: %.1f %% (1 slot) / %.1f %% (2 slots)\n",
+                g_st.walked ? (double)g_st.r3_rounds / g_st.walked : 0.0, g_st.r3_rounds ? 100.0 * g_st.r3_hit[0] / g_st.r3_rounds : 0.0, g_st.r3_rounds ? 100.0 * g_st.r3_hit[1] / g_st.r3_rounds : 0.0);
         fprintf(stderr, "  dense configuration, leaf speculation through candidates that are already resident: %.2f leaf fetches per walk, %.1f %% of the leaf switches served\n",
                 g_st.walked ? (double)g_st.dl_cand / g_st.walked : 0.0, g_st.leaf_sw ? 100.0 * g_st.dl_hit / g_st.leaf_sw : 0.0);
         fprintf(stderr, "  leaf speculation: %.3f leaf switches per walk; found among the speculated leaves with 2 / 4 / 8 slots: %.1f %% / %.1f %% / %.1f %%\n",
