@@ -507,6 +507,8 @@ def main():
                     help="images resident at a time (0 = the whole batch, -1 = as many as the device holds): the batch is streamed through ONE chunk-sized set of coefficient / "
                          "output slabs, chunk after chunk -- how C4 (256 x 8192x8192x4: 275 GB of coefficients alone) runs on one GPU")
     ap.add_argument("--cache", default=os.environ.get("FUIF_BENCH_CACHE", "/tmp/fuif_bench_cache"))
+    ap.add_argument("--no-rccl-selfcheck", action="store_true",
+                    help="one GPU: do not start the one-rank RCCL process group that runs the N>1 collectives on cuda:0 (outside the timed region except for the fence's barrier)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="(tests) start the ranks as --gpus asks, meet on the gloo backend, print {\"n_gpus\": world} and stop: no decoding, no GPU")
     args = ap.parse_args()
@@ -549,6 +551,21 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = fd.init(device=dev)
+    # One GPU: the collectives of the N>1 path still run, through a process group of ONE rank on RCCL (barrier, max-over-ranks
+    # all_reduce, checksum all_gather, the chunked gather of the packed pictures), so that an RCCL / HIP-runtime clash in this
+    # process shows on the one GPU the driver always has, not first on an 8-GPU node.  A failure to start RCCL is reported
+    # in the line (rccl_selfcheck), it does not stop the measurement; --no-rccl-selfcheck skips it.
+    rccl_note = None
+    if dist is None and world == 1 and not args.no_rccl_selfcheck:
+        try:
+            dist = fd.init(device=dev, world1=True)
+            probe = torch.ones(1, dtype=torch.int64, device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            rccl_note = "ok: process group of 1 rank on backend %s (RCCL); barrier / all_reduce / all_gather / gather ran on cuda:%d" % (dist.get_backend(), local_rank)
+        except Exception as e:   # noqa: BLE001 -- anything RCCL throws is a finding to report, not a reason to lose the bench line
+            rccl_note = "FAILED to start RCCL at world size 1: %s: %s" % (type(e).__name__, str(e)[:300])
+            dist = None
 
     if args.chunk < 0:
         # as many images per chunk as the device holds: coefficient + output slabs (int32) and the stream of every resident image,
@@ -652,8 +669,10 @@ def main():
         moved = (world - 1) * n_pack * pb
         gather_info = {"payload": "packed 8-bit interleaved pictures (k_pack_samples), %d bytes per image" % pb,
                        "images_per_rank": n_pack, "pack_ms": round(t_pack * 1e3, 3), "pack_GBps": round(n_pack * (pb + 4.0 * info.out_elems) / max(t_pack, 1e-9) / 1e9, 1),
-                       "gather_ms": round(t_gather * 1e3, 3) if world > 1 else None, "bytes_into_root": int(moved),
-                       "gather_GBps": round(moved / max(t_gather, 1e-9) / 1e9, 1) if world > 1 else None, "byte_sums_ok": bool(sums_ok)}
+                       "gather_ms": round(t_gather * 1e3, 3) if dist is not None else None, "bytes_into_root": int(moved),
+                       "bytes_through_rccl_per_rank": int(n_pack * pb) if dist is not None else 0,
+                       "gather_GBps": round(max(moved, n_pack * pb if world == 1 else 0) / max(t_gather, 1e-9) / 1e9, 1) if dist is not None else None,
+                       "byte_sums_ok": bool(sums_ok), "rccl_selfcheck": rccl_note}
     # replicas of one source image must agree on every rank
     for r in range(gathered.shape[0]):
         for k in range(K):

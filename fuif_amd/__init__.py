@@ -70,8 +70,14 @@ class ChannelDesc(C.Structure):
 
 
 class EncodeOptions(C.Structure):
-    _fields_ = [("ycocg", C.c_int32), ("squeeze", C.c_int32), ("max_properties", C.c_int32), ("tree_mode", C.c_int32),
+    """fuifgpu_encode_options (include/fuifgpu.h): versioned by its first field; make_encode_options() fills it in"""
+    _fields_ = [("struct_size", C.c_uint32), ("ycocg", C.c_int32), ("squeeze", C.c_int32), ("max_properties", C.c_int32), ("tree_mode", C.c_int32),
                 ("max_tree_nodes", C.c_int32), ("emit_index", C.c_int32), ("split_bits", C.c_int32), ("gpu_forward", C.c_int32), ("gpu_entropy", C.c_int32)]
+
+
+def make_encode_options(*fields):
+    """EncodeOptions with struct_size set, the fields behind it in header order"""
+    return EncodeOptions(C.sizeof(EncodeOptions), *fields)
 
 
 # every symbol include/fuifgpu.h declares (tests check that the library exports all of them)
@@ -388,7 +394,7 @@ def encode_image(planes, bit_depth=8, ycocg=True, squeeze=True, max_properties=1
     split_bits = DEFAULT_SPLIT_BITS if split_bits is None else split_bits
     planes = np.ascontiguousarray(planes, dtype=np.int32)
     c, h, w = planes.shape
-    opt = EncodeOptions(int(ycocg), int(squeeze), max_properties, tree_mode, max_tree_nodes, int(index), int(split_bits), int(gpu_forward), int(gpu_entropy))
+    opt = make_encode_options(int(ycocg), int(squeeze), max_properties, tree_mode, max_tree_nodes, int(index), int(split_bits), int(gpu_forward), int(gpu_entropy))
     out = C.c_void_p()
     n = C.c_size_t(0)
     _check(lib().fuifgpu_encode_image(planes.ctypes.data, w, h, c, bit_depth, C.byref(opt), C.byref(out), C.byref(n)))
@@ -407,7 +413,7 @@ def encode_images(images, bit_depth=8, ycocg=True, squeeze=True, max_properties=
     if any(a.shape != (c, h, w) for a in arrs):
         raise FuifGpuError(4, "encode_images: all pictures of a batch must have one shape")
     n = len(arrs)
-    opt = EncodeOptions(int(ycocg), int(squeeze), max_properties, tree_mode, max_tree_nodes, int(index), int(split_bits), int(gpu_forward), 1)
+    opt = make_encode_options(int(ycocg), int(squeeze), max_properties, tree_mode, max_tree_nodes, int(index), int(split_bits), int(gpu_forward), 1)
     ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
     outs = (C.c_void_p * n)()
     sizes = (C.c_size_t * n)()

@@ -16,9 +16,9 @@
 // reports as FUIFGPU_E_UNSUPPORTED / FUIFGPU_ST_UNSUPPORTED (a data-driven Permute over channels of different geometry; soft 2D
 // matches).  Stills and
 // animations (FUAF), Squeeze / YCoCg / YCbCr / DCT / Quantize / Subsample / Palette / Approximate / 2D-match / Permute
-// chains all decode on the GPU.  With FUIFGPU_NO_CPU_FALLBACK=1 in the environment nothing is ever
-// routed to the reference's CPU decoder: an unsupported stream is an error (tests/test_boundary_cli.py
-// runs that way, so a planner regression cannot hide behind the fallback); FUIFGPU_VERBOSE=1 reports
+// chains all decode on the GPU.  By DEFAULT nothing is ever routed to the reference's CPU decoder: an
+// unsupported stream is a loud error (so a planner regression cannot hide behind a fallback);
+// FUIFGPU_ALLOW_CPU_FALLBACK=1 opts in to the reference's code for such input; FUIFGPU_VERBOSE=1 reports
 // on stderr which path decoded.  Everything else (fuif.cpp, import/export code, the encoder) is
 // compiled and linked UNCHANGED.
 //
@@ -78,6 +78,10 @@ std::map<const Image *, std::unique_ptr<Resident>> &registry() {
     return *r;
 }
 bool env_flag(const char *name) { const char *e = getenv(name); return e && *e && strcmp(e, "0") != 0; }
+// The reference's own CPU code is kept in the link (as *_cpu) but is OPT-IN: by default a stream or transform the GPU path
+// does not take is a loud error, so a planner regression in a deployment can never silently run the code this path replaces.
+// FUIFGPU_ALLOW_CPU_FALLBACK=1 lets such input go to the reference's decoder instead.
+bool cpu_fallback_allowed() { return env_flag("FUIFGPU_ALLOW_CPU_FALLBACK"); }
 // den / num / loops of an animation header (encoding.cpp:611-622): the four varints after the magic, then these
 struct Cursor {
     const std::vector<uint8_t> &b; size_t pos;
@@ -185,8 +189,8 @@ template <typename IO> bool fuif_decode(IO &io, Image &image, fuif_options optio
     bool unsupported = false;
     if (gpu_decode_bytes(bytes, image, options, &unsupported)) return true;
     if (!unsupported) return false;
-    if (env_flag("FUIFGPU_NO_CPU_FALLBACK")) {
-        e_printf("fuifgpu: this stream needs a feature outside the GPU path (%s) and FUIFGPU_NO_CPU_FALLBACK is set\n", fuifgpu_last_error());
+    if (!cpu_fallback_allowed()) {
+        e_printf("fuifgpu: this stream needs a feature outside the GPU path (%s); set FUIFGPU_ALLOW_CPU_FALLBACK=1 to decode it with the reference's CPU code\n", fuifgpu_last_error());
         return false;
     }
     if (env_flag("FUIFGPU_VERBOSE")) fprintf(stderr, "fuifgpu: outside the GPU path, decoding with the reference's CPU code\n");
@@ -240,7 +244,7 @@ bool cpu_decode_whole(const std::vector<uint8_t> &bytes, Image &img, const fuif_
 
 int fuif_decode_files(const char *const *filenames, int n_files, Image *images, fuif_options options, bool *ok_out) {
     if (!filenames || !images || n_files < 1) return 0;
-    const bool verbose = env_flag("FUIFGPU_VERBOSE"), no_cpu = env_flag("FUIFGPU_NO_CPU_FALLBACK");
+    const bool verbose = env_flag("FUIFGPU_VERBOSE"), no_cpu = !cpu_fallback_allowed();
     std::vector<std::vector<uint8_t>> bytes((size_t)n_files);
     std::vector<fuifgpu_plan *> plans((size_t)n_files, nullptr);
     std::vector<char> ok((size_t)n_files, 0), cpu_route((size_t)n_files, 0);
@@ -324,7 +328,7 @@ int fuif_decode_files(const char *const *filenames, int n_files, Image *images, 
             BlobReader io(bytes[i].data(), bytes[i].size());
             if (fuif_decode(io, images[i], options)) { fuifgpu_boundary_undo_transforms(&images[i], 0); ok[i] = !images[i].error; }
         } else if (cpu_route[i] == 1) {
-            if (no_cpu) { e_printf("fuifgpu: %s needs a feature outside the GPU path and FUIFGPU_NO_CPU_FALLBACK is set\n", filenames[i]); continue; }
+            if (no_cpu) { e_printf("fuifgpu: %s needs a feature outside the GPU path; set FUIFGPU_ALLOW_CPU_FALLBACK=1 to decode it with the reference's CPU code\n", filenames[i]); continue; }
             if (verbose) fprintf(stderr, "fuifgpu: %s is outside the GPU path, decoding with the reference's CPU code\n", filenames[i]);
             ok[i] = cpu_decode_whole(bytes[i], images[i], options) ? 1 : 0;
         }
@@ -369,8 +373,8 @@ void fuifgpu_boundary_undo_transforms(Image *self, int keep) {
     int32_t status = 0;
     fuifgpu_batch_status(res.batch, &status, nullptr);
     if (status & FUIFGPU_ST_UNSUPPORTED) {
-        if (env_flag("FUIFGPU_NO_CPU_FALLBACK")) {
-            e_printf("fuifgpu: the transform chain needs a feature outside the GPU path and FUIFGPU_NO_CPU_FALLBACK is set\n");
+        if (!cpu_fallback_allowed()) {
+            e_printf("fuifgpu: the transform chain needs a feature outside the GPU path; set FUIFGPU_ALLOW_CPU_FALLBACK=1 to run it with the reference's CPU code\n");
             self->error = true;
         } else {
             // the planes on the host are still the coded ones: decode again with the reference's code and undo there
@@ -616,8 +620,8 @@ bool fuifgpu_boundary_transform_apply(Transform *self, Image &input, bool invers
         }
         // a transform this layer binds, on an image its kernels do not take (or a device error): the image is untouched (every
         // gpu_inv_* works on a copy), so the reference's own loop can run -- unless the caller asked for the GPU path or nothing
-        if (claimed && env_flag("FUIFGPU_NO_CPU_FALLBACK")) {
-            e_printf("fuifgpu: inverse %s could not run on the GPU (%s) and FUIFGPU_NO_CPU_FALLBACK is set\n", self->name(), fuifgpu_last_error());
+        if (claimed && !cpu_fallback_allowed()) {
+            e_printf("fuifgpu: inverse %s could not run on the GPU (%s); set FUIFGPU_ALLOW_CPU_FALLBACK=1 to run it with the reference's CPU code\n", self->name(), fuifgpu_last_error());
             return false;
         }
         if (claimed && env_flag("FUIFGPU_VERBOSE")) fprintf(stderr, "fuifgpu: inverse %s with the reference's CPU code (Transform::apply)\n", self->name());

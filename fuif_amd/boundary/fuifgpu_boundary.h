@@ -11,5 +11,5 @@
 #include "image/image.h"
 
 // images[i] receives file i; ok[i] (optional) says whether it decoded.  Returns the number of files decoded.
-// A file outside the GPU scope is decoded by the reference's own code unless FUIFGPU_NO_CPU_FALLBACK is set.
+// A file outside the GPU scope is an error (ok[i] = false) unless FUIFGPU_ALLOW_CPU_FALLBACK=1 lets the reference's own code decode it.
 int fuif_decode_files(const char *const *filenames, int n_files, Image *images, fuif_options options, bool *ok = nullptr);

@@ -272,8 +272,41 @@ int fuifgpu_batch_create(const fuifgpu_plan *plan, int n_images, size_t blob_cap
     return batch_create_impl(plan->plan, n_images, blob_capacity_bytes, coef_ext, out_ext, tmp_images, nullptr, out);
 }
 
+// The launch resources a sibling borrows must not move while it may be decoding: the documented pipeline runs an upload into one
+// batch on a host thread while the other batch decodes.  When the first sibling is created the primary's decoder scratch and
+// context arenas are therefore sized ONCE for the worst case -- as many wavefronts as the device holds (or the batch can ever
+// have tiles), arenas for a full batch -- and are never reallocated while a sibling exists (fuifgpu_batch_upload clamps to them).
+static size_t ctx_bytes_per_image() {
+    size_t per_image = 16u << 20;
+    if (const char *e = getenv("FUIFGPU_CTX_MB")) per_image = (size_t)std::max(1, atoi(e)) << 20;
+    if (const char *e = getenv("FUIFGPU_CTX_KB")) per_image = (size_t)std::max(0, atoi(e)) << 10;   // tests: arenas that run out (pinned tiles)
+    return per_image;
+}
+static int freeze_launch_resources(fuifgpu_batch *b) {
+    const int64_t cap = std::max(b->max_waves[0], b->max_waves[1]);
+    const int waves = (int)std::max<int64_t>(1, std::min<int64_t>(cap, (int64_t)b->n * std::max<int64_t>((int64_t)b->plan.coded.size(), 1)));
+    if (waves > b->scratch_waves) {
+        HIPCHK(hipDeviceSynchronize());
+        hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_waves = 0;
+        HIPCHK(hipMalloc((void **)&b->d_scratch, b->scratch_stride * (size_t)waves));
+        b->scratch_waves = waves;
+    }
+    size_t need = ctx_bytes_per_image() * (size_t)b->n;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) need = std::min(need, (free_b + b->ctx_bytes) / 2);
+    need = need / 256 * 256;
+    if (need > b->ctx_bytes) {
+        HIPCHK(hipDeviceSynchronize());
+        hipFree(b->d_ctx); b->d_ctx = nullptr; b->ctx_bytes = 0;
+        HIPCHK(hipMalloc((void **)&b->d_ctx, std::max<size_t>(need, 256)));
+        b->ctx_bytes = need;
+    }
+    return FUIFGPU_OK;
+}
+
 int fuifgpu_batch_create_sibling(fuifgpu_batch *primary, size_t blob_capacity_bytes, fuifgpu_batch **out) {
     if (!primary || primary->share) return FUIFGPU_E_ARG;
+    if (primary->siblings.empty()) { const int frc = freeze_launch_resources(primary); if (frc != FUIFGPU_OK) return frc; }
     const int rc = batch_create_impl(primary->plan, primary->n, blob_capacity_bytes, primary->d_coef, primary->d_out, primary->tmp_images, primary, out);
     if (rc == FUIFGPU_OK) primary->siblings.push_back(*out);
     return rc;
@@ -431,9 +464,7 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
             // Context arenas: a suspendable tile keeps its supernodes and leaf chances in its image's queue arena (bump
             // allocation inside a launch).  16 MiB per image covers trees of ~2000 nodes on every tile of a 61-tile image
             // three times over (FUIFGPU_CTX_MB overrides); a tile that finds the arena full is simply not suspendable.
-            size_t per_image = 16u << 20;
-            if (const char *e = getenv("FUIFGPU_CTX_MB")) per_image = (size_t)std::max(1, atoi(e)) << 20;
-            if (const char *e = getenv("FUIFGPU_CTX_KB")) per_image = (size_t)std::max(0, atoi(e)) << 10;   // tests: arenas that run out (pinned tiles)
+            const size_t per_image = ctx_bytes_per_image();
             const size_t images_per_queue = ((size_t)n_images + b->n_queues - 1) / b->n_queues;
             size_t per_queue = per_image * images_per_queue;
             size_t free_b = 0, total_b = 0;
@@ -441,6 +472,9 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
                 const size_t budget = (free_b + b->ctx_bytes) / 2;   // never more than half of what is left
                 if (per_queue * (size_t)b->n_queues > budget) per_queue = budget / (size_t)b->n_queues;
             }
+            // a primary with siblings never moves its arenas (a sibling may be decoding out of them right now): it lives with what
+            // fuifgpu_batch_create_sibling froze
+            if (!b->siblings.empty()) per_queue = std::min(per_queue, b->ctx_bytes / (size_t)b->n_queues);
             per_queue = std::min<size_t>(per_queue / 256 * 256, (size_t)0xFFFFFF00u / (size_t)b->n_queues * 256);
             b->ctx_units_per_queue = (uint32_t)(per_queue / 256);
             const size_t need = per_queue * (size_t)b->n_queues;
@@ -461,9 +495,10 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
     HIPCHK(hipStreamSynchronize(st));  // b->tiles / b->jobs may be rebuilt by the next upload
     // one persistent wavefront per tile up to what the device holds at once; each owns a scratch area
     if (b->share) {
-        // a sibling launches with the primary's decoder scratch: the primary must have been loaded with at least as many tiles
-        if (b->n_waves > b->share->scratch_waves) { g_last_error = "sibling batch: upload the primary first (its decoder scratch serves both)"; return FUIFGPU_E_ARG; }
+        // a sibling launches with the primary's decoder scratch, sized for the device's wavefront capacity when the sibling was created
+        if (b->n_waves > b->share->scratch_waves) { g_last_error = "sibling batch: more wavefronts than the primary's decoder scratch was sized for"; return FUIFGPU_E_ARG; }
     } else if (b->n_waves > b->scratch_waves) {
+        if (!b->siblings.empty()) { g_last_error = "primary batch with siblings: decoder scratch cannot grow (internal sizing error)"; return FUIFGPU_E_ARG; }
         hipFree(b->d_scratch); b->d_scratch = nullptr; b->scratch_waves = 0;
         HIPCHK(hipMalloc((void **)&b->d_scratch, b->scratch_stride * (size_t)b->n_waves));
         b->scratch_waves = b->n_waves;

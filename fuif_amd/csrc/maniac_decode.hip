@@ -181,7 +181,7 @@ struct Node {  // maniac/compound.h:41-51; property -1 = leaf, child = leaf id
 // loads (it sinks the splitval load behind the leaf test), doubling the per-level latency.
 #ifdef FUIF_EMU
 // emulator-only statistics (tools/emu_walk_stats.py): where the walk rounds behind the root supernode are served from
-extern unsigned long long g_emu_stats[6];   // symbols with a walk, rounds from LDS, rounds from scratch memory, suspended tiles, (FUIF_SPEC_LEAF) leaf switches, of them served from a speculated LDS slot
+extern unsigned long long g_emu_stats[6];   // symbols with a walk, rounds from LDS, rounds from scratch memory, suspended tiles (slots 4-5 unused)
 #define EMU_COUNT(k) do { if (lane == 0) __atomic_fetch_add(&g_emu_stats[k], 1ull, __ATOMIC_RELAXED); } while (0)
 static thread_local const char *emu_lds_base;   // LDS byte addresses are offsets from the supernode array in the emulator
 DEV uint2 lds_load_node(uint32_t lds_byte_addr) { return *reinterpret_cast<const uint2 *>(emu_lds_base + lds_byte_addr); }
@@ -198,73 +198,6 @@ DEV uint2 global_load_node(const void *p) {
     asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
-#endif
-
-#ifdef FUIF_SPEC_WALK
-// -DFUIF_SPEC_WALK (experiment, not the release build): the two LDS supernode slots of the dense configuration hold
-// SPECULATIVELY FETCHED second-level supernodes instead of the first two in breadth-first order (which 0.9 % of the walks
-// enter, profiles/r2_walk_locality.txt).  While pixel x is decoded, the root round of pixel x+1 is evaluated on the properties
-// that do not depend on x; every node that tests a left-dependent property is taken both ways, and the (up to two) second-level
-// supernodes that stay reachable are moved into the slots by LDS-DMA (global_load_lds_dwordx4: 32 lanes x 16 bytes, no
-// registers, nothing waited for).  The real walk of x+1 then finds its supernode in LDS for most symbols of the large groups
-// (1.9-2.0 reachable exits on average, profiles/r3_first_left_dependent_test.txt) and the supernode fetch leaves the
-// per-symbol dependency chain.  M0 and EXEC are restored inside the statement (see the leaf-slot experiment of round 3 for why
-// this is inline asm and not __builtin_amdgcn_global_load_lds).
-#ifdef FUIF_EMU
-DEV void dma_supernode(const uint2 *snodes, uint32_t sn, uint32_t lds_byte_addr, int lane) {
-    if (lane < 32) memcpy(const_cast<char *>(emu_lds_base) + lds_byte_addr + 16 * lane, reinterpret_cast<const char *>(snodes) + (size_t)sn * 512 + 16 * lane, 16);
-}
-DEV void wait_dma() {}
-#else
-DEV void dma_supernode(const uint2 *snodes, uint32_t sn, uint32_t lds_byte_addr, int lane) {
-    uint32_t keep_m0;
-    unsigned long long keep_exec;
-    const uint32_t voff = sn * 512u + (uint32_t)lane * 16u;
-    lds_byte_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_byte_addr);   // uniform, but the compiler cannot always see it: M0 needs an SGPR
-    unsigned long long lower32 = 0xFFFFFFFFull;   // an SGPR pair, not a literal: `s_mov_b64 exec, 0xffffffff` may assemble to the inline constant -1 = all 64 lanes
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\t"
-                 "s_mov_b64 %1, exec\n\ts_mov_b64 exec, %5\n\t"
-                 "global_load_lds_dwordx4 %2, %3\n\t"
-                 "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep_m0), "=&s"(keep_exec) : "v"(voff), "s"(snodes), "s"(lds_byte_addr), "s"(lower32) : "memory");
-}
-DEV void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-#endif
-#endif
-
-#ifdef FUIF_SPEC_LEAF
-// -DFUIF_SPEC_LEAF (experiment, not the release build; the WIDE configuration = streams without a group index, one wavefront per
-// image): there the second-level supernodes are resident in LDS, so while pixel x waits for ITS leaf the walk of pixel x+1 can
-// be carried two rounds deep on the properties that do not depend on x (unknown nodes taken both ways) and the chances of the
-// leaves it can end in are fetched into a few LDS leaf slots by LDS-DMA.  Simulated on the CPU restatement with the bench's tree
-// shapes: 43-58 % of the leaf switches find their leaf in one of four slots (profiles/r3_first_left_dependent_test.txt).
-// A copy is used at most once (a leaf changes only while it is the current one), is never taken of the current leaf nor of the
-// one whose write-back was just issued.
-constexpr int kSpecLeafSlots = 4;
-#ifdef FUIF_EMU
-DEV void dma_leaf(const uint16_t *leaves, uint32_t leaf, void *lds_slot, int lane) {
-    if (lane < 4) memcpy(static_cast<char *>(lds_slot) + 16 * lane, reinterpret_cast<const char *>(leaves) + (size_t)leaf * 64 + 16 * lane, 16);
-}
-#ifndef FUIF_SPEC_WALK
-DEV void wait_dma() {}
-#endif
-#else
-DEV void dma_leaf(const uint16_t *leaves, uint32_t leaf, void *lds_slot, int lane) {
-    uint32_t keep_m0;
-    unsigned long long keep_exec;
-    const uint32_t voff = leaf * 64u + (uint32_t)lane * 16u;
-    const uint32_t lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)lds_slot);   // uniform, but the compiler cannot see it: M0 needs an SGPR
-    unsigned long long four = 0xFull;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\t"
-                 "s_mov_b64 %1, exec\n\ts_mov_b64 exec, %5\n\t"
-                 "global_load_lds_dwordx4 %2, %3\n\t"
-                 "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep_m0), "=&s"(keep_exec) : "v"(voff), "s"(leaves), "s"(lds), "s"(four) : "memory");
-}
-#ifndef FUIF_SPEC_WALK
-DEV void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-#endif
-#endif
 #endif
 
 struct Frame {  // one pending inner node of the pre-order tree parse
@@ -606,11 +539,26 @@ DEV int fast_symbol(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
     "s_and_b32 %[t0], %[t0], 0xff\n\ts_lshl_b32 %[L], %[L], 8\n\ts_or_b32 %[L], %[L], %[t0]\n\ts_add_u32 %[widx], %[widx], 1\n\ts_lshl_b32 %[R], %[R], 8\n\t" \
     "s_branch " back "\n\t"
 #define FS_RN_CHECK(lbl, back) "s_cmp_le_u32 %[R], 0x10000\n\ts_cbranch_scc1 " lbl "\n" back ":\n\t"
+// Sensitivity probes (diagnostic builds only, tools/experiments/r4_2_probes.sh): N extra instructions of one kind per decoded symbol,
+// on scratch registers of the block -- what one more scalar / vector instruction / taken branch costs the LAUNCH, measured
+// instead of guessed (round 3: instruction trims made the launch slower, so the derivative is worth knowing before trimming).
+#define FS_STR2(x) #x
+#define FS_STR(x) FS_STR2(x)
+#if defined(FUIF_PROBE_S)
+#define FS_PROBE ".rept " FS_STR(FUIF_PROBE_S) "\n\ts_add_u32 %[t0], %[t0], 1\n\t.endr\n\t"
+#elif defined(FUIF_PROBE_V)
+#define FS_PROBE ".rept " FS_STR(FUIF_PROBE_V) "\n\tv_add_u32 " FS_VB ", " FS_VB ", " FS_VB "\n\t.endr\n\t"
+#elif defined(FUIF_PROBE_B)
+#define FS_PROBE ".rept " FS_STR(FUIF_PROBE_B) "\n\ts_branch 1f\n\ts_nop 0\n1:\n\t.endr\n\t"
+#else
+#define FS_PROBE
+#endif
 DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
     uint32_t R = r.range, Lo = r.low, widx = s.pos - s.win_base;
     uint32_t res, touched, bits, t0, t1, thr, e, amax, emax, sign, have, one, skipped;
     asm volatile(
         "v_mov_b32 " FS_VK0 ", 0x800\n\tv_mov_b32 " FS_VK1 ", 0\n\t"
+        FS_PROBE
         // ---- zero?  (chance 0)
         FS_THR_PREP "s_nop 0\n\tv_readlane_b32 %[thr], " FS_VA ", 0\n\t"
         "s_cmp_ge_u32 %[L], %[thr]\n\ts_cbranch_scc1 70f\n\t"
@@ -722,9 +670,6 @@ struct Shared {
     uint16_t meta_ctx[3][32];            // three SimpleSymbolCoder contexts of the tree coder
     int32_t lo[kMaxProps], hi[kMaxProps];
     RefChan refs[kMaxRefs];
-#ifdef FUIF_SPEC_LEAF
-    uint16_t spec_leaf[kSpecLeafSlots * kLeafStride];   // speculatively fetched leaf chances (64 bytes each)
-#endif
 };
 
 // kHandOff = false: every image is one tile, nothing a tile writes is read by another one before the
@@ -748,16 +693,6 @@ template <int kLdsSuper, bool kHandOff>
 __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParams P) {
     __shared__ Shared<kLdsSuper> sh;
     constexpr int kChunk = Shared<kLdsSuper>::kChunk;
-#ifdef FUIF_SPEC_LEAF
-    constexpr bool kSpecLeaf = (kLdsSuper != kLdsDense);   // the wide configuration speculates on leaves
-#else
-    constexpr bool kSpecLeaf = false;
-#endif
-#ifdef FUIF_SPEC_WALK
-    constexpr bool kSpec = (kLdsSuper == kLdsDense);   // the dense configuration's two LDS slots hold speculatively fetched supernodes
-#else
-    constexpr bool kSpec = false;
-#endif
     const int lane = threadIdx.x;
 
     const uint16_t *tree_table = P.tables;          // cut 2, alpha 0xFFFFFFFF/19 (compound.h:262)
@@ -1190,12 +1125,10 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         int predictability = 2048;
         Rac rac;
         int tree_size = 1, n_super = 1, cur_leaf = 0;
-        uint32_t lf_t0 = 0xFFFFFFFFu, lf_t1 = 0xFFFFFFFFu, lf_t2 = 0xFFFFFFFFu, lf_t3 = 0xFFFFFFFFu, lf_victim = 0, lf_prev_wb = 0xFFFFFFFFu;   // FUIF_SPEC_LEAF: leaves in the LDS leaf slots, the leaf written back last
-        uint32_t pf_tag0 = 0, pf_tag1 = 0, pf_victim = 0;   // FUIF_SPEC_WALK: which supernodes the two LDS slots hold (0 = none), which slot goes next
         if (resumed) {
             rac.range = rflu(rec->range); rac.low = rflu(rec->low);
             tree_size = rfl((int)rec->tree_size); n_super = rfl((int)rec->n_super); cur_leaf = rfl((int)rec->cur_leaf);
-            if (!kSpec) for (int sn = 1; sn <= kLdsSuper && sn < n_super; sn++) sh.snodes[(sn - 1) * 64 + lane] = snodes_g[(size_t)sn * 64 + lane];
+            for (int sn = 1; sn <= kLdsSuper && sn < n_super; sn++) sh.snodes[(sn - 1) * 64 + lane] = snodes_g[(size_t)sn * 64 + lane];
             __syncthreads();
         }
         if (!resumed) {
@@ -1276,6 +1209,9 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                     tree_size += 2;
                     depth++;
                     pos = child;
+                    // sign of life for the stall verdicts while a big tree is parsed (up to 65535 nodes: tens of milliseconds without a
+                    // finished row) -- the row loops bump the same word through publish()
+                    if (kHandOff && lane == 0 && (tree_size & 1023) == 1) atomicAdd(P.heartbeat, 1u);
                     __syncthreads();
                     continue;
                 }
@@ -1375,6 +1311,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
             if (lane == 0) queue[0] = 0;
             __syncthreads();
             for (int sn = 0; sn < n_super; sn++) {
+                if (kHandOff && lane == 0 && (sn & 255) == 255) atomicAdd(P.heartbeat, 1u);   // (see the tree parse)
                 if (lane == 0) slot_node[0] = queue[sn];
                 st_split[lane] = 0x7FFFFFFF;
                 st_prop[lane] = 0;
@@ -1419,7 +1356,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 out.x = (uint32_t)(is_raw_slog_prop(st_prop[lane] - nrefprops) && st_split[lane] != 0x7FFFFFFF ? slog_threshold(st_split[lane]) : st_split[lane]);
                 out.y = ((uint32_t)st_prop[lane] & 0xFFu) | (tgt << 8);
                 snodes_g[(size_t)sn * 64 + lane] = out;
-                if (!kSpec && sn >= 1 && sn <= kLdsSuper) sh.snodes[(sn - 1) * 64 + lane] = out;   // the root (0) lives in registers: LDS holds 1..kLdsSuper
+                if (sn >= 1 && sn <= kLdsSuper) sh.snodes[(sn - 1) * 64 + lane] = out;   // the root (0) lives in registers: LDS holds 1..kLdsSuper
                 __syncthreads();
             }
         }
@@ -1439,37 +1376,11 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         L.leafv = (lane < 32) ? (int)leaves[(int64_t)cur_leaf * kLeafStride + lane] : 0;
         L.touched = 0; L.bits = 0;
         auto switch_leaf = [&](int id) {
-#ifdef FUIF_SPEC_LEAF
-            if (kSpecLeaf) {
-                if (LIKELY(id != cur_leaf)) {
-                    EMU_COUNT(4);
-                    if (lane < 32) leaves[(int64_t)cur_leaf * kLeafStride + lane] = (uint16_t)L.leafv;
-                    lf_prev_wb = (uint32_t)cur_leaf;
-                    const uint32_t uid = (uint32_t)id;
-                    const int slot = uid == lf_t0 ? 0 : uid == lf_t1 ? 1 : uid == lf_t2 ? 2 : uid == lf_t3 ? 3 : -1;
-                    if (slot >= 0) {
-                        // the copy was fetched after the leaf's last write-back and the leaf has not been current since: use it once
-                        wait_dma();
-                        if (lane < 32) L.leafv = (int)sh.spec_leaf[slot * kLeafStride + lane];
-                        if (slot == 0) lf_t0 = 0xFFFFFFFFu; else if (slot == 1) lf_t1 = 0xFFFFFFFFu; else if (slot == 2) lf_t2 = 0xFFFFFFFFu; else lf_t3 = 0xFFFFFFFFu;
-                        EMU_COUNT(5);
-                    } else if (lane < 32) L.leafv = (int)leaves[(int64_t)id * kLeafStride + lane];
-                    cur_leaf = id;
-                }
-                return;
-            }
-#endif
             if (LIKELY(id != cur_leaf)) {
-#ifndef FUIF_EXP_NOLEAFLOAD   // (experiments: what the leaf traffic costs -- FUIF_EXP_NOLEAFLOAD / _NOLEAFSTORE / _NOLEAFFETCH decode garbage)
                 if (lane < 32) {
-#ifndef FUIF_EXP_NOLEAFSTORE
                     leaves[(int64_t)cur_leaf * kLeafStride + lane] = (uint16_t)L.leafv;
-#endif
-#ifndef FUIF_EXP_NOLEAFFETCH
                     L.leafv = (int)leaves[(int64_t)id * kLeafStride + lane];
-#endif
                 }
-#endif
                 cur_leaf = id;
             }
         };
@@ -1561,21 +1472,6 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                         const bool f_abs = (kloc == 1);
                         const int c_left = ((kloc == 1) | (kloc == 3) | (kloc == 12) | (y ? ((kloc == 6) | (kloc == 8)) : ((kloc == 7) | (kloc == 9)))) ? 1 : 0;
                         const int c_ll = (kloc == 12) ? -1 : 0;
-                        uint32_t unk_lo = 0, unk_hi = 0;   // FUIF_SPEC_WALK: the root supernode's nodes that test a left-dependent property (in this row)
-                        bool spec_row = kSpec;
-#if defined(FUIF_SPEC_WALK) && (FUIF_SPEC_WALK + 0) >= 2
-                        // -DFUIF_SPEC_WALK=2: speculate only while this SIMD holds few wavefronts (the tail of a launch): with all six
-                        // resident the scalar pipe is the contended resource and the ~30 extra instructions per symbol are not free
-#ifndef FUIF_SPEC_MAX_ALIVE
-#define FUIF_SPEC_MAX_ALIVE 4
-#endif
-                        if (kSpec && P.cu_alive) spec_row = rflu(ld_agent(&P.cu_alive[simd_key])) <= (uint32_t)FUIF_SPEC_MAX_ALIVE;
-#endif
-                        if (kSpec) {
-                            const int dn = __builtin_amdgcn_ds_bpermute((int)((root_nd.y & 0xFFu) << 2), (c_left | (c_ll != 0)) ? 1 : 0);
-                            const unsigned long long u = __ballot(dn != 0);
-                            unk_lo = (uint32_t)u; unk_hi = (uint32_t)(u >> 32);
-                        }
                         for (int x0 = 0; x0 < w; x0 += kChunk) {
                             const int nx = min(kChunk, w - x0);
                             // ---- vector phase: lane j prepares pixel x0+j ------------------------
@@ -1658,24 +1554,14 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                     uint32_t tgt = walk_round(root_nd);
                                     EMU_COUNT(0);
                                     while (!(tgt & (kLeafFlag | kSlowFlag))) {
-                                        if (!kSpec) EMU_COUNT(tgt <= (uint32_t)kLdsSuper ? 1 : 2);
+                                        EMU_COUNT(tgt <= (uint32_t)kLdsSuper ? 1 : 2);
                                         // LDS-resident supernodes are the common case; the load is issued unconditionally
                                         // (index clamped) and replaced in the rare deep case
                                         // (supernode i sits in LDS slot i-1: the -512 folds into the base address)
                                         uint2 nd;
-#ifdef FUIF_SPEC_WALK
-                                        if (kSpec) {
-                                            // a slot holds this supernode if the speculative walk of the previous pixel fetched it
-                                            const bool h0 = tgt == pf_tag0, h1 = tgt == pf_tag1;
-                                            if (h0 | h1) { wait_dma(); nd = lds_load_node(lds_nodes_addr + (h0 ? 0u : 512u) + (uint32_t)lane * 8u); EMU_COUNT(1); }
-                                            else { nd = global_load_node(&snodes_g[(size_t)tgt * 64 + lane]); EMU_COUNT(2); }
-                                        } else
-#endif
-                                        {
                                         const uint32_t li = tgt <= (uint32_t)kLdsSuper ? tgt : (uint32_t)kLdsSuper;
                                         nd = lds_load_node(lds_nodes_addr + (li - 1u) * 512u + (uint32_t)lane * 8u);
                                         if (UNLIKELY(tgt > (uint32_t)kLdsSuper)) nd = global_load_node(&snodes_g[(size_t)tgt * 64 + lane]);
-                                        }
                                         tgt = walk_round(nd);
                                     }
                                     if (UNLIKELY(tgt & kSlowFlag)) {
@@ -1700,75 +1586,6 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                     prof_acc[7] += (unsigned)rdlane(L.leafv, 0) & 0u;  // force the leaf load to complete inside this lap
 #endif
                                     PROF_LAP(3);
-#ifdef FUIF_SPEC_LEAF
-                                    if (kSpecLeaf && tree_size > 1 && j + 1 < nx) {
-                                        const int depflag = (c_left | (c_ll != 0)) ? 1 : 0;   // per property lane: depends on the pixel being decoded
-                                        const int pvn = sh.cprops[(j + 1) * kPropPitch + (lane & 31)];
-                                        auto prefetch_leaf = [&](uint32_t lf) {
-                                            if (lf == (uint32_t)cur_leaf || lf == lf_prev_wb || lf == lf_t0 || lf == lf_t1 || lf == lf_t2 || lf == lf_t3) return;
-                                            dma_leaf(leaves, lf, &sh.spec_leaf[lf_victim * kLeafStride], lane);
-                                            if (lf_victim == 0) lf_t0 = lf; else if (lf_victim == 1) lf_t1 = lf; else if (lf_victim == 2) lf_t2 = lf; else lf_t3 = lf;
-                                            lf_victim = (lf_victim + 1u) & 3u;
-                                        };
-                                        // candidates of one supernode: the exits its KNOWN decisions leave reachable, lowest lane first
-                                        auto spec_cands = [&](const uint2 nd) -> unsigned long long {
-                                            const int sel = (int)((nd.y & 0xFFu) << 2);
-                                            const unsigned long long unk = __ballot(__builtin_amdgcn_ds_bpermute(sel, depflag) != 0);
-                                            const unsigned long long mm = __ballot(__builtin_amdgcn_ds_bpermute(sel, pvn) > (int)nd.x);
-                                            const uint32_t klo = (uint32_t)mm & ~(uint32_t)unk, khi = (uint32_t)(mm >> 32) & ~(uint32_t)(unk >> 32);
-                                            const uint32_t elo = exp_lo & ~(uint32_t)unk, ehi = exp_hi & ~(uint32_t)(unk >> 32);
-                                            const bool reach = ((((klo ^ elo) & msk_lo) | ((khi ^ ehi) & msk_hi)) == 0u);
-                                            return __ballot(reach);
-                                        };
-                                        unsigned long long c1 = spec_cands(root_nd);
-#pragma unroll
-                                        for (int k = 0; k < 2; k++) {
-                                            if (c1) {
-                                                const int e = __builtin_ctzll(c1);
-                                                c1 &= c1 - 1;
-                                                const uint32_t t = (uint32_t)rdlane((int)root_nd.y, e) >> 8;
-                                                if (t & kLeafFlag) prefetch_leaf(t & (kLeafFlag - 1u));
-                                                else if (!(t & kSlowFlag) && t <= (uint32_t)kLdsSuper) {
-                                                    const uint2 nd2 = lds_load_node(lds_nodes_addr + (t - 1u) * 512u + (uint32_t)lane * 8u);
-                                                    unsigned long long c2 = spec_cands(nd2);
-#pragma unroll
-                                                    for (int q = 0; q < 2; q++) {
-                                                        if (c2) {
-                                                            const int e2 = __builtin_ctzll(c2);
-                                                            c2 &= c2 - 1;
-                                                            const uint32_t t2 = (uint32_t)rdlane((int)nd2.y, e2) >> 8;
-                                                            if (t2 & kLeafFlag) prefetch_leaf(t2 & (kLeafFlag - 1u));
-                                                        }
-                                                    }
-                                                }
-                                            }
-                                        }
-                                    }
-#endif
-#ifdef FUIF_SPEC_WALK
-                                    if (kSpec && spec_row && n_super > 1 && j + 1 < nx) {   // (a tree that fits the root supernode has nothing to fetch)
-                                        // root round of pixel j+1 on the properties that do not depend on pixel j; unknown nodes go both ways
-                                        const int pvn = sh.cprops[(j + 1) * kPropPitch + (lane & 31)];
-                                        const int valn = __builtin_amdgcn_ds_bpermute((int)((root_nd.y & 0xFFu) << 2), pvn);
-                                        const unsigned long long mm = __ballot(valn > (int)root_nd.x);
-                                        const uint32_t klo = (uint32_t)mm, khi = (uint32_t)(mm >> 32);
-                                        const bool reach = ((((klo ^ exp_lo) & msk_lo & ~unk_lo) | ((khi ^ exp_hi) & msk_hi & ~unk_hi)) == 0u);
-                                        unsigned long long cand = __ballot(reach);
-#pragma unroll
-                                        for (int k = 0; k < 2; k++) {
-                                            if (cand) {
-                                                const int e = __builtin_ctzll(cand);
-                                                cand &= cand - 1;
-                                                const uint32_t t = (uint32_t)rdlane((int)root_nd.y, e) >> 8;
-                                                if (!(t & (kLeafFlag | kSlowFlag)) && t != pf_tag0 && t != pf_tag1) {
-                                                    dma_supernode(snodes_g, t, lds_nodes_addr + pf_victim * 512u, lane);
-                                                    if (pf_victim) pf_tag1 = t; else pf_tag0 = t;
-                                                    pf_victim ^= 1u;
-                                                }
-                                            }
-                                        }
-                                    }
-#endif
                                     if (PRED0 && sym_fast && LIKELY(s.pos + 64u <= s.size)) {
                                         // the symbol's bytes (at most 62) are in the stream; keep them in the window registers
                                         // (the reload starts at a 4-byte boundary; the 256 bytes it reads lie inside the allocation)

@@ -482,10 +482,11 @@ int maniac_encode_jobs_gpu(std::vector<EncJob> &jobs, const uint16_t *pixel_tabl
         first[nj] = (uint32_t)blocks;
         if (blocks > 0x7FFFFFFFull) rc = FUIFGPU_E_ARG;   // > 5 * 10^11 pixels in one batch: split it
         ECHK(hipMemcpy(arena + off_first, first.data(), sizeof(uint32_t) * (nj + 1), hipMemcpyHostToDevice));
-        if (rc == FUIFGPU_OK)
+        if (rc == FUIFGPU_OK) {   // the coder reads what the model kernel wrote: it only runs behind it (never on uninitialised guesses)
             hipLaunchKernelGGL(k_enc_model_jobs, dim3((unsigned)blocks), dim3(256), 0, nullptr, d_jobs, reinterpret_cast<const uint32_t *>(arena + off_first), (int)nj);
-        hipLaunchKernelGGL(k_enc_rac_jobs, dim3((unsigned)nj), dim3(64), 0, nullptr, d_jobs, d_table);
-        ECHK(hipGetLastError());
+            hipLaunchKernelGGL(k_enc_rac_jobs, dim3((unsigned)nj), dim3(64), 0, nullptr, d_jobs, d_table);
+            ECHK(hipGetLastError());
+        }
     }
     std::vector<uint32_t> states(8 * nj);
     ECHK(hipMemcpy(states.data(), arena + off_states, 32 * nj, hipMemcpyDeviceToHost));   // synchronises with the null stream's kernels

@@ -674,7 +674,17 @@ struct Builder {
             const int wo = h1.src[0].w + h1.src[1].w, h = h1.src[0].h;
             if (c.p0 != wo || c.p1 != h || c.src[0].w != wo || c.src[0].h != h || h1.dst[0].w != wo || h2.dst[0].w != wo) continue;
             if (h1.src[1].w < 1 || h1.src[0].buf < 0 || h1.src[1].buf < 0 || h2.src[1].buf < 0) continue;
-            // the Y plane must not be one of the chroma inputs, and the chroma inputs must not be the outputs
+            // The fused kernel reads its four chroma inputs tile by tile while other blocks already write R, G, B: no input
+            // range may overlap an output range (first-fit TMP planes can land on a plane released just before -- ADVICE r3).
+            // In-place on Y alone is fine: a block reads the Y samples of its own tile before it writes them.
+            auto overlaps = [](const PlaneRef &a, const PlaneRef &b) {
+                return a.buf == b.buf && a.off < b.off + (int64_t)b.w * b.h && b.off < a.off + (int64_t)a.w * a.h;
+            };
+            const PlaneRef ins[4] = {h1.src[0], h1.src[1], h2.src[0], h2.src[1]}, outs[3] = {c.src[0], c.src[1], c.src[2]};
+            bool alias = false;
+            for (const PlaneRef &i : ins) for (const PlaneRef &o : outs) alias = alias || overlaps(i, o);
+            for (int a = 0; a < 3; a++) for (int b2 = a + 1; b2 < 3; b2++) alias = alias || overlaps(outs[a], outs[b2]);
+            if (alias) continue;
             Op f{};
             f.kind = OP_HSQ2_YCOCG;
             f.lo = c.lo; f.hi = c.hi; f.p0 = wo; f.p1 = h;
@@ -865,7 +875,7 @@ int parse_and_plan(const uint8_t *blob, size_t n, Plan &plan) {
         plan.h < 1 || (int64_t)plan.w * plan.h > 0x7fffffffLL || plan.max_properties < 0 ||
         plan.max_properties > 2 * kMaxRefs) {
         plan.error = (plan.max_properties > 2 * kMaxRefs) ? FUIFGPU_E_UNSUPPORTED : FUIFGPU_E_CORRUPT;
-        plan.message = "implausible header";
+        plan.message = (plan.error == FUIFGPU_E_UNSUPPORTED) ? "more reference properties (-E) than the pixel loop's property lanes hold" : "implausible header";
         return plan.error;
     }
     plan.minval = 0;

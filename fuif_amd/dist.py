@@ -17,12 +17,26 @@ def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init(backend=None, device=None):
-    """init_process_group from the torchrun environment; returns the dist module or None (world 1)."""
+def init(backend=None, device=None, world1=False):
+    """init_process_group from the torchrun environment; returns the dist module or None (world 1).
+    world1=True: a single process still gets a process group of ONE rank (rendezvous on 127.0.0.1, a free port), so that
+    every collective of the N>1 path -- barrier, all_reduce, all_gather, the chunked gather of the packed pictures -- runs
+    through the real backend (RCCL on a GPU) on the one device there is: the RCCL / HIP-runtime self-check of bench.py and
+    tests/test_gpu_rccl_world1.py."""
     rank, local_rank, world = env_world()
-    if world == 1:
+    if world == 1 and not world1:
         return None
     import torch.distributed as dist
+    if world == 1 and "MASTER_PORT" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("LOCAL_RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     if not dist.is_initialized():
         if backend is None:
             backend = "nccl" if (device is not None and device.type == "cuda") else "gloo"

@@ -113,7 +113,7 @@ def encode_jpeg_like(rgb, quality=90, subsample420=True, tree_mode=1, max_proper
     words += [4, 0, 5, 0]                    # DCT (default parameters), Quantize
     arr = (RawChannel * len(chans))(*chans)
     tw = np.array(words, np.int32)
-    opt = fuif_amd.EncodeOptions(0, 1, max_properties, tree_mode, 4095, int(index), int(fuif_amd.DEFAULT_SPLIT_BITS), 0, 0)
+    opt = fuif_amd.make_encode_options(0, 1, max_properties, tree_mode, 4095, int(index), int(fuif_amd.DEFAULT_SPLIT_BITS), 0, 0)
     out, n = C.c_void_p(), C.c_size_t(0)
     L.fuifgpu_encode_channels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                           C.POINTER(fuif_amd.EncodeOptions), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]

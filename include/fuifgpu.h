@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define FUIFGPU_ABI_VERSION 1
+#define FUIFGPU_ABI_VERSION 2   /* 2 (round 4): fuifgpu_encode_options starts with struct_size; sibling batches freeze the launch resources */
 
 /* error codes (0 = success).  The reference reports these conditions as `return false` +
  * e_printf (encoding/encoding.cpp:601-605, 276-279, 697-700). */
@@ -87,7 +87,10 @@ void fuifgpu_batch_destroy(fuifgpu_batch *batch);
  * stream, from another host thread) runs while the previous batch decodes: the sibling owns what fuifgpu_batch_upload writes
  * (stream bytes, tile lists, per-image status / consumed / metadata) and launches with the primary's coefficient and output
  * slabs, decoder scratch, context arenas and transform arena -- ~12 MB per 4K stream instead of a second 45 GB of launch state.
- * Rules: upload the primary once before the sibling's first upload (its scratch serves both); decode / undo_transforms of the
+ * Creating the first sibling sizes the primary's decoder scratch and context arenas for the worst case (the device's wavefront
+ * capacity, a full batch) and they never move again while a sibling exists, so an upload into one batch on another host thread
+ * cannot pull them from under a decode of the other; either batch may be loaded first, with any number of images <= n_images.
+ * Rules: decode / undo_transforms of the
  * two on ONE stream (they share the slabs); destroy the sibling first (a sibling that outlives its primary refuses every call).  The pattern, per step k: thread U uploads into batch
  * (k+1)%2 on the copy stream while the caller runs decode + undo_transforms of batch k%2; join; consume; repeat
  * (bench.py's `value_incl_h2d`, tests/test_gpu_synthetic.py).  The reference has no counterpart: it reads one file at a time
@@ -216,6 +219,11 @@ int fuifgpu_fwd_vsqueeze(const int32_t *in, int w, int h, int32_t *avg, int32_t 
  * tree_mode 0 = single-leaf MANIAC trees (byte-identical to `fuif -I 0`), 1 = trees learned by the
  * writer's own greedy learner.  *blob_out is malloc'd; release with fuifgpu_free_blob. */
 typedef struct {
+    uint32_t struct_size;   /* = sizeof(fuifgpu_encode_options) of the CALLER's header.  The library reads that many bytes and takes
+                               every field behind them as 0, so the struct can grow at its end without breaking callers built
+                               against an older header (ABI 2, round 4: round 3 appended gpu_entropy to the unversioned struct and a
+                               caller built before that had 4 bytes read past its object).  0 or a size that is not a multiple of
+                               4 is FUIFGPU_E_ARG. */
     int32_t ycocg;          /* 1: YCoCg when nch >= 3 (CLI default) */
     int32_t squeeze;        /* 1: default Squeeze (CLI default "responsive") */
     int32_t max_properties; /* CLI default 12 (-E) */

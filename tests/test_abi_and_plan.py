@@ -17,7 +17,7 @@ def test_header_symbols_exported(gpulib):
     L = ctypes.CDLL(os.path.join(ROOT, "fuif_amd", "libfuifgpu.so"))
     for s in declared:
         assert hasattr(L, s), s
-    assert gpulib.lib().fuifgpu_abi_version() == 1
+    assert gpulib.lib().fuifgpu_abi_version() == 2
 
 
 def test_plan_matches_reference_geometry(gpulib, manifest):
@@ -104,10 +104,42 @@ def test_header_is_plain_c(tmp_path):
     if not shutil.which("gcc"):
         pytest.skip("no gcc")
     src = tmp_path / "abi.c"
-    src.write_text('#include "fuifgpu.h"\nint use(void) { fuifgpu_encode_options o; (void)o; return FUIFGPU_OK + (int)sizeof(fuifgpu_image_info); }\n')
+    src.write_text('#include "fuifgpu.h"\nint use(void) { fuifgpu_encode_options o; (void)o; return FUIFGPU_OK + (int)sizeof(fuifgpu_image_info); }\n'
+                   'typedef char encode_options_are_40_bytes[sizeof(fuifgpu_encode_options) == 40 ? 1 : -1];\n')
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_encode_options_are_versioned_by_their_size(gpulib):
+    """fuifgpu_encode_options::struct_size (ADVICE r3: the struct once grew without a version and old callers had bytes read past
+    their object): 10 x 4 bytes today, pinned; a caller built against a header that ends before gpu_entropy passes a shorter
+    struct -- the library must not look behind it (here: a sentinel that would select the GPU coder and fail on this host)"""
+    import ctypes as C
+    import numpy as np
+    from fuif_amd.synth import photographic
+    assert C.sizeof(gpulib.EncodeOptions) == 40
+    img = np.ascontiguousarray(photographic(48, 40, 3, 8, seed=12), dtype=np.int32)
+    full = gpulib.encode_image(img, 8, tree_mode=0)
+
+    def call(raw):
+        out, n = C.c_void_p(), C.c_size_t(0)
+        rc = gpulib.lib().fuifgpu_encode_image(img.ctypes.data, 48, 40, 3, 8, C.cast(raw, C.POINTER(gpulib.EncodeOptions)), C.byref(out), C.byref(n))
+        blob = C.string_at(out.value, n.value) if rc == 0 else None
+        if rc == 0:
+            gpulib.lib().fuifgpu_free_blob(out)
+        return rc, blob
+    # struct_size 36 = every field up to gpu_forward; the 4 bytes behind it hold garbage that must not be read as gpu_entropy
+    words = (C.c_int32 * 10)(36, 1, 1, 12, 0, 4095, 0, int(gpulib.DEFAULT_SPLIT_BITS), 0, 0x7fffffff)
+    rc, blob = call(words)
+    assert rc == 0 and blob == full
+    for bad in (0, 4, 38):
+        words[0] = bad
+        assert call(words)[0] == 4   # FUIFGPU_E_ARG
+    words[0] = 400                   # a NEWER caller: the fields this library knows are read, the rest ignored
+    words[9] = 0
+    rc, blob = call((C.c_int32 * 100)(*list(words)))
+    assert rc == 0 and blob == full
 
 
 def test_fp64_kernels_are_not_contracted(tmp_path):

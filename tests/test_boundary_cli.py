@@ -18,11 +18,14 @@ def run_cli(args, fallback=False):
     env = dict(os.environ)
     if os.path.exists("/opt/conda/lib/libjpeg.so.9"):
         env["LD_PRELOAD"] = "/opt/conda/lib/libjpeg.so.9"
-    # no silent CPU route: a stream the GPU planner rejects makes the CLI fail instead of quietly running the reference's
-    # decoder (which would keep these tests green without the GPU path); FUIFGPU_VERBOSE makes the path taken visible
+    # no environment switch: by DEFAULT a stream the GPU planner rejects makes the CLI fail instead of quietly running the
+    # reference's decoder (which would keep these tests green without the GPU path); FUIFGPU_ALLOW_CPU_FALLBACK=1 is the opt-in;
+    # FUIFGPU_VERBOSE makes the path taken visible
     env["FUIFGPU_VERBOSE"] = "1"
-    if not fallback:
-        env["FUIFGPU_NO_CPU_FALLBACK"] = "1"
+    env.pop("FUIFGPU_ALLOW_CPU_FALLBACK", None)
+    env.pop("FUIFGPU_NO_CPU_FALLBACK", None)
+    if fallback:
+        env["FUIFGPU_ALLOW_CPU_FALLBACK"] = "1"
     return subprocess.run([CLI] + args, env=env, capture_output=True, text=True, timeout=300)
 
 
@@ -118,8 +121,8 @@ def test_reference_cli_yuv_output_uses_the_per_transform_binding(tmp_path):
     r = run_cli(["-d", src, a])
     assert r.returncode == 0, r.stdout + r.stderr
     # undo_transforms(2) keeps the colour transform and the chroma subsampling: Squeeze, Quantization and DCT are undone, each
-    # through its GPU entry point (the CLI runs with FUIFGPU_NO_CPU_FALLBACK=1: a transform this layer binds may not fall
-    # back to the reference's loop silently)
+    # through its GPU entry point (the CLI runs with no environment switch: by default a transform this layer binds may not
+    # fall back to the reference's loop)
     for name in ("Squeeze", "Quantization", "DCT"):
         assert "inverse %s on the GPU (Transform::apply)" % name in r.stderr, r.stderr
     assert "with the reference's CPU code" not in r.stderr
@@ -151,7 +154,7 @@ def test_batch_entry_decodes_many_files_in_one_launch(tmp_path):
         files.append(str(p))
     others = ["jpeg420_256x192_q90", "pal_rgb_graphic_120x90", "rgba14_80x72"]
     files += [os.path.join(GOLDEN, n + ".fuif") for n in others]
-    r = subprocess.run([batch_cli, str(outdir)] + files, env=dict(env, FUIFGPU_VERBOSE="1", FUIFGPU_NO_CPU_FALLBACK="1"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([batch_cli, str(outdir)] + files, env=dict(env, FUIFGPU_VERBOSE="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-800:]
     assert "40 file(s) of 512x512 decoded in one batch on the GPU" in r.stderr
     expect = {}
@@ -164,3 +167,28 @@ def test_batch_entry_decodes_many_files_in_one_launch(tmp_path):
         assert open(str(outdir / ("c1_%02d.pam" % k)), "rb").read() == expect["c1_00"]
     for n in others:
         assert open(str(outdir / (n + ".pam")), "rb").read() == expect[n], n
+
+
+OUTSIDE = os.path.join(GOLDEN, "outside_gpu_scope_rgb8_64x48_E64.fuif")   # written by `fuif -E 64`: more reference properties than the GPU path takes
+OUTSIDE_PPM_SHA256 = "5200e0a07cf1683c449896c13553d91b9f1881553aba0d98cd7aaee9ecedc274"   # what the unmodified reference CLI decodes it to (= the source picture)
+
+
+def check_cpu_route_is_opt_in(run, tmp_path):
+    """shared with tests/test_emulated_kernels.py (CPU): default = loud error and no output file; FUIFGPU_ALLOW_CPU_FALLBACK=1 = the
+    reference's own decoder, announced on stderr, writing the file the unmodified reference CLI writes"""
+    import hashlib
+    out = str(tmp_path / "outside.ppm")
+    r = run(["-d", OUTSIDE, out], False)
+    assert r.returncode != 0 and "FUIFGPU_ALLOW_CPU_FALLBACK" in (r.stdout + r.stderr), r.stdout + r.stderr
+    assert "reference's CPU code" not in r.stderr.replace("to decode it with the reference's CPU code", "")
+    assert not os.path.exists(out) or os.path.getsize(out) == 0
+    r = run(["-d", OUTSIDE, out], True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "decoding with the reference's CPU code" in r.stderr
+    assert hashlib.sha256(open(out, "rb").read()).hexdigest() == OUTSIDE_PPM_SHA256
+
+
+@pytest.mark.gpu
+def test_cpu_route_is_opt_in(tmp_path):
+    need_cli()
+    check_cpu_route_is_opt_in(lambda args, fb: run_cli(args, fallback=fb), tmp_path)

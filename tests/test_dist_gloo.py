@@ -120,3 +120,27 @@ def test_two_rank_gather_of_packed_pictures_of_two_geometries():
         assert p.exitcode == 0
     assert res[1] is None                        # only the root holds the gathered pictures
     assert res[0] == payloads                    # byte for byte, in rank order
+
+
+def _world1_worker(q):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    dev = torch.device("cpu")
+    assert fd.init(device=dev) is None                       # the plain one-process case: no process group
+    dist = fd.init(backend="gloo", device=dev, world1=True)   # the self-check form: a group of ONE rank on the real backend
+    local = torch.arange(1000, dtype=torch.int64).to(torch.uint8)
+    kept = fd.gather_packed(local, dist, chunk_bytes=300, keep=True)
+    sums = fd.gather_packed(local, dist, chunk_bytes=300, keep=False)
+    q.put((dist.get_world_size(), torch.equal(kept[0], local), sums == [int(local.sum(dtype=torch.int64))], fd.max_over_ranks(0.5, dist, dev), fd.all_ok(True, dist, dev)))
+    dist.destroy_process_group()
+
+
+def test_world_size_one_process_group_runs_the_collectives():
+    """fd.init(world1=True): what bench.py's RCCL self-check and tests/test_gpu_rccl_world1.py use on one GPU, here on gloo"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_world1_worker, args=(q,))
+    p.start()
+    res = q.get(timeout=120)
+    p.join(60)
+    assert res == (1, True, True, 0.5, True)

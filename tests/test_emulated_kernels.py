@@ -83,6 +83,26 @@ def test_tile_hand_off_with_concurrent_emulated_wavefronts():
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
+@pytest.mark.parametrize("ctx_kb", ["0", "64"])
+def test_pinned_tiles_with_concurrent_emulated_wavefronts(ctx_kb):
+    """FUIFGPU_CTX_KB=0 / 64: the context arenas are empty / run out after the first tiles, so suspendable tiles are PINNED to the
+    wavefront that started them (maniac_decode.hip, pinned_tix).  Four persistent emulated wavefronts really suspend and resume
+    them; the dense group-parallel cases must decode as with full arenas (ADVICE r2's deadlock)."""
+    if sys.platform != "linux" or os.uname().machine != "x86_64":
+        pytest.skip("the emulator's context switch is x86-64 SysV assembly")
+    lib = build_emulated_library()
+    env = dict(os.environ)
+    env.update(FUIF_AMD_LIB=lib, FUIF_TEST_MAX_PIXELS="50000", FUIF_TEST_BATCH="12", FUIF_TEST_PINNED_BATCH="3", EMU_ALARM="1500", EMU_WAVES="4", EMU_THREADS="4",
+               FUIFGPU_CTX_KB=ctx_kb)
+    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+           "tests/test_gpu_group_parallel.py::test_reference_written_files_indexed_after_the_fact",
+           "tests/test_gpu_group_parallel.py::test_mixed_batch_with_more_tiles_than_wavefronts",
+           "tests/test_gpu_group_parallel.py::test_writer_indexed_streams_vs_oracle[97-61-3-8-2]"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1700)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
 def test_gpu_parity_tests_pass_on_the_wavefront_emulator():
     if sys.platform != "linux" or os.uname().machine != "x86_64":
         pytest.skip("the emulator's context switch is x86-64 SysV assembly")
@@ -137,10 +157,15 @@ def test_reference_cli_through_the_boundary_writes_the_reference_files(tmp_path)
     env = dict(os.environ)
     if os.path.exists("/opt/conda/lib/libjpeg.so.9"):
         env["LD_PRELOAD"] = "/opt/conda/lib/libjpeg.so.9"
-    env_gpu = dict(env, LD_LIBRARY_PATH=str(libdir), EMU_ALARM="600", FUIFGPU_NO_CPU_FALLBACK="1")   # the GPU path or nothing
+    env.pop("FUIFGPU_ALLOW_CPU_FALLBACK", None)
+    env_gpu = dict(env, LD_LIBRARY_PATH=str(libdir), EMU_ALARM="600")   # no switch set: by default it is the GPU path or nothing
     names = ["rgb8_97x61", "pal_rgb_graphic_120x90", "pal_rgba_graphic_72x64", "pal_rgb_channelwise_96x72", "approx_quant_rgb8_40x30",
              "approx_on_palette_gray12_24x50", "match_rgb_graphic_96x80", "gray8_nosqueeze_60x40", "jpeg420_256x192_q90", "rgba14_80x72",
              "anim3_48x32", "anim4_match_40x28"]
+    # the reference's CPU decoder behind the binding is opt-in: a stream outside the GPU scope is a loud error by default
+    from test_boundary_cli import check_cpu_route_is_opt_in
+    check_cpu_route_is_opt_in(lambda args, fb: subprocess.run([gpu_cli] + args, env=dict(env_gpu, FUIFGPU_VERBOSE="1", **({"FUIFGPU_ALLOW_CPU_FALLBACK": "1"} if fb else {})),
+                                                              capture_output=True, text=True, timeout=600), tmp_path)
     for name in names:
         src = os.path.join(ROOT, "tests", "golden", name + ".fuif")
         for extra in ([], ["-R", "2"]):

@@ -158,3 +158,31 @@ def test_stale_index_is_flagged_not_silently_wrong(gpulib, port):
     res = _run(gpulib, [stale, blob])
     assert res["st"][0] & 2                          # corrupt
     assert res["st"][1] == 0 and _same(res, good, 1, 0)   # the intact stream next to it in the batch is untouched
+
+
+@pytest.mark.parametrize("ctx_kb", ["0", "64"])
+def test_pinned_tiles_when_the_context_arena_runs_out(gpulib, port, monkeypatch, ctx_kb):
+    """FUIFGPU_CTX_KB (capi.hip, read at upload) sizes the per-image context arena: 0 = no arena at all, every suspendable tile keeps
+    its tree and leaves in its wavefront's scratch area and is PINNED to that wavefront (suspended and resumed by it alone); 64 KB
+    = the first few tiles of an image get an area, the rest are pinned.  Either way the planes, ranges, status and bytes consumed
+    equal the one-wavefront-per-image decode and the oracle (an exhausted arena once meant spinning tiles)."""
+    monkeypatch.setenv("FUIFGPU_CTX_KB", ctx_kb)
+    img = photographic(512, 384, 3, 8, seed=40)
+    blob = gpulib.encode_image(img, 8, tree_mode=1, index=True)
+    n = int(os.environ.get("FUIF_TEST_PINNED_BATCH", "24"))
+    par = _run(gpulib, [blob] * n)
+    assert par["st"] == [0] * n
+    pre, post = port.decode_both(blob)
+    for k in (0, n // 2, n - 1):
+        assert all(np.array_equal(g, ch["data"]) for g, ch in zip(par["pre"][k], pre.channels) if ch["size"])
+        assert all(np.array_equal(par["post"][k][i], img[i]) for i in range(3))
+    assert par["used"][0] == port.decode(blob, undo=False).stats["bytes"]
+    # a mixed batch (indexed + plain streams, more tiles than wavefronts) under the same arena
+    imgs = [photographic(160, 120, 3, 8, seed=500 + k) for k in range(3)]
+    indexed = [gpulib.encode_image(im, 8, tree_mode=1, index=True) for im in imgs]
+    plain = [gpulib.encode_image(im, 8, tree_mode=1) for im in imgs]
+    blobs = [(indexed if (k % 3) else plain)[k % 3] for k in range(int(os.environ.get("FUIF_TEST_BATCH", "96")))]
+    mixed = _run(gpulib, blobs)
+    assert mixed["st"] == [0] * len(blobs)
+    for k in range(len(blobs)):
+        assert all(np.array_equal(mixed["post"][k][i], imgs[k % 3][i]) for i in range(3)), k

@@ -49,3 +49,18 @@ def test_batch_of_pictures_in_one_launch_pair(gpulib):
         want = [gpulib.encode_image(im, 8, tree_mode=tree_mode, index=True, split_bits=split) for im in imgs]
         got = gpulib.encode_images(imgs, 8, tree_mode=tree_mode, index=True, split_bits=split)
         assert got == want
+
+
+def test_gpu_pixel_loop_writes_the_reference_clis_bytes(gpulib):
+    """closes the chain on the GPU in one step: tests/golden/rgb8_128x128_I0.fuif was written by the unmodified reference CLI
+    (`fuif -I 0`, tests/golden/make_golden.py) from photographic(128, 128, 3, 8, seed=6); the GPU pixel loop (one picture, the
+    batch form, and with the forward transforms on the GPU as well) must write those bytes -- up to the one stray byte the
+    reference appends (BlobIO::bytes_used = seek_pos + 1, fileio.h:252-254)"""
+    from conftest import GOLDEN
+    ref_bytes = open(os.path.join(GOLDEN, "rgb8_128x128_I0.fuif"), "rb").read()
+    img = photographic(128, 128, 3, 8, seed=6)
+    for kw in (dict(gpu_entropy=True), dict(gpu_entropy=True, gpu_forward=True)):
+        mine = gpulib.encode_image(img, 8, tree_mode=0, **kw)
+        assert mine == ref_bytes[: len(mine)] and 0 <= len(ref_bytes) - len(mine) <= 1, kw
+    batch = gpulib.encode_images([img, img], 8, tree_mode=0)
+    assert all(b == ref_bytes[: len(b)] and len(ref_bytes) - len(b) <= 1 for b in batch)

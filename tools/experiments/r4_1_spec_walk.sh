@@ -32,3 +32,9 @@ for lib in build/libfuifgpu_spec.so build/libfuifgpu_specleaf.so; do
   FUIF_AMD_LIB=$ROOT/$lib timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_group_parallel.py -m gpu -x -q
 done
 } 2>&1 | grep -v amdgpu | tee $OUT/times.txt
+# per channel group (long tiles vs the chain in front of them), release against the speculative walk, 1024 pictures
+{
+for lib in build/libfuifgpu_profch.so build/libfuifgpu_spec_profch.so; do
+  [ -f $lib ] && FUIF_AMD_LIB=$ROOT/$lib timeout 300 python tools/prof_by_channel.py 1024 3840 2160
+done
+} 2>&1 | grep -v amdgpu | tee $OUT/by_channel.txt
