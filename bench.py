@@ -362,9 +362,13 @@ def run_streamed(args, wl, inputs, blobs, dev, dist, rank, world, W, H, C, BITS,
     chunk = args.chunk
     plan = fuif_amd.Plan(blobs[0])
     info = plan.info
-    out = torch.empty(chunk * info.out_elems, dtype=torch.int32, device=dev)
+    # A chunk is entropy-decoded in ONE launch into the int16 coefficient slab of a streaming Batch (no output slab); its inverse
+    # transforms then run slice by slice into one slice-sized output tensor, each slice checked / consumed before the next
+    # (fuifgpu_batch_undo_transforms_to).  Outputs are 4 bytes per sample, coefficients 2: the slice keeps the outputs small.
+    n_slice = args.slice if args.slice > 0 else int(max(1, min(chunk, (16 << 30) // (4 * max(info.out_elems, 1)))))
+    out = torch.empty(n_slice * info.out_elems, dtype=torch.int32, device=dev)
     cap = max(sum(len(b) for b in blobs[c0:c0 + chunk]) for c0 in range(0, args.batch, chunk))
-    batch = fuif_amd.Batch(plan, chunk, cap, out_ptr=out.data_ptr())
+    batch = fuif_amd.Batch(plan, chunk, cap, streaming=True)
     batch.set_group_parallel(not args.no_index)
     outs = plan.output_channels
     srcs = None
@@ -383,19 +387,23 @@ def run_streamed(args, wl, inputs, blobs, dev, dist, rank, world, W, H, C, BITS,
             sub = blobs[c0:c0 + chunk]
             batch.upload(sub)
             batch.decode()
-            batch.undo_transforms()
-            batch.sync()
-            d, t = batch.timing()
-            dec += d; tr += t
+            view = out.view(n_slice, info.out_elems)
+            for s0 in range(0, len(sub), n_slice):
+                cnt = min(n_slice, len(sub) - s0)
+                batch.undo_transforms_to(s0, cnt, out.data_ptr())
+                batch.sync()
+                d, t = batch.timing()
+                tr += t
+                if s0 == 0:
+                    dec += d
+                if check and srcs is not None:
+                    for i in range(cnt):
+                        for c, oc in enumerate(outs):
+                            got = view[i, oc["offset"]: oc["offset"] + oc["w"] * oc["h"]].view(oc["h"], oc["w"])
+                            ok = ok and bool(torch.equal(got, srcs[(c0 + s0 + i) % K][c]))
             if check:
                 st, _ = batch.status()
                 ok = ok and not st.any()
-                view = out.view(chunk, info.out_elems)
-                if srcs is not None:
-                    for i in range(len(sub)):
-                        for c, oc in enumerate(outs):
-                            got = view[i, oc["offset"]: oc["offset"] + oc["w"] * oc["h"]].view(oc["h"], oc["w"])
-                            ok = ok and bool(torch.equal(got, srcs[(c0 + i) % K][c]))
         return ok, dec, tr
 
     ok = True
@@ -417,7 +425,7 @@ def run_streamed(args, wl, inputs, blobs, dev, dist, rank, world, W, H, C, BITS,
     ok = fd.all_ok(ok, dist, dev)
     if rank == 0:
         S = sum(len(b) for b in blobs) / args.batch
-        alg = args.batch * (S + 4.0 * info.coef_elems)
+        alg = args.batch * (S + 2.0 * info.coef_elems)   # stream read once, every coefficient written once as an int16 sample
         d_avg = float(np.mean(dec_ms)) / 1e3
         value = world * args.batch * W * H * args.steps / 1e6 / elapsed
         res = {"metric": "Mpixels/s decode (%s)" % args.workload, "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
@@ -426,7 +434,8 @@ def run_streamed(args, wl, inputs, blobs, dev, dist, rank, world, W, H, C, BITS,
                "config": {"workload": wl["desc"] % (args.batch, W, H), "images_per_gpu": args.batch, "chunk": chunk, "distinct_images": K,
                           "bytes_per_stream": int(S), "channels": C, "bits": BITS, "parity_roundtrip_ok": ok,
                           "parity_check": "decoded == source pixels for every image of one full pass" if wl["lossless"] else "status only",
-                          "streaming": "one chunk-sized set of slabs, %d chunks per step, uploads inside the timed region" % (-(-args.batch // chunk)),
+                          "streaming": "%d entropy launch(es) of up to %d images per step into one int16 coefficient slab; inverse transforms in slices of %d images into "
+                                       "one output tensor (fuifgpu_batch_undo_transforms_to); uploads inside the timed region" % (-(-args.batch // chunk), chunk, n_slice),
                           "input_gen_s": round(t_gen, 1)},
                "roofline": {"bound": "hbm", "kernel": "k_maniac_decode", "achieved": round(alg / d_avg / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(alg / d_avg / 1e9 / HBM_PEAK_GBS, 6), "traffic": None, "kernel_ms": round(d_avg * 1e3, 3),
@@ -506,6 +515,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0,
                     help="images resident at a time (0 = the whole batch, -1 = as many as the device holds): the batch is streamed through ONE chunk-sized set of coefficient / "
                          "output slabs, chunk after chunk -- how C4 (256 x 8192x8192x4: 275 GB of coefficients alone) runs on one GPU")
+    ap.add_argument("--slice", type=int, default=0, help="with --chunk: images per inverse-transform slice (0 = what fits 16 GiB of int32 outputs)")
     ap.add_argument("--cache", default=os.environ.get("FUIF_BENCH_CACHE", "/tmp/fuif_bench_cache"))
     ap.add_argument("--no-rccl-selfcheck", action="store_true",
                     help="one GPU: do not start the one-rank RCCL process group that runs the N>1 collectives on cuda:0 (outside the timed region except for the fence's barrier)")
@@ -571,10 +581,11 @@ def main():
         # as many images per chunk as the device holds: coefficient + output slabs (int32) and the stream of every resident image,
         # next to ~45 GB of decoder scratch, context arenas and the transform arena (C4: 86 of the 256 8192x8192x4 images)
         pinfo = fuif_amd.Plan(blobs[0]).info
-        per_image = 4 * (pinfo.coef_elems + pinfo.out_elems) + max(len(b) for _, b in inputs) + (32 << 20)
+        per_image = 2 * pinfo.coef_elems + max(len(b) for _, b in inputs) + (32 << 20)   # int16 coefficients; the outputs go through one 16 GiB slice
         free_b, _ = torch.cuda.mem_get_info(dev)
-        args.chunk = int(max(1, min(args.batch, (free_b - (45 << 30)) // per_image)))
-    if args.chunk and args.chunk < args.batch:
+        args.chunk = int(max(1, min(args.batch, (free_b - (45 << 30) - (16 << 30) - (12 << 30)) // per_image)))
+    if args.chunk:   # (also when one chunk holds the whole batch: the OUTPUTS of such a batch still only fit slice by slice)
+        args.chunk = min(args.chunk, args.batch)
         return run_streamed(args, wl, inputs, blobs, dev, dist, rank, world, W, H, C, BITS, K, t_gen)
 
     plan = fuif_amd.Plan(blobs[0])
@@ -785,8 +796,9 @@ def main():
         S = sum(len(b) for b in blobs) / args.batch
         N = info.coef_elems
         P = info.out_elems
-        # dominant kernel: k_maniac_decode reads the stream once and writes every coefficient once
-        alg_kernel = args.batch * (S + 4.0 * N)
+        # dominant kernel: k_maniac_decode reads the stream once and writes every coefficient once -- as an int16 sample since round 4
+        # (SURVEY 8(d) counted 4 bytes per coefficient for int32 planes; the kernel's algorithmic bytes are what it has to move now)
+        alg_kernel = args.batch * (S + 2.0 * N)
         d_avg = float(np.mean(dec_ms)) / 1e3
         t_avg = float(np.mean(tr_ms)) / 1e3
         achieved = alg_kernel / d_avg / 1e9
@@ -794,15 +806,18 @@ def main():
         roofline = {"bound": "hbm", "kernel": "k_maniac_decode", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel_ms": round(d_avg * 1e3, 3), "algorithmic_bytes_per_launch": int(alg_kernel),
+                    "algorithmic_bytes": "n x (S + 2 N): stream bytes read once, N int16 coefficient samples written once (rounds 1-3 wrote int32: S + 4 N, "
+                                         "which would read %.3f GB/s here)" % (args.batch * (S + 4.0 * N) / d_avg / 1e9),
                     "tiles_per_launch": n_tiles,
                     "note": "serial range decoders, one wavefront per channel group, 6 per SIMD, suspended while they wait for other groups' rows: "
                             "bound by the latency of two dependent memory round trips per symbol (supernode, leaf: ~980 cycles each when ~3000 long "
                             "groups share HBM, profiles/r3_fetch_latency_and_leaf_experiment.txt) and by what the wavefronts of a SIMD issue together, not by "
                             "HBM bandwidth (DESIGN.md 4.1); traffic = PMC bytes of the committed profile named in traffic_source (NOT measured in this "
                             "run), calibrated on the kernel's two access patterns",
-                    "transforms": {"ms": round(t_avg * 1e3, 3), "achieved": round(args.batch * 4.0 * (N + P) / t_avg / 1e9, 1),
-                                   "unit": "GB/s", "algorithmic_bytes": int(args.batch * 4.0 * (N + P))},
-                    "path_bytes_per_image": int(S + 8.0 * N + 4.0 * P)}
+                    "transforms": {"ms": round(t_avg * 1e3, 3), "achieved": round(args.batch * (2.0 * N + 4.0 * P) / t_avg / 1e9, 1),
+                                   "unit": "GB/s", "algorithmic_bytes": int(args.batch * (2.0 * N + 4.0 * P)),
+                                   "note": "int16 coefficients in, int32 planes out; the kernels work on an int32 copy of a chunk's coefficients (k_widen16: +6 N bytes of traffic)"},
+                    "path_bytes_per_image": int(S + 4.0 * N + 4.0 * P)}
         res = {"metric": "Mpixels/s decode (4K Squeeze+YCoCg)" if args.workload == "c2" else "Mpixels/s decode (%s)" % args.workload, "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",

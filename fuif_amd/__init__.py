@@ -86,7 +86,7 @@ ABI_SYMBOLS = [
     "fuifgpu_plan_info", "fuifgpu_plan_coded_channel", "fuifgpu_plan_output_channel", "fuifgpu_plan_transform",
     "fuifgpu_build_chance_table", "fuifgpu_batch_create", "fuifgpu_batch_create_sibling", "fuifgpu_dev_mem_info", "fuifgpu_encode_images", "fuifgpu_batch_destroy", "fuifgpu_batch_upload",
     "fuifgpu_batch_decode", "fuifgpu_batch_undo_transforms", "fuifgpu_batch_sync", "fuifgpu_batch_status",
-    "fuifgpu_batch_channel_meta", "fuifgpu_batch_coef_ptr", "fuifgpu_batch_out_ptr", "fuifgpu_batch_download_coef",
+    "fuifgpu_batch_create_streaming", "fuifgpu_batch_undo_transforms_to", "fuifgpu_batch_channel_meta", "fuifgpu_batch_coef_ptr", "fuifgpu_batch_out_ptr", "fuifgpu_batch_download_coef",
     "fuifgpu_batch_download_out", "fuifgpu_batch_last_timing", "fuifgpu_batch_profile", "fuifgpu_batch_tile_log", "fuifgpu_batch_sched_stats", "fuifgpu_inv_hsqueeze", "fuifgpu_inv_vsqueeze",
     "fuifgpu_inv_ycocg", "fuifgpu_inv_ycbcr", "fuifgpu_inv_quantize", "fuifgpu_idct8x8", "fuifgpu_upsample", "fuifgpu_fwd_ycocg", "fuifgpu_fwd_hsqueeze", "fuifgpu_fwd_vsqueeze", "fuifgpu_encode_image", "fuifgpu_encode_channels", "fuifgpu_free_blob",
     "fuifgpu_index_parse", "fuifgpu_index_append", "fuifgpu_batch_group_index", "fuifgpu_batch_set_group_parallel",
@@ -142,6 +142,8 @@ def lib():
     L.fuifgpu_batch_upload.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, vp]
     L.fuifgpu_batch_decode.argtypes = [vp, vp]
     L.fuifgpu_batch_undo_transforms.argtypes = [vp, vp]
+    L.fuifgpu_batch_create_streaming.argtypes = [vp, C.c_int, C.c_size_t, C.c_int, C.POINTER(vp)]
+    L.fuifgpu_batch_undo_transforms_to.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     L.fuifgpu_batch_sync.argtypes = [vp, vp]
     L.fuifgpu_batch_status.argtypes = [vp, vp, vp]
     L.fuifgpu_batch_channel_meta.argtypes = [vp, C.c_int, vp]
@@ -230,13 +232,21 @@ class Plan:
 class Batch:
     """Device state for ``n_images`` streams sharing one plan (geometry + transform chain)."""
 
-    def __init__(self, plan, n_images, blob_capacity, coef_ptr=None, out_ptr=None, tmp_images=0):
+    def __init__(self, plan, n_images, blob_capacity, coef_ptr=None, out_ptr=None, tmp_images=0, streaming=False):
         L = lib()
         self.plan = plan
         self.n = n_images
         self._h = C.c_void_p()
-        _check(L.fuifgpu_batch_create(plan._h, n_images, blob_capacity, coef_ptr, out_ptr, tmp_images, C.byref(self._h)))
+        if streaming:
+            # no output slab: the inverse transforms run range by range into caller memory (undo_transforms_to)
+            _check(L.fuifgpu_batch_create_streaming(plan._h, n_images, blob_capacity, tmp_images, C.byref(self._h)))
+        else:
+            _check(L.fuifgpu_batch_create(plan._h, n_images, blob_capacity, coef_ptr, out_ptr, tmp_images, C.byref(self._h)))
         self._keep = None
+
+    def undo_transforms_to(self, first_image, n_images, out_device_ptr, stream=None):
+        """inverse transforms of images [first, first + n) of the current decode into DEVICE memory (n * out_elems int32)"""
+        _check(lib().fuifgpu_batch_undo_transforms_to(self._h, first_image, n_images, out_device_ptr, stream))
 
     def sibling(self, blob_capacity):
         """a second set of stream buffers over this Batch's slabs, scratch and arenas (fuifgpu_batch_create_sibling): upload
@@ -459,7 +469,7 @@ def group_by_signature(blobs):
 
 def plan_bytes_per_image(plan, avg_blob_bytes=0):
     """HBM bytes one in-flight image needs: coefficient + output slabs + decoder scratch + its stream"""
-    return 4 * (plan.info.coef_elems + plan.info.out_elems) + 19 * (1 << 20) + int(avg_blob_bytes)
+    return 2 * plan.info.coef_elems + 4 * plan.info.out_elems + 19 * (1 << 20) + int(avg_blob_bytes)   # int16 coefficients, int32 outputs
 
 
 def decode_mixed(blobs, preview=-1, hbm_budget_bytes=200 << 30):

@@ -278,7 +278,7 @@ int fuif_decode_files(const char *const *filenames, int n_files, Image *images, 
             size_t free_b = 0, total_b = 0;
             if (fuifgpu_dev_mem_info(&free_b, &total_b) == FUIFGPU_OK && free_b) {
                 const size_t reserve = std::min<size_t>(free_b / 4, (size_t)40 << 30);
-                const size_t per_image = 4 * (size_t)(info.coef_elems + info.out_elems) + max_stream + ((size_t)16 << 20);
+                const size_t per_image = 2 * (size_t)info.coef_elems + 4 * (size_t)info.out_elems + max_stream + ((size_t)16 << 20);   // int16 coefficients, int32 outputs
                 chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, (free_b - reserve) / std::max<size_t>(per_image, 1)));
             }
             if (const char *e = getenv("FUIFGPU_BOUNDARY_CHUNK")) chunk = std::max(1, std::min(n, atoi(e)));

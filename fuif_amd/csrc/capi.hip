@@ -54,7 +54,9 @@ struct fuifgpu_batch {
     uint32_t ctx_units_per_queue = 0;
     std::vector<Tile> tiles;
     int max_nodes = kMaxNodes;
-    int32_t *d_coef = nullptr, *d_out = nullptr, *d_tmp = nullptr;
+    coef_t *d_coef = nullptr;         // int16 samples: what the entropy kernel writes (fuifgpu_internal.h)
+    int32_t *d_out = nullptr, *d_tmp = nullptr;
+    int32_t *d_coef32 = nullptr;      // the coefficients of tmp_images images widened to int32: what the inverse transforms read and rewrite (a launch resource, like d_tmp)
     bool own_coef = false, own_out = false;
     int tmp_images = 0;
     PlaneRef *d_list = nullptr;
@@ -65,6 +67,8 @@ struct fuifgpu_batch {
     std::vector<StreamJob> jobs;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool decode_timed = false, transform_timed = false;
+    bool no_out = false;              // fuifgpu_batch_create_streaming: no output slab; fuifgpu_batch_undo_transforms_to writes into caller memory
+    std::vector<char> undone;         // ... which images of the current decode have been through it (each once: the channel metadata is rewritten)
     bool coef_consumed = false;   // undo_transforms has run on the current decode: several inverse steps work in place on the coefficients
     // A sibling (fuifgpu_batch_create_sibling) owns only what an UPLOAD writes -- stream bytes, tile lists, per-image results -- and
     // decodes with the primary's slabs, decoder scratch, context arenas and transform arena (everything a LAUNCH uses)
@@ -193,7 +197,7 @@ void fuifgpu_batch_destroy(fuifgpu_batch *b) {
         v.erase(std::remove(v.begin(), v.end(), b), v.end());
     }
     hipFree(b->d_blobs); hipFree(b->d_jobs); hipFree(b->d_geom); hipFree(b->d_meta); hipFree(b->d_status); hipFree(b->d_consumed);
-    hipFree(b->d_tables); hipFree(b->d_scratch); hipFree(b->d_tmp); hipFree(b->d_list); hipFree(b->d_prof); hipFree(b->d_tile_log);
+    hipFree(b->d_tables); hipFree(b->d_scratch); hipFree(b->d_tmp); hipFree(b->d_coef32); hipFree(b->d_list); hipFree(b->d_prof); hipFree(b->d_tile_log);
     hipFree(b->d_tiles); hipFree(b->d_progress); hipFree(b->d_group_start); hipFree(b->d_sched); hipFree(b->d_layout); hipFree(b->d_ctx);
     if (b->own_coef) hipFree(b->d_coef);
     if (b->own_out) hipFree(b->d_out);
@@ -202,7 +206,8 @@ void fuifgpu_batch_destroy(fuifgpu_batch *b) {
     delete b;
 }
 
-static int batch_create_impl(const Plan &plan_in, int n_images, size_t blob_capacity_bytes, int32_t *coef_ext, int32_t *out_ext,
+static int32_t *const kNoOutSlab = reinterpret_cast<int32_t *>(~(uintptr_t)0);   // batch_create_impl: a batch without an output slab (streaming)
+static int batch_create_impl(const Plan &plan_in, int n_images, size_t blob_capacity_bytes, coef_t *coef_ext, int32_t *out_ext,
                              int tmp_images, fuifgpu_batch *share, fuifgpu_batch **out) {
     if (!out || n_images < 1 || n_images > 65535) return FUIFGPU_E_ARG;
     *out = nullptr;
@@ -244,16 +249,20 @@ static int batch_create_impl(const Plan &plan_in, int n_images, size_t blob_capa
     CHK(hipMalloc((void **)&b->d_progress, sizeof(uint32_t) * (size_t)n_images * std::max(nch, 1)));
     CHK(hipMalloc((void **)&b->d_group_start, sizeof(uint32_t) * (size_t)n_images * std::max(nch, 1)));
     if (coef_ext) b->d_coef = coef_ext;
-    else { CHK(hipMalloc((void **)&b->d_coef, sizeof(int32_t) * (size_t)std::max<int64_t>(p.coef_elems, 1) * n_images)); b->own_coef = true; }
-    if (out_ext) b->d_out = out_ext;
+    else { CHK(hipMalloc((void **)&b->d_coef, sizeof(coef_t) * (size_t)std::max<int64_t>(p.coef_elems, 1) * n_images)); b->own_coef = true; }
+    if (out_ext == kNoOutSlab) { b->d_out = nullptr; b->no_out = true; }
+    else if (out_ext) b->d_out = out_ext;
     else { CHK(hipMalloc((void **)&b->d_out, sizeof(int32_t) * (size_t)std::max<int64_t>(p.out_elems, 1) * n_images)); b->own_out = true; }
     if (tmp_images <= 0) {
-        // default: keep the TMP slab under ~8 GiB
-        int64_t per = std::max<int64_t>(p.tmp_elems, 1) * 4;
-        tmp_images = (int)std::max<int64_t>(1, std::min<int64_t>(n_images, (8LL << 30) / per));
+        // default: keep the TMP slab + the widened coefficients of the images it serves under ~12 GiB
+        int64_t per = (std::max<int64_t>(p.tmp_elems, 1) + std::max<int64_t>(p.coef_elems, 1)) * 4;
+        tmp_images = (int)std::max<int64_t>(1, std::min<int64_t>(n_images, (12LL << 30) / per));
     }
     b->tmp_images = std::min(tmp_images, n_images);
-    if (!share) CHK(hipMalloc((void **)&b->d_tmp, sizeof(int32_t) * (size_t)std::max<int64_t>(p.tmp_elems, 1) * b->tmp_images));
+    if (!share) {
+        CHK(hipMalloc((void **)&b->d_tmp, sizeof(int32_t) * (size_t)std::max<int64_t>(p.tmp_elems, 1) * b->tmp_images));
+        CHK(hipMalloc((void **)&b->d_coef32, sizeof(int32_t) * (size_t)std::max<int64_t>(p.coef_elems, 1) * b->tmp_images));
+    }
     if (!p.idct_src.empty()) {
         CHK(hipMalloc((void **)&b->d_list, sizeof(PlaneRef) * p.idct_src.size()));
         CHK(hipMemcpy(b->d_list, p.idct_src.data(), sizeof(PlaneRef) * p.idct_src.size(), hipMemcpyHostToDevice));
@@ -266,7 +275,7 @@ static int batch_create_impl(const Plan &plan_in, int n_images, size_t blob_capa
     return FUIFGPU_OK;
 }
 
-int fuifgpu_batch_create(const fuifgpu_plan *plan, int n_images, size_t blob_capacity_bytes, int32_t *coef_ext, int32_t *out_ext,
+int fuifgpu_batch_create(const fuifgpu_plan *plan, int n_images, size_t blob_capacity_bytes, int16_t *coef_ext, int32_t *out_ext,
                          int tmp_images, fuifgpu_batch **out) {
     if (!plan) return FUIFGPU_E_ARG;
     return batch_create_impl(plan->plan, n_images, blob_capacity_bytes, coef_ext, out_ext, tmp_images, nullptr, out);
@@ -304,8 +313,13 @@ static int freeze_launch_resources(fuifgpu_batch *b) {
     return FUIFGPU_OK;
 }
 
+int fuifgpu_batch_create_streaming(const fuifgpu_plan *plan, int n_images, size_t blob_capacity_bytes, int tmp_images, fuifgpu_batch **out) {
+    if (!plan) return FUIFGPU_E_ARG;
+    return batch_create_impl(plan->plan, n_images, blob_capacity_bytes, nullptr, kNoOutSlab, tmp_images, nullptr, out);
+}
+
 int fuifgpu_batch_create_sibling(fuifgpu_batch *primary, size_t blob_capacity_bytes, fuifgpu_batch **out) {
-    if (!primary || primary->share) return FUIFGPU_E_ARG;
+    if (!primary || primary->share || primary->no_out) return FUIFGPU_E_ARG;
     if (primary->siblings.empty()) { const int frc = freeze_launch_resources(primary); if (frc != FUIFGPU_OK) return frc; }
     const int rc = batch_create_impl(primary->plan, primary->n, blob_capacity_bytes, primary->d_coef, primary->d_out, primary->tmp_images, primary, out);
     if (rc == FUIFGPU_OK) primary->siblings.push_back(*out);
@@ -560,29 +574,57 @@ int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
     HIPCHK(hipEventRecord(b->ev[1], st));
     b->decode_timed = true;
     b->coef_consumed = false;
+    b->undone.clear();
+    return FUIFGPU_OK;
+}
+
+static int undo_range(fuifgpu_batch *b, int first, int count, int32_t *out_base, hipStream_t st) {
+    const Plan &p = b->plan;
+    const int nch = (int)p.coded.size();
+    const fuifgpu_batch *r = launch_res(b);
+    for (int i0 = first; i0 < first + count; i0 += r->tmp_images) {
+        const int cnt = std::min(r->tmp_images, first + count - i0);
+        Bases bases;
+        // the chunk's int16 coefficients, widened: the kernels below read (and dequantisation, Approximate, the match transforms
+        // rewrite) this copy, never the slab the entropy kernel wrote
+        launch_widen(b->d_coef + (int64_t)i0 * p.coef_elems, r->d_coef32, (int64_t)cnt * p.coef_elems, st);
+        bases.base[BUF_COEF] = r->d_coef32; bases.stride[BUF_COEF] = p.coef_elems;
+        bases.base[BUF_OUT] = out_base + (int64_t)(i0 - first) * p.out_elems; bases.stride[BUF_OUT] = p.out_elems;
+        bases.base[BUF_TMP] = r->d_tmp; bases.stride[BUF_TMP] = p.tmp_elems;
+        for (const Op &op : p.ops) launch_op(op, bases, b->d_list, b->d_meta, nch, i0, cnt, st, b->d_status);
+    }
+    HIPCHK(hipGetLastError());
+    return FUIFGPU_OK;
+}
+
+int fuifgpu_batch_undo_transforms_to(fuifgpu_batch *b, int first_image, int n_images, int32_t *out_device, void *stream) {
+    if (!b || b->orphan || !out_device || first_image < 0 || n_images < 1 || first_image + n_images > b->n_loaded) return FUIFGPU_E_ARG;
+    if (b->coef_consumed) { g_last_error = "fuifgpu_batch_undo_transforms_to: fuifgpu_batch_undo_transforms already ran on this decode"; return FUIFGPU_E_ARG; }
+    if ((int)b->undone.size() != b->n_loaded) b->undone.assign((size_t)b->n_loaded, 0);
+    for (int i = first_image; i < first_image + n_images; i++)
+        if (b->undone[i]) { g_last_error = "fuifgpu_batch_undo_transforms_to: an image of the range has been through the inverse transforms already (once per decode)"; return FUIFGPU_E_ARG; }
+    for (int i = first_image; i < first_image + n_images; i++) b->undone[i] = 1;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipEventRecord(b->ev[2], st));
+    const int rc = undo_range(b, first_image, n_images, out_device, st);
+    if (rc != FUIFGPU_OK) return rc;
+    HIPCHK(hipEventRecord(b->ev[3], st));
+    b->transform_timed = true;
     return FUIFGPU_OK;
 }
 
 int fuifgpu_batch_undo_transforms(fuifgpu_batch *b, void *stream) {
     if (!b || b->n_loaded < 1) return FUIFGPU_E_ARG;
-    // dequantisation, YCoCg / YCbCr, Approximate and the match transforms rewrite the coefficient slab (and ChannelMeta::q): a second
-    // pass over the same decode would apply them twice
-    if (b->coef_consumed) { g_last_error = "fuifgpu_batch_undo_transforms: already run on this decode (it works in place on the coefficients); decode again first"; return FUIFGPU_E_ARG; }
+    if (b->no_out) { g_last_error = "fuifgpu_batch_undo_transforms: a streaming batch has no output slab (fuifgpu_batch_undo_transforms_to)"; return FUIFGPU_E_ARG; }
+    for (char u : b->undone) if (u) { g_last_error = "fuifgpu_batch_undo_transforms: part of this decode went through fuifgpu_batch_undo_transforms_to already"; return FUIFGPU_E_ARG; }
+    // The inverse kernels work on a widened COPY of the coefficients (round 4), so the slab itself stays as decoded; but
+    // Approximate rewrites ChannelMeta::q, which a second pass over the same decode would apply twice
+    if (b->coef_consumed) { g_last_error = "fuifgpu_batch_undo_transforms: already run on this decode (it rewrites the channel metadata); decode again first"; return FUIFGPU_E_ARG; }
     b->coef_consumed = true;
     hipStream_t st = (hipStream_t)stream;
-    const Plan &p = b->plan;
-    const int nch = (int)p.coded.size();
     HIPCHK(hipEventRecord(b->ev[2], st));
-    const fuifgpu_batch *r = launch_res(b);
-    for (int i0 = 0; i0 < b->n_loaded; i0 += r->tmp_images) {
-        const int cnt = std::min(r->tmp_images, b->n_loaded - i0);
-        Bases bases;
-        bases.base[BUF_COEF] = b->d_coef + (int64_t)i0 * p.coef_elems; bases.stride[BUF_COEF] = p.coef_elems;
-        bases.base[BUF_OUT] = b->d_out + (int64_t)i0 * p.out_elems; bases.stride[BUF_OUT] = p.out_elems;
-        bases.base[BUF_TMP] = r->d_tmp; bases.stride[BUF_TMP] = p.tmp_elems;
-        for (const Op &op : p.ops) launch_op(op, bases, b->d_list, b->d_meta, nch, i0, cnt, st, b->d_status);
-    }
-    HIPCHK(hipGetLastError());
+    const int rc = undo_range(b, 0, b->n_loaded, b->d_out, st);
+    if (rc != FUIFGPU_OK) return rc;
     HIPCHK(hipEventRecord(b->ev[3], st));
     b->transform_timed = true;
     return FUIFGPU_OK;
@@ -635,18 +677,21 @@ int fuifgpu_batch_channel_meta(fuifgpu_batch *b, int image, int32_t *meta4) {
     return FUIFGPU_OK;
 }
 
-int32_t *fuifgpu_batch_coef_ptr(fuifgpu_batch *b, int image) { return (b && !b->orphan && image >= 0 && image < b->n) ? b->d_coef + (int64_t)image * b->plan.coef_elems : nullptr; }
-int32_t *fuifgpu_batch_out_ptr(fuifgpu_batch *b, int image) { return (b && !b->orphan && image >= 0 && image < b->n) ? b->d_out + (int64_t)image * b->plan.out_elems : nullptr; }
+int16_t *fuifgpu_batch_coef_ptr(fuifgpu_batch *b, int image) { return (b && !b->orphan && image >= 0 && image < b->n) ? b->d_coef + (int64_t)image * b->plan.coef_elems : nullptr; }
+int32_t *fuifgpu_batch_out_ptr(fuifgpu_batch *b, int image) { return (b && !b->orphan && !b->no_out && image >= 0 && image < b->n) ? b->d_out + (int64_t)image * b->plan.out_elems : nullptr; }
 
 int fuifgpu_batch_download_coef(fuifgpu_batch *b, int image, int32_t *host, void *stream) {
     if (!b || image < 0 || image >= b->n || !host || b->orphan) return FUIFGPU_E_ARG;
-    if (b->coef_consumed) { g_last_error = "fuifgpu_batch_download_coef: the coefficients were consumed by fuifgpu_batch_undo_transforms"; return FUIFGPU_E_ARG; }
-    HIPCHK(hipMemcpyAsync(host, fuifgpu_batch_coef_ptr(b, image), sizeof(int32_t) * (size_t)b->plan.coef_elems, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    // the slab holds int16 samples; the caller gets them as int32, like every other plane of the interface
+    const size_t n = (size_t)b->plan.coef_elems;
+    std::vector<coef_t> narrow(n);
+    HIPCHK(hipMemcpyAsync(narrow.data(), fuifgpu_batch_coef_ptr(b, image), sizeof(coef_t) * n, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    for (size_t k = 0; k < n; k++) host[k] = narrow[k];
     return FUIFGPU_OK;
 }
 int fuifgpu_batch_download_out(fuifgpu_batch *b, int image, int32_t *host, void *stream) {
-    if (!b || image < 0 || image >= b->n || !host || b->orphan) return FUIFGPU_E_ARG;
+    if (!b || image < 0 || image >= b->n || !host || b->orphan || b->no_out) return FUIFGPU_E_ARG;
     HIPCHK(hipMemcpyAsync(host, fuifgpu_batch_out_ptr(b, image), sizeof(int32_t) * (size_t)b->plan.out_elems, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     return FUIFGPU_OK;
@@ -673,13 +718,13 @@ size_t fuifgpu_plan_packed_bytes(const fuifgpu_plan *plan, int components) {
     return (size_t)plan->plan.w * plan->plan.h * pp.n * bps;
 }
 int fuifgpu_batch_pack_out(fuifgpu_batch *b, int first_image, int n_images, int components, uint8_t *dst_device, void *stream) {
-    if (!b || !dst_device || first_image < 0 || n_images < 1 || first_image + n_images > b->n_loaded) return FUIFGPU_E_ARG;
+    if (!b || !dst_device || first_image < 0 || n_images < 1 || first_image + n_images > b->n_loaded || b->no_out) return FUIFGPU_E_ARG;
     const Plan &p = b->plan;
     PackedPlanes pp; int bps = 1;
     int rc = packed_layout(p, components, &pp, &bps);
     if (rc != FUIFGPU_OK) return rc;
     Bases bases;
-    bases.base[BUF_COEF] = b->d_coef + (int64_t)first_image * p.coef_elems; bases.stride[BUF_COEF] = p.coef_elems;
+    bases.base[BUF_COEF] = nullptr; bases.stride[BUF_COEF] = 0;   // final planes always live in the output slab (plan.cpp finalize())
     bases.base[BUF_OUT] = b->d_out + (int64_t)first_image * p.out_elems; bases.stride[BUF_OUT] = p.out_elems;
     bases.base[BUF_TMP] = launch_res(b)->d_tmp; bases.stride[BUF_TMP] = p.tmp_elems;
     launch_pack(bases, pp, p.w, p.h, p.minval, p.maxval, bps, dst_device, (int64_t)p.w * p.h * pp.n * bps, n_images, (hipStream_t)stream);

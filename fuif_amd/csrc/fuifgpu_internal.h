@@ -21,7 +21,11 @@ constexpr int kMaxRefs = 9;            // 2*9 + 13 = 31 properties: what the 32 
 constexpr int kMaxNodes = 65535;        // childID is uint16_t (maniac/compound.h:46)
 constexpr int kLeafStride = 32;         // 31 chances (maniac/symbol.h:72-77) padded to 64 bytes
 constexpr int kTreeStackDepth = 2048;   // explicit stack replacing the recursion of compound.h:277-308
-constexpr int kPlaneAlign = 64;         // planes start on 256-byte boundaries inside a slab
+constexpr int kPlaneAlign = 128;        // planes start on 256-byte boundaries inside a slab (coefficient slab: 128 int16 elements)
+// A coded sample is a pixel_type = int16_t in the reference (image/image.h:35; check_bit_depth caps compressed samples at 15 bits
+// of magnitude, encoding.cpp:61-72): the coefficient slab the entropy kernel writes holds int16 samples (round 4: half the slab,
+// twice the images per launch for C4).  The inverse transforms compute in int32: they run on a widened copy of a chunk of images.
+using coef_t = int16_t;
 
 // status word per image (bit flags)
 enum : int {

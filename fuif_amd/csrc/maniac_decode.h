@@ -31,7 +31,7 @@ struct DecodeParams {
     int32_t n_images;
     int32_t n_channels;
     const ChannelGeom *geom;     // coded channel table (shared by the batch)
-    int32_t *coef;               // [n_images][coef_stride]
+    coef_t *coef;                // [n_images][coef_stride] int16 samples (fuifgpu_internal.h)
     int64_t coef_stride;
     ChannelMeta *meta;           // [n_images][n_channels]
     int32_t *status;             // [n_images]

@@ -87,7 +87,7 @@ constexpr int CH_ZERO = 0, CH_SIGN = 1, CH_EXP = 2, CH_MANT = 16, CH_N = 31;
 #define FUIF_LDS_WIDE 58
 #endif
 #ifndef FUIF_LDS_DENSE
-#define FUIF_LDS_DENSE 2
+#define FUIF_LDS_DENSE 0   // round 4: the two slots served 0.9 % of the walk rounds (profiles/r2_walk_locality.txt) and cost every round an LDS read, a compare and two branches
 #endif
 constexpr int kLdsWide = FUIF_LDS_WIDE, kLdsDense = FUIF_LDS_DENSE;
 #ifndef FUIF_SIZE_ORDERED
@@ -117,7 +117,8 @@ static_assert(kChunkDense == 64 || kChunkDense == 32 || kChunkDense == 16, "chun
 DEV int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 DEV uint32_t rflu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 DEV int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-// clang for ROCm 7.2 has no writelane builtin: a uniform compare + v_cndmask does the same job
+// clang for ROCm 7.2 has no writelane builtin, and v_writelane_b32 cannot take both its value and its lane from SGPRs (one
+// constant-bus operand on gfx9): a uniform compare + v_cndmask does the job
 DEV int wrlane(int val, int l, int old) { return ((int)threadIdx.x == l) ? val : old; }
 
 // ---- tile-to-tile hand-off (placement independent) ----------------------------------------------
@@ -129,11 +130,15 @@ DEV int wrlane(int val, int l, int old) { return ((int)threadIdx.x == l) ? val :
 #ifdef FUIF_EMU   // tools/emu: the same source compiled for the CPU wavefront emulator (test infrastructure)
 typedef int32_t gi32;
 typedef uint32_t gu32;
+typedef int16_t gi16;
 #else
 typedef __attribute__((address_space(1))) int32_t gi32;
 typedef __attribute__((address_space(1))) uint32_t gu32;
+typedef __attribute__((address_space(1))) int16_t gi16;
 #endif
 DEV void st_agent(int32_t *p, int v) { __hip_atomic_store((gi32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void st_agent(int16_t *p, int v) { __hip_atomic_store((gi16 *)p, (int16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // coefficient samples
+DEV int ld_agent(const int16_t *p) { return (int)__hip_atomic_load((const gi16 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store((gu32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV int ld_agent(const int32_t *p) { return __hip_atomic_load((const gi32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load((const gu32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -196,6 +201,17 @@ DEV uint2 lds_load_node(uint32_t lds_byte_addr) {
 DEV uint2 global_load_node(const void *p) {
     uint2 v;
     asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+#endif
+// supernode `sn` of a tree at `base`, lane's record: a scalar base + one 32-bit vector offset (a tree's supernodes span at most 2 MB)
+#ifdef FUIF_EMU
+DEV uint2 global_load_supernode(const uint2 *base, uint32_t sn, uint32_t lane8) { return *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(base) + sn * 512u + lane8); }
+#else
+DEV uint2 global_load_supernode(const uint2 *base, uint32_t sn, uint32_t lane8) {
+    uint2 v;
+    uint32_t off;
+    asm volatile("v_lshl_add_u32 %1, %3, 9, %4\n\tglobal_load_dwordx2 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(v), "=&v"(off) : "s"(base), "s"(sn), "v"(lane8) : "memory");
     return v;
 }
 #endif
@@ -408,6 +424,7 @@ DEV int leaf_symbol(Rac &r, Stream &s, int lane, LeafRegs &L, int min, int max) 
 // from e and the magnitude instead of being updated per decision; a mantissa bit can only be impossible when e == emax.
 struct FastSym {
     int amax_pos, amax_neg, emax_pos, emax_neg;
+    int ilast_pos, ilast_neg;   // emax + 1: the index of the last exponent chance of each sign (fast_symbol_hw)
 };
 DEV uint32_t lane_thresholds(uint32_t range, int leafv) {   // rac.h:43-52 for every lane's own chance: range - chance
     return range - (uint32_t)(((unsigned long long)range * (uint32_t)leafv + 0x800ull) >> 12);
@@ -554,8 +571,16 @@ DEV int fast_symbol(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
 #define FS_PROBE
 #endif
 DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
+    // Round 4 (profiles/r4_instruction_probes.txt: a scalar instruction or a taken branch costs the launch twice a vector one):
+    //   * a decision is `s_sub t, low, thr`: SCC = borrow = (low < thr) = NOT the bit, and three s_cselect / s_addc take it from there
+    //     (no compare, no separate subtraction of the selected amount);
+    //   * the exponent loop counts the chance index itself (no index add per decision); a one-bit ends it with e < emax, which is
+    //     the case in which every mantissa bit is coded (symbol.h:173-183): the lean mantissa loop of 8 scalar instructions and 2
+    //     branches per bit (was 15 and 3), the bits collected INVERTED by s_addc and turned round once at the end;
+    //   * the exhausted exponent (e == emax, under 1 % of the symbols) keeps the careful loop with the amax test per bit;
+    //   * (index, bit) masks for leaf_commit from s_bfm_b32 fields.
     uint32_t R = r.range, Lo = r.low, widx = s.pos - s.win_base;
-    uint32_t res, touched, bits, t0, t1, thr, e, amax, emax, sign, have, one, skipped;
+    uint32_t res, touched, bits, t0, t1, thr, idx, ilast, sm, hv, e, midx, amax, have, skipped;
     asm volatile(
         "v_mov_b32 " FS_VK0 ", 0x800\n\tv_mov_b32 " FS_VK1 ", 0\n\t"
         FS_PROBE
@@ -564,64 +589,80 @@ DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
         "s_cmp_ge_u32 %[L], %[thr]\n\ts_cbranch_scc1 70f\n\t"
         "s_mov_b32 %[R], %[thr]\n\t"
         FS_RN_CHECK("91f", "81")
-        // ---- sign  (chance 1): 1 = positive
+        // ---- sign  (chance 1): bit 1 = positive.  sm = 0 for positive, -1 for negative
         FS_THR_PREP "s_nop 0\n\tv_readlane_b32 %[thr], " FS_VA ", 1\n\t"
-        "s_sub_u32 %[t0], %[R], %[thr]\n\ts_cmp_ge_u32 %[L], %[thr]\n\t"
-        "s_cselect_b32 %[R], %[t0], %[thr]\n\ts_cselect_b32 %[t1], %[thr], 0\n\ts_cselect_b32 %[sign], 2, 0\n\t"
-        "s_cselect_b32 %[amax], %[amaxp], %[amaxn]\n\ts_cselect_b32 %[emax], %[emaxp], %[emaxn]\n\ts_sub_u32 %[L], %[L], %[t1]\n\t"
+        "s_sub_u32 %[t0], %[R], %[thr]\n\ts_sub_u32 %[t1], %[L], %[thr]\n\t"
+        "s_cselect_b32 %[L], %[L], %[t1]\n\ts_cselect_b32 %[R], %[thr], %[t0]\n\ts_cselect_b32 %[sm], -1, 0\n\ts_cselect_b32 %[ilast], %[ilastn], %[ilastp]\n\t"
         FS_RN_CHECK("92f", "82")
-        // ---- unary exponent  (chances 2 + e)
-        "s_mov_b32 %[e], 0\n\ts_mov_b32 %[one], 0\n\ts_cmp_lg_u32 %[emax], 0\n\ts_cbranch_scc0 40f\n"
+        // ---- unary exponent  (chances 2 .. emax + 1 = ilast); idx = the chance decided last
+        "s_mov_b32 %[idx], 1\n\ts_cmp_lt_u32 %[idx], %[ilast]\n\ts_cbranch_scc0 40f\n"
         "20:\n\t"
-        FS_THR_PREP "s_add_u32 %[t0], %[e], 2\n\tv_readlane_b32 %[thr], " FS_VA ", %[t0]\n\t"
+        FS_THR_PREP "s_add_u32 %[idx], %[idx], 1\n\tv_readlane_b32 %[thr], " FS_VA ", %[idx]\n\t"
         "s_cmp_ge_u32 %[L], %[thr]\n\ts_cbranch_scc1 25f\n\t"
         "s_mov_b32 %[R], %[thr]\n\t"
         FS_RN_CHECK("93f", "83")
-        "s_add_u32 %[e], %[e], 1\n\ts_cmp_lt_u32 %[e], %[emax]\n\ts_cbranch_scc1 20b\n\t"
+        "s_cmp_lt_u32 %[idx], %[ilast]\n\ts_cbranch_scc1 20b\n\t"
         "s_branch 40f\n"
         "25:\n\t"
-        "s_sub_u32 %[L], %[L], %[thr]\n\ts_sub_u32 %[R], %[R], %[thr]\n\ts_mov_b32 %[one], 1\n\t"
+        "s_sub_u32 %[L], %[L], %[thr]\n\ts_sub_u32 %[R], %[R], %[thr]\n\t"
         FS_RN_CHECK("94f", "84")
-        // ---- mantissa, top bit first  (chances 16 + pos); a 1 that would exceed amax is not coded (symbol.h:180)
-        "40:\n\t"
-        "s_lshl_b32 %[have], 1, %[e]\n\ts_mov_b32 %[skipped], 0\n\ts_mov_b32 %[t1], %[e]\n"
+        // ---- mantissa, e = idx - 2 < emax: every bit is coded  (chances 16 + pos, top bit first); hv collects the INVERTED bits
+        "s_cmp_eq_u32 %[idx], 2\n\ts_mov_b32 %[hv], 0\n\ts_cbranch_scc1 60f\n\t"
+        "s_add_u32 %[midx], %[idx], 14\n"
         "41:\n\t"
-        "s_sub_u32 %[t1], %[t1], 1\n\ts_cbranch_scc1 60f\n\t"
+        FS_THR_PREP "s_sub_u32 %[midx], %[midx], 1\n\tv_readlane_b32 %[thr], " FS_VA ", %[midx]\n\t"
+        "s_sub_u32 %[t0], %[R], %[thr]\n\ts_sub_u32 %[t1], %[L], %[thr]\n\t"
+        "s_cselect_b32 %[L], %[L], %[t1]\n\ts_cselect_b32 %[R], %[thr], %[t0]\n\ts_addc_u32 %[hv], %[hv], %[hv]\n\t"
+        FS_RN_CHECK("96f", "86")
+        "s_cmp_gt_u32 %[midx], 16\n\ts_cbranch_scc1 41b\n"
+        // ---- value and the (index, bit) pairs of the decisions taken, for leaf_commit
+        "60:\n\t"
+        "s_sub_u32 %[e], %[idx], 2\n\ts_bfm_b32 %[t1], %[e], 16\n\t"              // mantissa chances: ((1 << e) - 1) << 16
+        "s_add_u32 %[t0], %[idx], 1\n\ts_bfm_b32 %[touched], %[t0], 0\n\ts_or_b32 %[touched], %[touched], %[t1]\n\t"   // chances 0 .. idx
+        "s_lshl_b32 %[t0], %[hv], 16\n\ts_andn2_b32 %[t0], %[t1], %[t0]\n\t"      // the mantissa bits as decided, at 16 ..
+        "s_lshl_b32 %[bits], 1, %[idx]\n\ts_or_b32 %[bits], %[bits], %[t0]\n\t"   // the exponent's closing 1
+        "s_andn2_b32 %[t1], 2, %[sm]\n\ts_or_b32 %[bits], %[bits], %[t1]\n\t"     // sign decision
+        "s_lshr_b32 %[t0], %[t0], 16\n\ts_bitset1_b32 %[t0], %[e]\n\t"           // magnitude = 1 << e | mantissa
+        "s_xor_b32 %[t0], %[t0], %[sm]\n\ts_sub_u32 %[res], %[t0], %[sm]\n\t"
+        "s_branch 99f\n"
+        // ---- exponent exhausted: e = emax = idx - 1, no closing 1; a mantissa 1 that would exceed amax is not coded (symbol.h:180)
+        "40:\n\t"
+        "s_sub_u32 %[e], %[idx], 1\n\ts_cmp_eq_u32 %[sm], 0\n\ts_cselect_b32 %[amax], %[amaxp], %[amaxn]\n\t"
+        "s_lshl_b32 %[have], 1, %[e]\n\ts_mov_b32 %[skipped], 0\n\ts_mov_b32 %[t1], %[e]\n"
+        "42:\n\t"
+        "s_sub_u32 %[t1], %[t1], 1\n\ts_cbranch_scc1 61f\n\t"
         "s_lshl_b32 %[t0], 1, %[t1]\n\ts_or_b32 %[res], %[have], %[t0]\n\ts_cmp_gt_i32 %[res], %[amax]\n\ts_cbranch_scc1 45f\n\t"
         FS_THR_PREP "s_add_u32 %[t0], %[t1], 16\n\tv_readlane_b32 %[thr], " FS_VA ", %[t0]\n\t"
         "s_sub_u32 %[t0], %[R], %[thr]\n\ts_cmp_ge_u32 %[L], %[thr]\n\t"
         "s_cselect_b32 %[R], %[t0], %[thr]\n\ts_cselect_b32 %[t0], %[thr], 0\n\ts_cselect_b32 %[have], %[res], %[have]\n\ts_sub_u32 %[L], %[L], %[t0]\n\t"
-        "s_cmp_le_u32 %[R], 0x10000\n\ts_cbranch_scc0 41b\n\t"
-        // (renormalisation inside the mantissa loop uses t0 and bits as scratch: t1 is the loop counter)
-        "s_lshr_b32 %[t0], %[widx], 2\n\tv_readlane_b32 %[t0], %[win], %[t0]\n\ts_lshl_b32 %[bits], %[widx], 3\n\ts_lshr_b32 %[t0], %[t0], %[bits]\n\t"
+        // (the renormalisation stub uses t0 and hv as scratch here: t1 is the loop counter)
+        "s_cmp_le_u32 %[R], 0x10000\n\ts_cbranch_scc0 42b\n\t"
+        "s_lshr_b32 %[t0], %[widx], 2\n\tv_readlane_b32 %[t0], %[win], %[t0]\n\ts_lshl_b32 %[hv], %[widx], 3\n\ts_lshr_b32 %[t0], %[t0], %[hv]\n\t"
         "s_and_b32 %[t0], %[t0], 0xff\n\ts_lshl_b32 %[L], %[L], 8\n\ts_or_b32 %[L], %[L], %[t0]\n\ts_add_u32 %[widx], %[widx], 1\n\ts_lshl_b32 %[R], %[R], 8\n\t"
-        "s_cmp_gt_u32 %[R], 0x10000\n\ts_cbranch_scc1 41b\n\t"
-        "s_lshr_b32 %[t0], %[widx], 2\n\tv_readlane_b32 %[t0], %[win], %[t0]\n\ts_lshl_b32 %[bits], %[widx], 3\n\ts_lshr_b32 %[t0], %[t0], %[bits]\n\t"
+        "s_cmp_gt_u32 %[R], 0x10000\n\ts_cbranch_scc1 42b\n\t"
+        "s_lshr_b32 %[t0], %[widx], 2\n\tv_readlane_b32 %[t0], %[win], %[t0]\n\ts_lshl_b32 %[hv], %[widx], 3\n\ts_lshr_b32 %[t0], %[t0], %[hv]\n\t"
         "s_and_b32 %[t0], %[t0], 0xff\n\ts_lshl_b32 %[L], %[L], 8\n\ts_or_b32 %[L], %[L], %[t0]\n\ts_add_u32 %[widx], %[widx], 1\n\ts_lshl_b32 %[R], %[R], 8\n\t"
-        "s_branch 41b\n"
+        "s_branch 42b\n"
         "45:\n\t"
-        "s_or_b32 %[skipped], %[skipped], %[t0]\n\ts_branch 41b\n"
-        // ---- the (index, bit) pairs of the decisions taken, for leaf_commit; the value
-        "60:\n\t"
-        "s_bfm_b32 %[t0], %[e], 0\n\t"                                          // (1 << e) - 1
-        "s_add_u32 %[t1], %[e], %[one]\n\ts_bfm_b32 %[t1], %[t1], 2\n\t"       // exponent decisions taken: chances 2 .. 2 + e + one - 1
+        "s_or_b32 %[skipped], %[skipped], %[t0]\n\ts_branch 42b\n"
+        "61:\n\t"
+        "s_bfm_b32 %[t0], %[e], 0\n\ts_bfm_b32 %[t1], %[e], 2\n\t"              // (1 << e) - 1; exponent decisions: chances 2 .. 2 + e - 1
         "s_andn2_b32 %[touched], %[t0], %[skipped]\n\ts_lshl_b32 %[touched], %[touched], 16\n\ts_or_b32 %[touched], %[touched], %[t1]\n\ts_or_b32 %[touched], %[touched], 3\n\t"
-        "s_and_b32 %[bits], %[have], %[t0]\n\ts_lshl_b32 %[bits], %[bits], 16\n\ts_add_u32 %[t1], %[e], 2\n\ts_lshl_b32 %[t1], %[one], %[t1]\n\t"
-        "s_or_b32 %[bits], %[bits], %[t1]\n\ts_or_b32 %[bits], %[bits], %[sign]\n\t"
-        "s_sub_u32 %[t1], 0, %[have]\n\ts_cmp_lg_u32 %[sign], 0\n\ts_cselect_b32 %[res], %[have], %[t1]\n\t"
+        "s_and_b32 %[bits], %[have], %[t0]\n\ts_lshl_b32 %[bits], %[bits], 16\n\ts_andn2_b32 %[t1], 2, %[sm]\n\ts_or_b32 %[bits], %[bits], %[t1]\n\t"
+        "s_xor_b32 %[t0], %[have], %[sm]\n\ts_sub_u32 %[res], %[t0], %[sm]\n\t"
         "s_branch 99f\n"
         // ---- the symbol is zero
         "70:\n\t"
         "s_sub_u32 %[L], %[L], %[thr]\n\ts_sub_u32 %[R], %[R], %[thr]\n\ts_mov_b32 %[res], 0\n\ts_mov_b32 %[touched], 1\n\ts_mov_b32 %[bits], 1\n\t"
         FS_RN_CHECK("95f", "85")
         "s_branch 99f\n"
-        FS_RENORM("91", "81b") FS_RENORM("92", "82b") FS_RENORM("93", "83b") FS_RENORM("94", "84b") FS_RENORM("95", "85b")
+        FS_RENORM("91", "81b") FS_RENORM("92", "82b") FS_RENORM("93", "83b") FS_RENORM("94", "84b") FS_RENORM("95", "85b") FS_RENORM("96", "86b")
         "99:\n\t"
         : [R] "+s"(R), [L] "+s"(Lo), [widx] "+s"(widx), [res] "=&s"(res), [touched] "=&s"(touched), [bits] "=&s"(bits), [t0] "=&s"(t0),
-          [t1] "=&s"(t1), [thr] "=&s"(thr), [e] "=&s"(e), [amax] "=&s"(amax), [emax] "=&s"(emax), [sign] "=&s"(sign), [have] "=&s"(have),
-          [one] "=&s"(one), [skipped] "=&s"(skipped)
-        : [leafv] "v"(L.leafv), [win] "v"(s.win), [amaxp] "s"(F.amax_pos), [amaxn] "s"(F.amax_neg), [emaxp] "s"(F.emax_pos),
-          [emaxn] "s"(F.emax_neg)
+          [t1] "=&s"(t1), [thr] "=&s"(thr), [idx] "=&s"(idx), [ilast] "=&s"(ilast), [sm] "=&s"(sm), [hv] "=&s"(hv), [e] "=&s"(e),
+          [midx] "=&s"(midx), [amax] "=&s"(amax), [have] "=&s"(have), [skipped] "=&s"(skipped)
+        : [leafv] "v"(L.leafv), [win] "v"(s.win), [amaxp] "s"(F.amax_pos), [amaxn] "s"(F.amax_neg), [ilastp] "s"(F.ilast_pos),
+          [ilastn] "s"(F.ilast_neg)
         : "scc", "vcc", FS_VA, FS_VB, FS_VC, FS_VK0, FS_VK1);
     r.range = R; r.low = Lo; s.pos = s.win_base + widx;
     L.touched = touched; L.bits = bits;
@@ -629,7 +670,17 @@ DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
 }
 #endif
 DEV void leaf_commit(LeafRegs &L, int lane, const uint16_t *table) {
-    if ((L.touched >> lane) & 1u) L.leafv = table[L.leafv * 2 + ((L.bits >> lane) & 1u)];
+#ifdef FUIF_EMU
+    if ((L.touched >> (lane & 31)) & 1u) L.leafv = table[L.leafv * 2 + ((L.bits >> (lane & 31)) & 1u)];   // (lanes 32..63 mirror 0..31)
+#else
+    // the scalar masks ARE lane masks: inverse_ballot hands them to the compiler as per-lane conditions (EXEC and a v_cndmask
+    // operand) without a vector test per lane.  (An inline-asm load here would be invisible to the compiler's s_waitcnt
+    // placement: tools/test_fast_symbol.hip caught exactly that.)
+    const unsigned long long b64 = (unsigned long long)L.bits * 0x100000001ull, t64 = (unsigned long long)L.touched * 0x100000001ull;   // both halves: lanes 32..63 mirror 0..31
+    const uint32_t boff = __builtin_amdgcn_inverse_ballot_w64(b64) ? 2u : 0u;
+    if (__builtin_amdgcn_inverse_ballot_w64(t64))
+        L.leafv = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(table) + (((uint32_t)L.leafv << 2) | boff));
+#endif
     L.touched = 0; L.bits = 0;
 }
 
@@ -664,7 +715,7 @@ struct RefChan {  // one reference channel of the current group (context_predict
 
 template <int kLdsSuper>
 struct Shared {
-    uint2 snodes[kLdsSuper * 64];        // breadth-first top of the supernode tree: lane i = {split_i, prop_i | exit_i << 8}
+    uint2 snodes[kLdsSuper > 0 ? kLdsSuper * 64 : 1];   // breadth-first top of the supernode tree: lane i = {split_i, prop_i << 2 | exit_i << 8}
     static constexpr int kChunk = kLdsSuper == kLdsDense ? kChunkDense : 64;
     int32_t cprops[(kChunk > 4 ? kChunk : 4) * kPropPitch]; // [pixel of the chunk][property]; the supernode build borrows 256 words
     uint16_t meta_ctx[3][32];            // three SimpleSymbolCoder contexts of the tree coder
@@ -676,14 +727,14 @@ struct Shared {
 // kernel ends -- plain cached stores and loads (write-through stores drop the line from L2, and the
 // decoder re-reads its own previous rows: ~4 % on a whole-stream decode)
 template <bool kHandOff>
-DEV void st_plane(int32_t *p, int v) {
+DEV void st_plane(coef_t *p, int v) {   // a sample is stored as the reference stores it: narrowed to pixel_type (image/image.h:35)
     if (kHandOff) st_agent(p, v);
-    else *p = v;
+    else *p = (coef_t)v;
 }
 template <bool kHandOff>
-DEV int ld_plane(const int32_t *p) { return kHandOff ? ld_agent(p) : *p; }
+DEV int ld_plane(const coef_t *p) { return kHandOff ? ld_agent(p) : (int)*p; }
 template <bool kHandOff>
-DEV void fill_plane(int32_t *plane, int64_t first, int64_t count, int v, int lane) {
+DEV void fill_plane(coef_t *plane, int64_t first, int64_t count, int v, int lane) {
     for (int64_t i = first + lane; i < first + count; i += 64) st_plane<kHandOff>(plane + i, v);
 }
 
@@ -937,7 +988,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
     s.eof_flag = 0;
     s.blob_mode = rfl((int)(job.flags & 1u));
 
-    int32_t *coef = P.coef + (int64_t)img * P.coef_stride;
+    coef_t *coef = P.coef + (int64_t)img * P.coef_stride;
     ChannelMeta *meta = P.meta + (int64_t)img * P.n_channels;
     uint32_t *progress = P.progress + (size_t)img * nch;
     int status = 0;
@@ -1156,7 +1207,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 const int gw = rfl(geom[i].w), gh = rfl(geom[i].h);
                 const int minv = rfl(ld_agent(&meta[i].minval)), maxv = rfl(ld_agent(&meta[i].maxval));
                 if (minv == maxv) continue;
-                int32_t *plane = coef + geom[i].coef_off;
+                coef_t *plane = coef + geom[i].coef_off;
                 const int zero = minv > 0 ? minv : (maxv < 0 ? maxv : 0);
                 int y = 0;
                 for (; y < gh; y++) {
@@ -1354,7 +1405,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 n_super += __popcll(__ballot(admit));
                 uint2 out;
                 out.x = (uint32_t)(is_raw_slog_prop(st_prop[lane] - nrefprops) && st_split[lane] != 0x7FFFFFFF ? slog_threshold(st_split[lane]) : st_split[lane]);
-                out.y = ((uint32_t)st_prop[lane] & 0xFFu) | (tgt << 8);
+                out.y = (((uint32_t)st_prop[lane] << 2) & 0xFFu) | (tgt << 8);   // the property as a ds_bpermute byte address (lane * 4): no shift or mask per walk round
                 snodes_g[(size_t)sn * 64 + lane] = out;
                 if (sn >= 1 && sn <= kLdsSuper) sh.snodes[(sn - 1) * 64 + lane] = out;   // the root (0) lives in registers: LDS holds 1..kLdsSuper
                 __syncthreads();
@@ -1373,14 +1424,16 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         }  // !resumed
         const uint2 root_nd = snodes_g[lane];  // the root supernode lives in registers
         LeafRegs L;
-        L.leafv = (lane < 32) ? (int)leaves[(int64_t)cur_leaf * kLeafStride + lane] : 0;
+        L.leafv = (int)leaves[(int64_t)cur_leaf * kLeafStride + (lane & 31)];   // lanes 32..63 mirror lanes 0..31 (switch_leaf)
         L.touched = 0; L.bits = 0;
         auto switch_leaf = [&](int id) {
+            // Lanes 32..63 mirror lanes 0..31 (same addresses, same values): the write-back and the fetch need no lane mask, and the
+            // compiler tracks both (32-bit offsets from the leaves' base: a tree has at most 32768 leaves of 64 bytes)
             if (LIKELY(id != cur_leaf)) {
-                if (lane < 32) {
-                    leaves[(int64_t)cur_leaf * kLeafStride + lane] = (uint16_t)L.leafv;
-                    L.leafv = (int)leaves[(int64_t)id * kLeafStride + lane];
-                }
+                char *lb = reinterpret_cast<char *>(leaves);
+                const uint32_t l2 = (uint32_t)(lane & 31) * 2u;
+                *reinterpret_cast<uint16_t *>(lb + ((uint32_t)cur_leaf * 64u + l2)) = (uint16_t)L.leafv;
+                L.leafv = (int)*reinterpret_cast<const uint16_t *>(lb + ((uint32_t)id * 64u + l2));
                 cur_leaf = id;
             }
         };
@@ -1391,7 +1444,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
             const int ghs = rfl(geom[i].hshift), gvs = rfl(geom[i].vshift);
             const int minv = rfl(ld_agent(&meta[i].minval)), maxv = rfl(ld_agent(&meta[i].maxval));
             if (minv == maxv) continue;
-            int32_t *plane = coef + geom[i].coef_off;
+            coef_t *plane = coef + geom[i].coef_off;
             const int zero = minv > 0 ? minv : (maxv < 0 ? maxv : 0);
             int y = resumed ? (int)resume_y : 0;
             uint32_t ref_seen = 0;  // lane k: last progress word seen for reference channel k
@@ -1415,6 +1468,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 FastSym fsym;
                 fsym.amax_pos = maxv - zero; fsym.amax_neg = zero - minv;
                 fsym.emax_pos = ilog2u((uint32_t)fsym.amax_pos); fsym.emax_neg = ilog2u((uint32_t)fsym.amax_neg);
+                fsym.ilast_pos = rfl(fsym.emax_pos + 1); fsym.ilast_neg = rfl(fsym.emax_neg + 1);
                 const bool sym_fast = minv < zero && zero < maxv;   // both signs possible: symbol.h:160-165 codes zero and sign
                 auto rows = [&](auto pred0_tag) {
                     constexpr bool PRED0 = decltype(pred0_tag)::value;
@@ -1456,8 +1510,8 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                 }
                             }
                         }
-                        const int32_t *row1 = plane + (int64_t)(y - 1) * w;
-                        const int32_t *row2 = plane + (int64_t)(y - 2) * w;
+                        const coef_t *row1 = plane + (int64_t)(y - 1) * w;
+                        const coef_t *row2 = plane + (int64_t)(y - 2) * w;
                         // left / leftleft start as `zero`, which is exactly what the edge rules
                         // give at x == 0 (context_predict.h:126,131)
                         int left = zero, leftleft = zero;
@@ -1470,8 +1524,9 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                         const int kloc = lane - nrefprops;
                         // (3, 8, 9, 12 stay raw differences: the supernodes hold slog_threshold(split) for them)
                         const bool f_abs = (kloc == 1);
-                        const int c_left = ((kloc == 1) | (kloc == 3) | (kloc == 12) | (y ? ((kloc == 6) | (kloc == 8)) : ((kloc == 7) | (kloc == 9)))) ? 1 : 0;
-                        const int c_ll = (kloc == 12) ? -1 : 0;
+                        // per-lane masks: d = bias + (left & m_left) - (leftleft & m_ll) -- two ANDs and one add3 instead of two 24-bit multiplies
+                        const int m_left = ((kloc == 1) | (kloc == 3) | (kloc == 12) | (y ? ((kloc == 6) | (kloc == 8)) : ((kloc == 7) | (kloc == 9)))) ? -1 : 0;
+                        const int m_ll = (kloc == 12) ? -1 : 0;
                         for (int x0 = 0; x0 < w; x0 += kChunk) {
                             const int nx = min(kChunk, w - x0);
                             // ---- vector phase: lane j prepares pixel x0+j ------------------------
@@ -1508,13 +1563,22 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                             PROF_LAP(0);
                             int rowv = 0;
                             // ---- scalar phase: one pixel at a time ---------------------------------
-                            for (int j = 0; j < nx; j++) {
+                            // kChunkFast: every symbol of this chunk has its (at most 62) bytes inside the stream -- known once per
+                            // chunk, so the hand-written decoder needs no end-of-stream test per pixel (the loop is compiled twice)
+                            auto pixels = [&](auto chunk_fast_tag) {
+                            constexpr bool kChunkFast = decltype(chunk_fast_tag)::value;
+                            // leftleft = value at x-2, except at x == 1 where the rule is leftleft = left (context_predict.h:131): the first
+                            // pixel of a row is a loop part of its own, so that the rule costs nothing per pixel
+                            const int j_split = x0 == 0 ? 1 : 0;
+                            const int32_t *prow = &sh.cprops[lane & 31];
+                            for (int part = 0; part < 2; part++) {
+                            const int j_end = part ? nx : j_split;
+                            for (int j = part ? j_split : 0; j < j_end; j++) {
                                 PROF_START();
-                                int pv = sh.cprops[j * kPropPitch + (lane & 31)];
+                                int pv = *prow; prow += kPropPitch;   // sh.cprops[j * kPropPitch + (lane & 31)]
                                 const int l = left;
                                 {
-                                    // samples of a compressed group have at most 16 significant bits (check_bit_depth): 24-bit multiplies
-                                    const int d = pv + __mul24(c_left, l) + __mul24(c_ll, leftleft);
+                                    const int d = pv + (l & m_left) + (-leftleft & m_ll);
                                     pv = f_abs ? iabs(d) : d;
                                 }
                                 int guess = zero;
@@ -1544,7 +1608,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                     // Control flow is kept to one `while` with a single condition and if-without-else
                                     // bodies: hipcc's structuriser turns every if/else into 2-3 branches (~25 cycles each).
                                     auto walk_round = [&](const uint2 nd) -> uint32_t {
-                                        const int val = __builtin_amdgcn_ds_bpermute((int)((nd.y & 0xFFu) << 2), pv);
+                                        const int val = __builtin_amdgcn_ds_bpermute((int)nd.y, pv);   // the source lane is address bits 7..2: the exit bits above are ignored
                                         const unsigned long long m = __ballot(val > (int)nd.x);
                                         const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
                                         const bool hit = ((((mlo ^ exp_lo) & msk_lo) | ((mhi ^ exp_hi) & msk_hi)) == 0u);
@@ -1559,9 +1623,11 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                         // (index clamped) and replaced in the rare deep case
                                         // (supernode i sits in LDS slot i-1: the -512 folds into the base address)
                                         uint2 nd;
-                                        const uint32_t li = tgt <= (uint32_t)kLdsSuper ? tgt : (uint32_t)kLdsSuper;
-                                        nd = lds_load_node(lds_nodes_addr + (li - 1u) * 512u + (uint32_t)lane * 8u);
-                                        if (UNLIKELY(tgt > (uint32_t)kLdsSuper)) nd = global_load_node(&snodes_g[(size_t)tgt * 64 + lane]);
+                                        if (kLdsSuper > 0) {
+                                            const uint32_t li = tgt <= (uint32_t)kLdsSuper ? tgt : (uint32_t)kLdsSuper;
+                                            nd = lds_load_node(lds_nodes_addr + (li - 1u) * 512u + (uint32_t)lane * 8u);
+                                            if (UNLIKELY(tgt > (uint32_t)kLdsSuper)) nd = global_load_node(&snodes_g[(size_t)tgt * 64 + lane]);
+                                        } else nd = global_load_supernode(snodes_g, tgt, (uint32_t)lane * 8u);   // dense configuration: every supernode behind the root comes from memory
                                         tgt = walk_round(nd);
                                     }
                                     if (UNLIKELY(tgt & kSlowFlag)) {
@@ -1586,7 +1652,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                     prof_acc[7] += (unsigned)rdlane(L.leafv, 0) & 0u;  // force the leaf load to complete inside this lap
 #endif
                                     PROF_LAP(3);
-                                    if (PRED0 && sym_fast && LIKELY(s.pos + 64u <= s.size)) {
+                                    if (kChunkFast || (PRED0 && sym_fast && LIKELY(s.pos + 64u <= s.size))) {
                                         // the symbol's bytes (at most 62) are in the stream; keep them in the window registers
                                         // (the reload starts at a 4-byte boundary; the 256 bytes it reads lie inside the allocation)
                                         if (UNLIKELY(s.pos - s.win_base > 188u)) {
@@ -1605,11 +1671,14 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                 }
                                 const int v = diff + guess;
                                 rowv = wrlane(v, j, rowv);
-                                // leftleft = value at x-1 for the next pixel; at x == 0 the rule is leftleft = left
-                                leftleft = (x0 + j) ? l : v;
+                                leftleft = l;
                                 left = v;
                                 PROF_LAP(5);
                             }
+                            if (part == 0 && j_split) leftleft = left;   // after x == 0
+                            }
+                            };
+                            if (PRED0 && sym_fast && s.pos + 64u * (uint32_t)(nx + 1) <= s.size) pixels(std::true_type{}); else pixels(std::false_type{});
                             PROF_START();
                             if (lane < nx) st_plane<kHandOff>(plane + (int64_t)y * w + x0 + lane, rowv);
                             __syncthreads();  // cprops is rewritten by the next chunk

@@ -15,6 +15,9 @@ struct Bases {
 void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMeta *meta, int n_channels, int img_first,
                int n_images, hipStream_t stream, int32_t *status = nullptr);   // status: per-image FUIFGPU_ST_* words (optional)
 
+// coefficient samples as the entropy kernel stores them (int16, fuifgpu_internal.h) -> the int32 planes the inverse kernels work on
+void launch_widen(const coef_t *src, int32_t *dst, int64_t n, hipStream_t stream);
+
 // interleaved 8/16-bit samples of up to 5 final planes (export/write_pam.h:136-150)
 struct PackedPlanes {
     int32_t n;

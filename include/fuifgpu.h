@@ -48,7 +48,8 @@ typedef struct {
     int32_t nb_transforms, nb_coded_channels, nb_output_channels, nb_ops;
     int32_t responsive_offsets[5];
     int32_t data_start;
-    int64_t coef_elems, out_elems, tmp_elems; /* int32 elements per image */
+    int64_t coef_elems, out_elems, tmp_elems; /* elements per image: int16 samples in the coefficient slab (a coded sample is the
+                                                 reference's pixel_type, image/image.h:35), int32 in the output and scratch slabs */
     uint64_t signature;
 } fuifgpu_image_info;
 
@@ -80,8 +81,20 @@ void fuifgpu_build_chance_table(uint16_t *table8192, uint32_t alpha, int cut);
  * n_images*out_elems int32 (e.g. a torch tensor's data_ptr); NULL = allocated by the library.
  * tmp_images: number of images whose inverse-transform scratch is resident at once (0 = default). */
 int fuifgpu_batch_create(const fuifgpu_plan *plan, int n_images, size_t blob_capacity_bytes,
-                         int32_t *coef_ext, int32_t *out_ext, int tmp_images, fuifgpu_batch **out);
+                         int16_t *coef_ext, int32_t *out_ext, int tmp_images, fuifgpu_batch **out);
 void fuifgpu_batch_destroy(fuifgpu_batch *batch);
+
+/* A batch WITHOUT an output slab, for batches whose outputs do not fit next to their coefficients (BASELINE config C4: 256 x
+ * 8192x8192x4 -- 137 GB of int16 coefficients, 275 GB of int32 outputs): every image is entropy-decoded in ONE launch, then the
+ * inverse transforms run range by range into caller memory (fuifgpu_batch_undo_transforms_to) and the caller consumes each
+ * slice before the next.  fuifgpu_batch_undo_transforms, _out_ptr, _download_out and _pack_out are refused on such a batch.
+ * The reference has no counterpart: it decodes one image at a time (fuif.cpp:213-233). */
+int fuifgpu_batch_create_streaming(const fuifgpu_plan *plan, int n_images, size_t blob_capacity_bytes, int tmp_images, fuifgpu_batch **out);
+/* Image::undo_transforms(0) for images [first_image, first_image + n_images) of the current decode; their output planes go to
+ * out_device (n_images * out_elems int32, device memory; plan output-channel offsets apply inside each image's slice).  Any
+ * batch takes it; every image once per decode (a range that repeats an image, or a mix with fuifgpu_batch_undo_transforms, is
+ * FUIFGPU_E_ARG). */
+int fuifgpu_batch_undo_transforms_to(fuifgpu_batch *batch, int first_image, int n_images, int32_t *out_device, void *stream);
 
 /* A second set of stream buffers for the SAME slabs, so that the upload of the next batch (host parse + H2D copies, on a copy
  * stream, from another host thread) runs while the previous batch decodes: the sibling owns what fuifgpu_batch_upload writes
@@ -113,15 +126,16 @@ int fuifgpu_batch_decode(fuifgpu_batch *batch, void *stream);
  * inverse Squeeze / Quantize / DCT / ChromaSubsample / YCoCg / YCbCr + final clamp into the
  * output slab. */
 int fuifgpu_batch_undo_transforms(fuifgpu_batch *batch, void *stream);
-/* (once per decode: several inverse steps work in place on the coefficient slab, so a second call, or
- * fuifgpu_batch_download_coef after it, is refused with FUIFGPU_E_ARG until the batch is decoded again) */
+/* (once per decode: the inverse of Approximate rewrites the per-channel metadata, so a second call is refused with FUIFGPU_E_ARG
+ * until the batch is decoded again.  The coefficient slab itself is not touched -- the kernels work on a widened copy of a chunk
+ * of images -- and fuifgpu_batch_download_coef stays legal after it.) */
 
 int fuifgpu_batch_sync(fuifgpu_batch *batch, void *stream);
 /* status[n_images] (FUIFGPU_ST_* bits), bytes_consumed[n_images] (io.ftell() at the end) */
 int fuifgpu_batch_status(fuifgpu_batch *batch, int32_t *status, uint32_t *bytes_consumed);
 /* {minval,maxval,q,decoded} of every coded channel of one image (Channel::minval/maxval/q) */
 int fuifgpu_batch_channel_meta(fuifgpu_batch *batch, int image, int32_t *meta4_per_channel);
-int32_t *fuifgpu_batch_coef_ptr(fuifgpu_batch *batch, int image);   /* device pointer */
+int16_t *fuifgpu_batch_coef_ptr(fuifgpu_batch *batch, int image);   /* device pointer: int16 samples (ABI 2; fuifgpu_batch_download_coef hands them out as int32) */
 int32_t *fuifgpu_batch_out_ptr(fuifgpu_batch *batch, int image);    /* device pointer */
 int fuifgpu_batch_download_coef(fuifgpu_batch *batch, int image, int32_t *host, void *stream);
 int fuifgpu_batch_download_out(fuifgpu_batch *batch, int image, int32_t *host, void *stream);

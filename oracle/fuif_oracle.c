@@ -277,6 +277,11 @@ static void ch_setzero(fo_channel *c) {
     else if (c->maxval < 0) c->zero = c->maxval;
     else c->zero = 0;
 }
+/* A stored sample is the reference's pixel_type = int16_t (image/image.h:35): what the entropy decoder stores -- decoded samples, the
+ * fill of a constant plane, the `zero` a resize fills with -- is narrowed like an assignment to pixel_type narrows it.  No effect on
+ * valid streams (check_bit_depth, encoding.cpp:61-72, caps compressed samples at 15 bits of magnitude); on damaged ones an uncompressed
+ * group or a constant plane can name a larger value, and the product's coefficient slab holds int16 samples as well. */
+static inline int32_t px(int v) { return (int32_t)(int16_t)v; }
 /* image/image.h:73-79 resize(): data.resize(w*h, zero) keeps existing leading samples */
 static void ch_materialize(fo_channel *c) {
     /* planes made by the Image constructor (image.h:117-122, data(iw*ih,0)) are kept virtual
@@ -289,17 +294,17 @@ static void ch_resize(fo_channel *c) {
         size_t keep = c->size < want ? c->size : want;
         c->data = (int32_t *)malloc(sizeof(int32_t) * (want ? want : 1));
         for (size_t i = 0; i < keep; i++) c->data[i] = 0;
-        for (size_t i = keep; i < want; i++) c->data[i] = c->zero;
+        for (size_t i = keep; i < want; i++) c->data[i] = px(c->zero);
     } else if (want > c->size) {
         c->data = (int32_t *)realloc(c->data, sizeof(int32_t) * (want ? want : 1));
-        for (size_t i = c->size; i < want; i++) c->data[i] = c->zero;
+        for (size_t i = c->size; i < want; i++) c->data[i] = px(c->zero);
     }
     c->size = want;
 }
 static void ch_fill(fo_channel *c, int v) {
     size_t want = (size_t)c->w * (size_t)c->h;
     c->data = (int32_t *)realloc(c->data, sizeof(int32_t) * (want ? want : 1));
-    for (size_t i = 0; i < want; i++) c->data[i] = v;
+    for (size_t i = 0; i < want; i++) c->data[i] = px(v);
     c->size = want;
 }
 /* image/image.h:82-85 checked accessor (unsigned compare => negative indices also give zero) */
@@ -924,7 +929,7 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
             for (int y = 0; y < c->h; y++) {
                 if (LIMIT_HIT(io, btl)) break;
                 for (int x = 0; x < c->w; x++) {
-                    c->data[(size_t)y * c->w + x] = uniform_read_int(&rac, c->minval, c->maxval - c->minval);
+                    c->data[(size_t)y * c->w + x] = px(uniform_read_int(&rac, c->minval, c->maxval - c->minval));
                     img->stat_symbols++;
                 }
             }
@@ -991,12 +996,16 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
             for (int y = 0; y < c->h; y++) {
                 if (LIMIT_HIT(io, btl)) break;
                 for (int x = 0; x < c->w; x++) {
-                    c->data[(size_t)y * c->w + x] = read_symbol(&rac, leaves, g_table_pixel, c->minval, c->maxval);
+                    c->data[(size_t)y * c->w + x] = px(read_symbol(&rac, leaves, g_table_pixel, c->minval, c->maxval));
                     img->stat_symbols++;
                 }
             }
         } else {
             int32_t *refs = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nref > 0 ? nref : 1) * (size_t)(c->w > 0 ? c->w : 1));
+            /* FO_STATS: the pixel ABOVE as a predictor of this pixel's second-level supernode and leaf (a prefetch keyed on the previous row) */
+            int *up_sn = (int *)malloc(sizeof(int) * (size_t)(c->w + 2)), *up_leaf = (int *)malloc(sizeof(int) * (size_t)(c->w + 2));
+            for (int x = 0; x < c->w + 2; x++) { up_sn[x] = -1; up_leaf[x] = -1; }
+            unsigned long long v_rounds = 0, v_hit = 0, v_hit3 = 0, v_leaf = 0, v_leaf_hit = 0, v_leaf_hit3 = 0;
             for (int y = 0; y < c->h; y++) {
                 if (LIMIT_HIT(io, btl)) break;
                 precompute_references(c, y, img, beginc, img->max_properties, refs, nref);
@@ -1081,7 +1090,9 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
                                 }
                             }
                         }
+                        int my_sn = -1;
                         while (tree.n[pos].property != -1) {
+                            if (g_stats > 0 && depth == 6) { my_sn = pos; v_rounds++; if (pos == up_sn[x + 1]) v_hit++; if (pos == up_sn[x + 1] || pos == up_sn[x] || pos == up_sn[x + 2]) v_hit3++; }
                             if (g_stats > 0 && depth == 6) { g_st.spec_round2++; if (pos == st_tag[0] || pos == st_tag[1]) g_st.spec_hit++; }
                             if (g_stats > 0 && depth && depth % 6 == 0) g_st.rounds_behind++;
                             if (g_stats > 0 && depth == 12) { g_st.r3_rounds++; if (pos == st_t3[0][0]) g_st.r3_hit[0]++; if (pos == st_t3[1][0] || pos == st_t3[1][1]) g_st.r3_hit[1]++; }
@@ -1103,6 +1114,11 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
                             for (int b = 0; b < 3; b++) for (int q = 0; q < (2 << b); q++) if (st_ltag[b][q] == (int)tree.n[pos].childID) { g_st.leaf_hit[b]++; break; }
                         }
                         if (g_stats > 0) {
+                            const int lf = (int)tree.n[pos].childID;
+                            if (lf != st_prev_leaf) { v_leaf++; if (lf == up_leaf[x + 1]) v_leaf_hit++; if (lf == up_leaf[x + 1] || lf == up_leaf[x] || lf == up_leaf[x + 2]) v_leaf_hit3++; }
+                            up_sn[x + 1] = my_sn; up_leaf[x + 1] = lf;
+                        }
+                        if (g_stats > 0) {
                             int se = 0, si = 0;
                             fo_spec_walk(tree.n, 0, 0, props, nref, y, &se, &si);
                             g_st.spec_exits += se; g_st.spec_inner += si;
@@ -1118,11 +1134,15 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
                                          g_slot_acc[0]++; if (lf_root[lid]) g_slot_acc[1]++; else { if (sl < 4) g_slot_acc[2]++; if (sl < 8) g_slot_acc[3]++; if (sl < 16) g_slot_acc[4]++; } }
                         diff = read_symbol(&rac, leaves + (size_t)tree.n[pos].childID * CH_N, g_table_pixel, mn, mx);
                     }
-                    c->data[(size_t)y * c->w + x] = diff + guess;
+                    c->data[(size_t)y * c->w + x] = px(diff + guess);
                     img->stat_symbols++;
                 }
             }
             free(refs);
+            if (g_stats > 0 && v_rounds > 100000)
+                fprintf(stderr, "  vertical predictor c%d: second-level supernode = the one of the pixel above: %.1f %% of %llu rounds (above or its neighbours: %.1f %%); leaf = the leaf above: %.1f %% of %llu switches (3 candidates: %.1f %%)\n",
+                        i, 100.0 * v_hit / v_rounds, v_rounds, 100.0 * v_hit3 / v_rounds, 100.0 * v_leaf_hit / (v_leaf ? v_leaf : 1), v_leaf, 100.0 * v_leaf_hit3 / (v_leaf ? v_leaf : 1));
+            free(up_sn); free(up_leaf);
         }
         if (LIMIT_HIT(io, btl)) break;
     }

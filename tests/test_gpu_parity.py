@@ -119,8 +119,9 @@ def test_packed_output_is_the_pam_payload(gpulib, manifest, port):
 
 
 def test_undo_transforms_is_once_per_decode(gpulib, manifest):
-    """the inverse schedule works in place on the coefficients (dequantisation, YCoCg, ...): a second pass over the same
-    decode, or reading the coefficients after it, is refused instead of returning twice-transformed data"""
+    """the inverse schedule rewrites channel metadata (Approximate): a second pass over the same decode is refused instead of
+    returning twice-transformed data.  The coefficient slab (int16 samples) is NOT consumed: the kernels work on a widened copy,
+    so the coefficients read the same before and after"""
     by = {e["name"]: e for e in manifest["fixtures"]}
     e = by["jpeg420_256x192_q90"] if "jpeg420_256x192_q90" in by else manifest["fixtures"][0]
     blob = golden_blob(e, e["cases"][0])
@@ -129,15 +130,15 @@ def test_undo_transforms_is_once_per_decode(gpulib, manifest):
     try:
         batch.upload([blob])
         batch.decode()
-        batch.coef_planes(0)
+        before = batch.coef_planes(0)
         batch.undo_transforms()
         batch.sync()
         first = batch.out_planes(0)
         with pytest.raises(gpulib.FuifGpuError) as ei:
             batch.undo_transforms()
         assert ei.value.code == 4   # FUIFGPU_E_ARG
-        with pytest.raises(gpulib.FuifGpuError):
-            batch.coef_planes(0)
+        after = batch.coef_planes(0)
+        assert all(np.array_equal(a, b) for a, b in zip(before, after))
         batch.decode()                 # a new decode makes both legal again
         batch.undo_transforms()
         batch.sync()

@@ -277,3 +277,44 @@ def test_unsqueeze_kernels_on_geometries_around_their_tile_edges(gpulib, w, h):
         for planes in post:
             for k in range(3):
                 assert np.array_equal(planes[k], img[k]), (fuse, k)
+
+
+def test_streaming_batch_undoes_transforms_range_by_range(gpulib, port):
+    """fuifgpu_batch_create_streaming + fuifgpu_batch_undo_transforms_to (include/fuifgpu.h): a batch without an output slab is
+    entropy-decoded in one launch and its inverse transforms run slice by slice into caller memory -- how BASELINE config C4 (256
+    x 8192x8192x4) fits one launch.  Slices of 1, 3 and the rest, out of order, must give every image its own source pixels; an
+    image twice, a mix with the whole-batch call and the slab-based calls are refused.  Also on an ordinary batch."""
+    import torch
+    n = 7
+    imgs = [photographic(200, 136, 4, 14, seed=9100 + i) for i in range(n)]
+    blobs = [gpulib.encode_image(im, 14, ycocg=False, tree_mode=1, index=True) for im in imgs]
+    plan = gpulib.Plan(blobs[0])
+    oe = plan.info.out_elems
+    outs = plan.output_channels
+    for streaming in (True, False):
+        batch = gpulib.Batch(plan, n, sum(len(b) for b in blobs), streaming=streaming)
+        try:
+            batch.upload(blobs)
+            for rep in range(2):            # a second decode makes every image available again
+                batch.decode()
+                got = {}
+                for first, cnt in ((4, 3), (0, 1), (1, 3)):
+                    buf = torch.empty(cnt * oe, dtype=torch.int32, device="cuda")
+                    batch.undo_transforms_to(first, cnt, buf.data_ptr())
+                    batch.sync()
+                    host = buf.cpu().numpy().reshape(cnt, oe)
+                    for k in range(cnt):
+                        got[first + k] = [host[k, oc["offset"]: oc["offset"] + oc["w"] * oc["h"]].reshape(oc["h"], oc["w"]) for oc in outs]
+                assert not batch.status()[0].any()
+                for i in range(n):
+                    assert all(np.array_equal(got[i][c], imgs[i][c]) for c in range(4)), (streaming, rep, i)
+                buf = torch.empty(oe, dtype=torch.int32, device="cuda")
+                with pytest.raises(gpulib.FuifGpuError):
+                    batch.undo_transforms_to(2, 1, buf.data_ptr())       # image 2 again
+                with pytest.raises(gpulib.FuifGpuError):
+                    batch.undo_transforms()                               # the whole batch after ranges (and: no slab when streaming)
+            if streaming:
+                with pytest.raises(gpulib.FuifGpuError):
+                    batch.out_planes(0)
+        finally:
+            batch.close()
