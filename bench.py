@@ -451,6 +451,77 @@ def run_streamed(args, wl, inputs, blobs, dev, dist, rank, world, W, H, C, BITS,
         raise SystemExit("PARITY FAILURE: decoded planes differ from the source pixels")
 
 
+def pmc_child(args):
+    """what live_pmc_traffic() runs under `rocprofv3 --pmc <one counter>`: the headline launch once, nothing else (inputs from the
+    parent's cache, no checks, no CPU legs).  Prints the launch's HIP-event time."""
+    import fuif_amd
+    wl = WORKLOADS[args.workload]
+    K = max(1, min(args.distinct, args.batch))
+    inputs = make_inputs(K, args.width, args.height, wl["channels"], wl["bits"], 1000, args.cache, wl["kind"])
+    blobs = [inputs[i % K][1] for i in range(args.batch)]
+    plan = fuif_amd.Plan(blobs[0])
+    batch = fuif_amd.Batch(plan, args.batch, sum(len(b) for b in blobs), streaming=True)   # (no output slab: only the entropy kernel runs)
+    batch.set_group_parallel(not args.no_index)
+    batch.upload(blobs)
+    batch.decode()
+    batch.sync()
+    print(json.dumps({"pmc_child_kernel_ms": round(batch.timing()[0], 3)}))
+    batch.close()
+
+
+def live_pmc_traffic(args, committed_src):
+    """HBM traffic of ONE headline launch measured in THIS run: two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE: one counter per
+    pass, no trace domain next to them -- the guide's recipe) over a child process that runs the launch once.  The raw counters are
+    live; the calibration factors (one per access pattern: 64-byte leaf records, 512-byte supernodes, 2-byte sample stores) are
+    the committed ones of tools/ubench_gather.hip (profiles/r*_pmc_traffic.json), named in the result.  Any failure -- no
+    rocprofv3, a timeout, an unexpected CSV -- returns (None, reason): the caller falls back to the committed figure and says so."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="fuif_pmc_")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload, "--batch", str(args.batch), "--width", str(args.width),
+             "--height", str(args.height), "--distinct", str(args.distinct), "--cache", args.cache] + (["--no-index"] if args.no_index else [])
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s failed (%d): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-200:])
+            tot, launches = 0.0, set()
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == counter and "k_maniac_decode" in row.get("Kernel_Name", ""):
+                        tot += float(row["Counter_Value"])
+                        launches.add(row.get("Dispatch_Id"))
+            if not launches:
+                return None, "no %s rows for k_maniac_decode in rocprofv3's output" % counter
+            out[counter] = tot / len(launches)
+            try:
+                out[counter + "_kernel_ms"] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])["pmc_child_kernel_ms"]
+            except (IndexError, KeyError, ValueError):
+                pass
+    except subprocess.TimeoutExpired:
+        return None, "rocprofv3 --pmc pass timed out"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    # one factor per access pattern (committed calibration): reads are a mix of supernodes and leaves weighted by requested bytes
+    rf = (committed_src or {}).get("read_factor_used") or 1.9
+    wf = 1.0
+    traffic = int(out["FETCH_SIZE"] * 1024 * rf + out["WRITE_SIZE"] * 1024 * wf)
+    return traffic, {"measured": "live: two rocprofv3 --pmc passes in this run (FETCH_SIZE, WRITE_SIZE), one launch each", "FETCH_SIZE_KiB": round(out["FETCH_SIZE"]),
+                     "WRITE_SIZE_KiB": round(out["WRITE_SIZE"]), "read_factor_used": rf, "write_factor_used": wf,
+                     "calibration": "factors from the committed profile %s (tools/ubench_gather.hip on the kernel's access patterns)" % (committed_src or {}).get("profile"),
+                     "kernel_ms_under_pmc": [out.get("FETCH_SIZE_kernel_ms"), out.get("WRITE_SIZE_kernel_ms")]}
+
+
 def ensure_ranks(args):
     """`--gpus N` means N ranks, one per GPU of this node.  Under an external launcher (the driver's `python -m
     torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) WORLD_SIZE is already set and must agree; started as a
@@ -519,6 +590,9 @@ def main():
     ap.add_argument("--cache", default=os.environ.get("FUIF_BENCH_CACHE", "/tmp/fuif_bench_cache"))
     ap.add_argument("--no-rccl-selfcheck", action="store_true",
                     help="one GPU: do not start the one-rank RCCL process group that runs the N>1 collectives on cuda:0 (outside the timed region except for the fence's barrier)")
+    ap.add_argument("--pmc-child", action="store_true", help="(internal) run the headline launch once and exit: what the live traffic measurement profiles")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two rocprofv3 --pmc passes over one extra launch each, ~2 min): use the committed profile's figure")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="(tests) start the ranks as --gpus asks, meet on the gloo backend, print {\"n_gpus\": world} and stop: no decoding, no GPU")
     args = ap.parse_args()
@@ -527,6 +601,8 @@ def main():
         return launcher_selftest(args)
 
     import fuif_amd
+    if args.pmc_child:
+        return pmc_child(args)
     rank = int(os.environ.get("RANK", "0"))
     if args.workload == "c5":
         fuif_amd.lib()
@@ -792,6 +868,23 @@ def main():
             h2d.update({"value_incl_h2d": serial, "note": "host parse of every stream + H2D copies from pageable memory + one step; not overlapped"})
         del separate
 
+    # roofline.traffic measured in THIS run (it used to be read from a committed profile): the batch is released first,
+    # the child processes need the device's memory for the same launch
+    live_traffic, live_src = None, None
+    if rank == 0 and world == 1 and args.workload == "c2" and not args.no_live_traffic:
+        committed = pmc_traffic(args.batch, "images" if args.no_index else "groups")[1]
+        n_tiles_keep = n_tiles
+        batch.close()
+        del view, out
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            live_traffic, live_src = live_pmc_traffic(args, committed)
+        except Exception as e:   # noqa: BLE001 -- a measurement aid must not cost the bench line
+            live_traffic, live_src = None, "%s: %s" % (type(e).__name__, str(e)[:200])
+        n_tiles = n_tiles_keep
+
     if rank == 0:
         S = sum(len(b) for b in blobs) / args.batch
         N = info.coef_elems
@@ -803,6 +896,10 @@ def main():
         t_avg = float(np.mean(tr_ms)) / 1e3
         achieved = alg_kernel / d_avg / 1e9
         traffic, traffic_src = pmc_traffic(args.batch, "images" if args.no_index else "groups") if args.workload == "c2" else (None, None)
+        if live_traffic is not None:
+            traffic, traffic_src = live_traffic, dict(live_src, committed_profile_figure=traffic)
+        elif live_src is not None and traffic_src is not None:
+            traffic_src = dict(traffic_src, live_measurement_failed=live_src)
         roofline = {"bound": "hbm", "kernel": "k_maniac_decode", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel_ms": round(d_avg * 1e3, 3), "algorithmic_bytes_per_launch": int(alg_kernel),
