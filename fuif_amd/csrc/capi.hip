@@ -60,6 +60,7 @@ struct fuifgpu_batch {
     bool own_coef = false, own_out = false;
     int tmp_images = 0;
     PlaneRef *d_list = nullptr;
+    int64_t *d_widen = nullptr;       // Plan::widen on the device: the coded planes the inverse kernels want as int32
     unsigned long long *d_prof = nullptr, *d_tile_log = nullptr;   // d_tile_log: only allocated once fuifgpu_batch_tile_log has been asked for
     int tile_log_cap = 0; bool want_tile_log = false;
     // host staging (pinned)
@@ -197,7 +198,7 @@ void fuifgpu_batch_destroy(fuifgpu_batch *b) {
         v.erase(std::remove(v.begin(), v.end(), b), v.end());
     }
     hipFree(b->d_blobs); hipFree(b->d_jobs); hipFree(b->d_geom); hipFree(b->d_meta); hipFree(b->d_status); hipFree(b->d_consumed);
-    hipFree(b->d_tables); hipFree(b->d_scratch); hipFree(b->d_tmp); hipFree(b->d_coef32); hipFree(b->d_list); hipFree(b->d_prof); hipFree(b->d_tile_log);
+    hipFree(b->d_tables); hipFree(b->d_scratch); hipFree(b->d_tmp); hipFree(b->d_coef32); hipFree(b->d_list); hipFree(b->d_widen); hipFree(b->d_prof); hipFree(b->d_tile_log);
     hipFree(b->d_tiles); hipFree(b->d_progress); hipFree(b->d_group_start); hipFree(b->d_sched); hipFree(b->d_layout); hipFree(b->d_ctx);
     if (b->own_coef) hipFree(b->d_coef);
     if (b->own_out) hipFree(b->d_out);
@@ -266,6 +267,10 @@ static int batch_create_impl(const Plan &plan_in, int n_images, size_t blob_capa
     if (!p.idct_src.empty()) {
         CHK(hipMalloc((void **)&b->d_list, sizeof(PlaneRef) * p.idct_src.size()));
         CHK(hipMemcpy(b->d_list, p.idct_src.data(), sizeof(PlaneRef) * p.idct_src.size(), hipMemcpyHostToDevice));
+    }
+    if (!p.widen.empty()) {
+        CHK(hipMalloc((void **)&b->d_widen, sizeof(int64_t) * p.widen.size()));
+        CHK(hipMemcpy(b->d_widen, p.widen.data(), sizeof(int64_t) * p.widen.size(), hipMemcpyHostToDevice));
     }
     CHK(hipMalloc((void **)&b->d_prof, sizeof(unsigned long long) * 8 * n_images));
     CHK(hipMemset(b->d_prof, 0, sizeof(unsigned long long) * 8 * n_images));
@@ -584,11 +589,17 @@ static int undo_range(fuifgpu_batch *b, int first, int count, int32_t *out_base,
     const fuifgpu_batch *r = launch_res(b);
     for (int i0 = first; i0 < first + count; i0 += r->tmp_images) {
         const int cnt = std::min(r->tmp_images, first + count - i0);
-        Bases bases;
-        // the chunk's int16 coefficients, widened: the kernels below read (and dequantisation, Approximate, the match transforms
-        // rewrite) this copy, never the slab the entropy kernel wrote
-        launch_widen(b->d_coef + (int64_t)i0 * p.coef_elems, r->d_coef32, (int64_t)cnt * p.coef_elems, st);
+        Bases bases{};
+        // The coded planes some kernel reads as int32 (or rewrites: dequantisation, Approximate, the match transforms) are copied,
+        // widened, into the chunk's int32 coefficient copy (Plan::widen); Squeeze residuals -- nearly all coded samples of a Squeeze
+        // chain -- are read as int16 straight from the slab the entropy kernel wrote (Op::r16).  The slab itself is never written here.
+        {
+            int64_t widest = 0;
+            for (size_t k = 1; k < p.widen.size(); k += 2) widest = std::max(widest, p.widen[k]);
+            launch_widen_planes(b->d_coef + (int64_t)i0 * p.coef_elems, r->d_coef32, p.coef_elems, b->d_widen, (int)(p.widen.size() / 2), widest, cnt, st);
+        }
         bases.base[BUF_COEF] = r->d_coef32; bases.stride[BUF_COEF] = p.coef_elems;
+        bases.c16 = b->d_coef + (int64_t)i0 * p.coef_elems;
         bases.base[BUF_OUT] = out_base + (int64_t)(i0 - first) * p.out_elems; bases.stride[BUF_OUT] = p.out_elems;
         bases.base[BUF_TMP] = r->d_tmp; bases.stride[BUF_TMP] = p.tmp_elems;
         for (const Op &op : p.ops) launch_op(op, bases, b->d_list, b->d_meta, nch, i0, cnt, st, b->d_status);
@@ -723,7 +734,7 @@ int fuifgpu_batch_pack_out(fuifgpu_batch *b, int first_image, int n_images, int 
     PackedPlanes pp; int bps = 1;
     int rc = packed_layout(p, components, &pp, &bps);
     if (rc != FUIFGPU_OK) return rc;
-    Bases bases;
+    Bases bases{};
     bases.base[BUF_COEF] = nullptr; bases.stride[BUF_COEF] = 0;   // final planes always live in the output slab (plan.cpp finalize())
     bases.base[BUF_OUT] = b->d_out + (int64_t)first_image * p.out_elems; bases.stride[BUF_OUT] = p.out_elems;
     bases.base[BUF_TMP] = launch_res(b)->d_tmp; bases.stride[BUF_TMP] = p.tmp_elems;
@@ -842,7 +853,7 @@ static PlaneRef raw_plane(int buf, int w, int h) {
 int fuifgpu_inv_hsqueeze(const int32_t *avg, int w1, const int32_t *res, int w2, int h, int32_t *out, int n_planes, int64_t sa, int64_t sr,
                          int64_t so, void *stream) {
     if (!avg || !out || (!res && w2 > 0) || w1 < 1 || h < 1 || w1 - w2 < 0 || w1 - w2 > 1 || n_planes < 1 || n_planes > 65535) return FUIFGPU_E_ARG;
-    Bases b;
+    Bases b{};
     b.base[0] = const_cast<int32_t *>(avg); b.stride[0] = sa;
     b.base[1] = const_cast<int32_t *>(res ? res : avg); b.stride[1] = sr;
     b.base[2] = out; b.stride[2] = so;
@@ -855,7 +866,7 @@ int fuifgpu_inv_hsqueeze(const int32_t *avg, int w1, const int32_t *res, int w2,
 int fuifgpu_inv_vsqueeze(const int32_t *avg, int h1, const int32_t *res, int h2, int w, int32_t *out, int n_planes, int64_t sa, int64_t sr,
                          int64_t so, void *stream) {
     if (!avg || !out || (!res && h2 > 0) || h1 < 1 || w < 1 || h1 - h2 < 0 || h1 - h2 > 1 || n_planes < 1 || n_planes > 65535) return FUIFGPU_E_ARG;
-    Bases b;
+    Bases b{};
     b.base[0] = const_cast<int32_t *>(avg); b.stride[0] = sa;
     b.base[1] = const_cast<int32_t *>(res ? res : avg); b.stride[1] = sr;
     b.base[2] = out; b.stride[2] = so;
@@ -867,7 +878,7 @@ int fuifgpu_inv_vsqueeze(const int32_t *avg, int h1, const int32_t *res, int h2,
 }
 static int color_raw(int kind, int32_t *c0, int32_t *c1, int32_t *c2, int w, int h, int p0, int p1, int p2, int minval, int maxval, void *stream) {
     if (!c0 || !c1 || !c2 || w < 1 || h < 1 || p0 < w || p1 < w || p2 < w) return FUIFGPU_E_ARG;
-    Bases b;
+    Bases b{};
     b.base[0] = c0; b.base[1] = c1; b.base[2] = c2;
     b.stride[0] = b.stride[1] = b.stride[2] = 0;
     Op op = raw_op(kind);
@@ -904,7 +915,7 @@ int fuifgpu_idct8x8(const int32_t *const *src64, int bw, int bh, int32_t *out, i
     HIPCHK(hipMalloc((void **)&d_list, sizeof(PlaneRef) * 64));
     hipError_t e = hipMemcpy(d_list, list.data(), sizeof(PlaneRef) * 64, hipMemcpyHostToDevice);
     if (e != hipSuccess) { hipFree(d_list); return hip_fail(e, "hipMemcpy"); }
-    Bases b;
+    Bases b{};
     b.base[0] = nullptr; b.stride[0] = 0; b.base[1] = out; b.stride[1] = 0; b.base[2] = nullptr; b.stride[2] = 0;
     Op op = raw_op(OP_IDCT);
     op.p0 = bw; op.p1 = bh; op.hi = maxval; op.idct_first = 0; op.pad = 64;
@@ -935,7 +946,7 @@ int fuifgpu_fwd_vsqueeze(const int32_t *in, int w, int h, int32_t *avg, int32_t 
 }
 int fuifgpu_upsample(const int32_t *in, int w, int h, int srh, int srv, int32_t *out, void *stream) {
     if (!in || !out || w < 1 || h < 1 || srh < 1 || srh > 8 || srv < 1 || srv > 8) return FUIFGPU_E_ARG;
-    Bases b;
+    Bases b{};
     b.base[0] = const_cast<int32_t *>(in); b.stride[0] = 0; b.base[1] = out; b.stride[1] = 0; b.base[2] = nullptr; b.stride[2] = 0;
     Op op = raw_op(OP_UPSAMPLE);
     op.src[0] = raw_plane(0, w, h); op.dst[0] = raw_plane(1, w * srh, h * srv); op.p0 = srh; op.p1 = srv;

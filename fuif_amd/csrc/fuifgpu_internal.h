@@ -16,8 +16,10 @@ enum : int {
 
 constexpr int kMaxBitDepth = 15;        // config.h:5 (MAX_BIT_DEPTH)
 constexpr int kNonRefProps = 13;        // encoding/context_predict.h:210
-constexpr int kMaxProps = 32;           // 2*6 reference properties + 13 local ones = 25 at default options
-constexpr int kMaxRefs = 9;            // 2*9 + 13 = 31 properties: what the 32 property lanes of the pixel loop hold (-E 18)
+constexpr int kMaxProps = 64;           // 2*6 reference properties + 13 local ones = 25 at default options; one property per lane of the wavefront
+constexpr int kMaxRefs = 25;            // 2*25 + 13 = 63 properties: what the 64 lanes hold (-E 50).  Up to 9 references (31 properties, -E 18) a chunk's
+                                        // property rows have 33 words and the chunk its full length; beyond, 65 words and half the pixels (round 4)
+constexpr int kFastRefs = 9;            // references whose loads the vector phase issues together (unrolled); further ones go through a loop
 constexpr int kMaxNodes = 65535;        // childID is uint16_t (maniac/compound.h:46)
 constexpr int kLeafStride = 32;         // 31 chances (maniac/symbol.h:72-77) padded to 64 bytes
 constexpr int kTreeStackDepth = 2048;   // explicit stack replacing the recursion of compound.h:277-308
@@ -113,6 +115,9 @@ struct Op {
     int32_t idct_first;        // OP_IDCT: index into Plan::idct_src of the 64 source planes
     int32_t pad;
     PlaneRef ext[1];           // OP_HSQ2_YCOCG: a fourth source
+    int32_t r16;               // squeeze family: the residual plane(s) are coded planes nobody has rewritten -- the kernel reads them as int16 samples
+                               // straight from the coefficient slab (no widened copy of them is made)
+    int32_t pad2;
 };
 
 struct TransformDesc {
@@ -137,6 +142,8 @@ struct Plan {
     // inverse schedule (image/image.cpp:94-115)
     std::vector<Op> ops;
     std::vector<PlaneRef> idct_src;
+    std::vector<int64_t> widen;                 // {element offset, elements} pairs: the coded planes some inverse kernel reads (or rewrites) as int32 --
+                                                // they are widened into the int32 copy before the schedule runs; squeeze residuals are not (Op::r16)
     std::vector<OutputChannel> outputs;
     int64_t out_elems = 0, tmp_elems = 0;
     uint64_t signature = 0;                     // equal signature <=> same geometry & schedule

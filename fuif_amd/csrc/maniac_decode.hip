@@ -96,7 +96,8 @@ constexpr int kLdsWide = FUIF_LDS_WIDE, kLdsDense = FUIF_LDS_DENSE;
 constexpr int kSizeOrdered = FUIF_SIZE_ORDERED;
 constexpr uint32_t kLeafFlag = 0x800000u;
 constexpr uint32_t kSlowFlag = 0x400000u;   // exit leads to a plain tree node (index in the low 16 bits), not to a supernode
-constexpr int kPropPitch = 33;    // odd pitch: conflict-free column writes / row reads
+constexpr int kPropPitch = 33;    // odd pitch: conflict-free column writes / row reads; groups with more than 31 properties use 2 * 33 - 1 = 65 words and half the chunk
+constexpr int kPropPitchWide = 65;
 // Pixels whose properties are prepared at once (lane = pixel).  The property rows are the largest LDS
 // item; a shorter chunk buys resident wavefronts (the real lever of this kernel: it is issue bound).
 #ifndef FUIF_CHUNK
@@ -1172,6 +1173,12 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
             nprops += kNonRefProps;
         }
         const int nrefprops = nprops - kNonRefProps;
+        // property rows of a chunk: 33 words and the full chunk up to 31 properties, 65 words and half the chunk beyond (the LDS array
+        // is sized for kChunk rows of 33 words); lane p of the pixel loop holds property p either way
+        const bool wide_props = nprops > 32;
+        const int prop_pitch = wide_props ? kPropPitchWide : kPropPitch;
+        const int prop_mask = wide_props ? 63 : 31;
+        const int chunk_px = wide_props ? kChunk / 2 : kChunk;
 
         int predictability = 2048;
         Rac rac;
@@ -1432,8 +1439,12 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
             if (LIKELY(id != cur_leaf)) {
                 char *lb = reinterpret_cast<char *>(leaves);
                 const uint32_t l2 = (uint32_t)(lane & 31) * 2u;
+                // the fetch is issued FIRST: it does not depend on the chances in leafv, the write-back does (the commit's table lookup may
+                // still be landing in them) -- where the walk is short (wide configuration: every round from LDS) that wait would
+                // otherwise sit in front of the leaf's memory round trip
+                const int fresh = (int)*reinterpret_cast<const uint16_t *>(lb + ((uint32_t)id * 64u + l2));
                 *reinterpret_cast<uint16_t *>(lb + ((uint32_t)cur_leaf * 64u + l2)) = (uint16_t)L.leafv;
-                L.leafv = (int)*reinterpret_cast<const uint16_t *>(lb + ((uint32_t)id * 64u + l2));
+                L.leafv = fresh;
                 cur_leaf = id;
             }
         };
@@ -1527,8 +1538,8 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                         // per-lane masks: d = bias + (left & m_left) - (leftleft & m_ll) -- two ANDs and one add3 instead of two 24-bit multiplies
                         const int m_left = ((kloc == 1) | (kloc == 3) | (kloc == 12) | (y ? ((kloc == 6) | (kloc == 8)) : ((kloc == 7) | (kloc == 9)))) ? -1 : 0;
                         const int m_ll = (kloc == 12) ? -1 : 0;
-                        for (int x0 = 0; x0 < w; x0 += kChunk) {
-                            const int nx = min(kChunk, w - x0);
+                        for (int x0 = 0; x0 < w; x0 += chunk_px) {
+                            const int nx = min(chunk_px, w - x0);
                             // ---- vector phase: lane j prepares pixel x0+j ------------------------
                             PROF_START();
                             const int x = min(x0 + lane, w - 1);
@@ -1536,10 +1547,18 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                             const int vtl = (y && x) ? row1[x - 1] : zero;                 // x == 0: topleft = left = zero
                             const int vtr = (x + 1 < w && y) ? row1[x + 1] : vtop;         // context_predict.h:129
                             const int vtt = y > 1 ? row2[x] : vtop;                        // :133
-                            if (kChunk == 64 || lane < kChunk) {
-                                int32_t *cp = sh.cprops + lane * kPropPitch;
+                            if (lane < chunk_px) {
+                                int32_t *cp = sh.cprops + lane * prop_pitch;
+                                // (more than kFastRefs references, -E > 18: the rest one by one -- rare, and its chunks are half as long)
+                                for (int k = kFastRefs; k < nrefs; k++) {
+                                    const RefChan rc = sh.refs[k];
+                                    int ry = (y << gvs) >> rc.vshift; if (ry >= rc.h) ry = rc.h - 1;
+                                    int rx = ghs < 0 ? rc.w - 1 : (x << ghs) >> rc.hshift; if (rx >= rc.w) rx = rc.w - 1;
+                                    const int v = ld_plane<kHandOff>(coef + rc.off + (int64_t)ry * rc.w + rx);
+                                    cp[2 * k] = iabs(v); cp[2 * k + 1] = slog(v);
+                                }
 #pragma unroll
-                                for (int k = 0; k < kMaxRefs; k++) {
+                                for (int k = 0; k < kFastRefs; k++) {
                                     if (k < nrefs) {
                                         // rx = min((x<<hshift)>>ref.hshift, ref.w-1) covers the three cases of context_predict.h:241-284
                                         const RefChan rc = sh.refs[k];
@@ -1570,12 +1589,12 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                             // leftleft = value at x-2, except at x == 1 where the rule is leftleft = left (context_predict.h:131): the first
                             // pixel of a row is a loop part of its own, so that the rule costs nothing per pixel
                             const int j_split = x0 == 0 ? 1 : 0;
-                            const int32_t *prow = &sh.cprops[lane & 31];
+                            const int32_t *prow = &sh.cprops[lane & prop_mask];
                             for (int part = 0; part < 2; part++) {
                             const int j_end = part ? nx : j_split;
                             for (int j = part ? j_split : 0; j < j_end; j++) {
                                 PROF_START();
-                                int pv = *prow; prow += kPropPitch;   // sh.cprops[j * kPropPitch + (lane & 31)]
+                                int pv = *prow; prow += prop_pitch;   // sh.cprops[j * prop_pitch + (lane & prop_mask)]
                                 const int l = left;
                                 {
                                     const int d = pv + (l & m_left) + (-leftleft & m_ll);

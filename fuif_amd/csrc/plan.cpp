@@ -698,6 +698,43 @@ struct Builder {
         }
     }
 
+    // The coefficient slab holds int16 samples; the inverse kernels work on int32 planes.  Most coded samples are Squeeze residuals, each
+    // read exactly once by the unsqueeze that consumes it: those kernels take them as int16 straight from the slab (Op::r16).  Every other
+    // coded plane an op touches -- the lowest-resolution averages, DCT coefficients, palette / match / permutation planes, anything an
+    // earlier op of the schedule has rewritten in place (dequantisation, Approximate, the match transforms) -- goes into Plan::widen and
+    // is copied, widened, into the int32 coefficient copy before the schedule runs.
+    void mark_int16_residuals() {
+        std::vector<std::pair<int64_t, int64_t>> need;
+        std::vector<int64_t> dirty;
+        auto is_dirty = [&](const PlaneRef &r) { for (int64_t o : dirty) if (o == r.off) return true; return false; };
+        auto want = [&](const PlaneRef &r) {
+            if (r.buf != BUF_COEF || (int64_t)r.w * r.h <= 0) return;
+            for (auto &n : need) if (n.first == r.off) { n.second = std::max<int64_t>(n.second, (int64_t)r.w * r.h); return; }
+            need.push_back({r.off, (int64_t)r.w * r.h});
+        };
+        auto clean_coded = [&](const PlaneRef &r) { return r.buf == BUF_COEF && !is_dirty(r); };
+        static const bool enabled = [] { const char *e = getenv("FUIFGPU_INT16_RESIDUALS"); return !e || atoi(e) != 0; }();   // 0: widen everything (A/B, tests)
+        for (Op &op : plan.ops) {
+            op.r16 = 0;
+            const bool squeeze = op.kind == OP_HSQUEEZE || op.kind == OP_VSQUEEZE;
+            if (squeeze && enabled && clean_coded(op.src[1])) { op.r16 = 1; want(op.src[0]); }
+            else if (op.kind == OP_HSQ2_YCOCG && enabled && clean_coded(op.src[1]) && clean_coded(op.ext[0])) { op.r16 = 1; want(op.src[0]); want(op.src[2]); }
+            else { for (int d = 0; d < 3; d++) want(op.src[d]); want(op.ext[0]); }
+            for (int d = 0; d < 3; d++) { want(op.dst[d]); if (op.dst[d].buf == BUF_COEF) dirty.push_back(op.dst[d].off); }
+            if (op.kind == OP_APPROX && op.src[0].buf == BUF_COEF) dirty.push_back(op.src[0].off);   // quotient * q + remainder in place
+        }
+        // planes named through the side list (iDCT sources, dequantisation / match / permute lists): read or rewritten as int32, widened up front.
+        // They never are squeeze residuals of a LATER op in a valid chain, but if one is, that op must not read the pristine samples:
+        for (const PlaneRef &r : plan.idct_src) want(r);
+        for (Op &op : plan.ops) {
+            if (!op.r16) continue;
+            auto listed = [&](const PlaneRef &r) { for (const PlaneRef &l : plan.idct_src) if (l.buf == BUF_COEF && l.off == r.off) return true; return false; };
+            if (listed(op.src[1]) || (op.kind == OP_HSQ2_YCOCG && listed(op.ext[0]))) { op.r16 = 0; want(op.src[1]); want(op.ext[0]); }
+        }
+        plan.widen.clear();
+        for (auto &n : need) { plan.widen.push_back(n.first); plan.widen.push_back(n.second); }
+    }
+
     bool finalize() {
         // every plane still referenced by a live channel is a final plane
         int nops_before = (int)ops.size();
@@ -801,6 +838,7 @@ struct Builder {
             plan.ops.push_back(op);
         }
         fuse_chroma_hsqueeze_ycocg();
+        mark_int16_residuals();
         plan.outputs.clear();
         for (auto &ch : live) {
             OutputChannel oc{};

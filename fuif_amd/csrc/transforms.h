@@ -10,6 +10,8 @@ namespace fuifgpu {
 struct Bases {
     int32_t *base[3];
     int64_t stride[3];
+    const coef_t *c16;      // the chunk's coefficient slab as the entropy kernel wrote it (int16 samples; same plane offsets and image stride
+                            // as base[BUF_COEF]): what the squeeze kernels read their residuals from when Op::r16 is set; may be NULL otherwise
 };
 
 void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMeta *meta, int n_channels, int img_first,
@@ -17,6 +19,8 @@ void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMe
 
 // coefficient samples as the entropy kernel stores them (int16, fuifgpu_internal.h) -> the int32 planes the inverse kernels work on
 void launch_widen(const coef_t *src, int32_t *dst, int64_t n, hipStream_t stream);
+// the planes of Plan::widen ({element offset, elements} pairs, device array) of n_images images: src / dst advance by `stride` elements per image
+void launch_widen_planes(const coef_t *src, int32_t *dst, int64_t stride, const int64_t *dev_pairs, int n_planes, int64_t max_elems, int n_images, hipStream_t stream);
 
 // interleaved 8/16-bit samples of up to 5 final planes (export/write_pam.h:136-150)
 struct PackedPlanes {

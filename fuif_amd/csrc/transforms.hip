@@ -41,6 +41,10 @@ namespace {
 #define DEV __device__ __forceinline__
 
 DEV int32_t *plane_ptr(const Bases &b, const PlaneRef &p, int z) { return b.base[p.buf] + (int64_t)z * b.stride[p.buf] + p.off; }
+// a squeeze residual: TR = int32_t -> like every other plane; TR = coef_t -> the coded plane itself, int16 samples in the coefficient slab (Op::r16)
+template <typename TR> DEV const TR *residual_ptr(const Bases &b, const PlaneRef &p, int z);
+template <> DEV const int32_t *residual_ptr<int32_t>(const Bases &b, const PlaneRef &p, int z) { return plane_ptr(b, p, z); }
+template <> DEV const coef_t *residual_ptr<coef_t>(const Bases &b, const PlaneRef &p, int z) { return b.c16 + (int64_t)z * b.stride[BUF_COEF] + p.off; }
 DEV int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 }  // namespace
@@ -51,12 +55,13 @@ DEV int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); 
 #define FUIF_VS_STEP 8
 #endif
 constexpr int VS_STEP = FUIF_VS_STEP;
+template <typename TR>
 __global__ __launch_bounds__(256) void k_inv_vsqueeze(Bases b, PlaneRef pa, PlaneRef pr, PlaneRef po, int clamp, int lo, int hi) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int w = pa.w, h1 = pa.h, h2 = pr.h;
     if (x >= w) return;
     const int32_t *a = plane_ptr(b, pa, blockIdx.z) + x;
-    const int32_t *r = plane_ptr(b, pr, blockIdx.z) + x;
+    const TR *r = residual_ptr<TR>(b, pr, blockIdx.z) + x;
     int32_t *o = plane_ptr(b, po, blockIdx.z) + x;
     int avg = a[0];
     int prevB = avg;  // first pair uses tendency(avg,avg,next): squeeze.h:186
@@ -108,13 +113,22 @@ __global__ __launch_bounds__(256) void k_inv_vsqueeze(Bases b, PlaneRef pa, Plan
 // 87.6 ms for the whole inverse schedule; this kernel with 4 pairs per step 68.0 ms (every line re-fetched up to 8
 // times); with 32 pairs per step 49.3 ms.
 struct __attribute__((packed, aligned(4))) Int4U { int32_t v[4]; };
+struct __attribute__((packed, aligned(2))) Short4U { int16_t v[4]; };
+// four consecutive residuals (any 4-byte / 2-byte aligned address): one 16-byte or one 8-byte load
+DEV Int4U load4(const int32_t *p) { return *reinterpret_cast<const Int4U *>(p); }
+DEV Int4U load4(const coef_t *p) {
+    const Short4U s = *reinterpret_cast<const Short4U *>(p);
+    Int4U v; v.v[0] = s.v[0]; v.v[1] = s.v[1]; v.v[2] = s.v[2]; v.v[3] = s.v[3];
+    return v;
+}
 constexpr int HS_STEP = 32;   // pairs per step = one 128-byte line of each input row, two of the output row
+template <typename TR>
 __global__ __launch_bounds__(256) void k_inv_hsqueeze_rows(Bases b, PlaneRef pa, PlaneRef pr, PlaneRef po, int clamp, int lo, int hi) {
     const int y = blockIdx.x * 256 + threadIdx.x;
     const int w1 = pa.w, w2 = pr.w, h = pa.h, wo = w1 + w2;
     if (y >= h) return;
     const int32_t *a = plane_ptr(b, pa, blockIdx.z) + (int64_t)y * w1;
-    const int32_t *r = plane_ptr(b, pr, blockIdx.z) + (int64_t)y * w2;
+    const TR *r = residual_ptr<TR>(b, pr, blockIdx.z) + (int64_t)y * w2;
     int32_t *o = plane_ptr(b, po, blockIdx.z) + (int64_t)y * wo;
     int avg = a[0];
     int left = avg;   // first pair: tendency(avg, avg, next), squeeze.h:89
@@ -123,7 +137,7 @@ __global__ __launch_bounds__(256) void k_inv_hsqueeze_rows(Bases b, PlaneRef pa,
         Int4U rv[HS_STEP / 4], nv[HS_STEP / 4];
 #pragma unroll
         for (int q = 0; q < HS_STEP / 4; q++) {
-            rv[q] = *reinterpret_cast<const Int4U *>(r + x + 4 * q);
+            rv[q] = load4(r + x + 4 * q);
             nv[q] = *reinterpret_cast<const Int4U *>(a + x + 1 + 4 * q);
         }
 #pragma unroll
@@ -175,6 +189,7 @@ constexpr int HL_IN_STEPS = HL_P / 4;      // load instructions per input tile: 
 constexpr int HL_OUT_LANES = HL_P / 2, HL_OUT_STEPS = HL_P / 2;
 constexpr int HL_IN_PITCH = HL_P + 4;        // words
 constexpr int HL_OUT_PITCH = 2 * HL_P + 4;
+template <typename TR>
 __global__ __launch_bounds__(64) void k_inv_hsqueeze_tiles(Bases b, PlaneRef pa, PlaneRef pr, PlaneRef po, int clamp, int lo, int hi) {
     __shared__ __attribute__((aligned(16))) int32_t tile[2 * 64 * HL_IN_PITCH];   // HL_P = 32: 18432 bytes; the 64 x 68-word output tile needs 17408
     const int lane = threadIdx.x;
@@ -183,11 +198,11 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze_tiles(Bases b, PlaneRef pa,
     const int rows = min(64, h - y0);
     if (rows <= 0) return;
     const int32_t *A = plane_ptr(b, pa, blockIdx.z) + (int64_t)y0 * w1;
-    const int32_t *R = plane_ptr(b, pr, blockIdx.z) + (int64_t)y0 * w2;
+    const TR *R = residual_ptr<TR>(b, pr, blockIdx.z) + (int64_t)y0 * w2;
     int32_t *O = plane_ptr(b, po, blockIdx.z) + (int64_t)y0 * wo;
     const bool mine = lane < rows;
     const int32_t *a = A + (int64_t)(mine ? lane : 0) * w1;
-    const int32_t *r = R + (int64_t)(mine ? lane : 0) * w2;
+    const TR *r = R + (int64_t)(mine ? lane : 0) * w2;
     int32_t *o = O + (int64_t)(mine ? lane : 0) * wo;
     int avg = a[0];
     int left = avg;   // first pair: tendency(avg, avg, next), squeeze.h:89
@@ -201,7 +216,7 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze_tiles(Bases b, PlaneRef pa,
 #pragma unroll
         for (int i = 0; i < HL_IN_STEPS; i++) {
             const int row = min((64 / HL_IN_LANES) * i + sub8, rows - 1);   // rows beyond the plane repeat its last row: no branches around the loads
-            grv[i] = *reinterpret_cast<const Int4U *>(R + (int64_t)row * w2 + xt + 4 * piece8);
+            grv[i] = load4(R + (int64_t)row * w2 + xt + 4 * piece8);
             gnv[i] = *reinterpret_cast<const Int4U *>(A + (int64_t)row * w1 + xt + 1 + 4 * piece8);
         }
     };
@@ -280,6 +295,7 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze_tiles(Bases b, PlaneRef pa,
 constexpr int HF_P = 16;
 constexpr int HF_IN_PITCH = HF_P + 4;
 constexpr int HF_OUT_PITCH = 2 * HF_P + 4;
+template <typename TR>
 __global__ __launch_bounds__(64) void k_inv_hsq2_ycocg(Bases b, PlaneRef pa0, PlaneRef pr0, PlaneRef pa1, PlaneRef pr1, PlaneRef py, PlaneRef pg, PlaneRef pb,
                                                        int maxval) {
     __shared__ __attribute__((aligned(16))) int32_t tile[4 * 64 * HF_IN_PITCH];   // 20480 bytes; the two 64 x 36-word output tiles need 18432
@@ -289,7 +305,7 @@ __global__ __launch_bounds__(64) void k_inv_hsq2_ycocg(Bases b, PlaneRef pa0, Pl
     const int rows = min(64, h - y0);
     if (rows <= 0) return;
     const int32_t *A[2] = {plane_ptr(b, pa0, blockIdx.z) + (int64_t)y0 * w1, plane_ptr(b, pa1, blockIdx.z) + (int64_t)y0 * w1};
-    const int32_t *R[2] = {plane_ptr(b, pr0, blockIdx.z) + (int64_t)y0 * w2, plane_ptr(b, pr1, blockIdx.z) + (int64_t)y0 * w2};
+    const TR *R[2] = {residual_ptr<TR>(b, pr0, blockIdx.z) + (int64_t)y0 * w2, residual_ptr<TR>(b, pr1, blockIdx.z) + (int64_t)y0 * w2};
     int32_t *OY = plane_ptr(b, py, blockIdx.z) + (int64_t)y0 * py.w;
     int32_t *OG = plane_ptr(b, pg, blockIdx.z) + (int64_t)y0 * pg.w;
     int32_t *OB = plane_ptr(b, pb, blockIdx.z) + (int64_t)y0 * pb.w;
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(64) void k_inv_hsq2_ycocg(Bases b, PlaneRef pa0, Pl
                 const int row = 16 * i + sub, src = min(row, rows - 1);   // rows beyond the plane repeat its last row: no branches around the loads
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
-                    const Int4U rv = *reinterpret_cast<const Int4U *>(R[c] + (int64_t)src * w2 + x + 4 * piece);
+                    const Int4U rv = load4(R[c] + (int64_t)src * w2 + x + 4 * piece);
                     const Int4U nv = *reinterpret_cast<const Int4U *>(A[c] + (int64_t)src * w1 + x + 1 + 4 * piece);
                     *reinterpret_cast<int4 *>(tile + (2 * c) * 64 * HF_IN_PITCH + row * HF_IN_PITCH + 4 * piece) = make_int4(rv.v[0], rv.v[1], rv.v[2], rv.v[3]);
                     *reinterpret_cast<int4 *>(tile + (2 * c + 1) * 64 * HF_IN_PITCH + row * HF_IN_PITCH + 4 * piece) = make_int4(nv.v[0], nv.v[1], nv.v[2], nv.v[3]);
@@ -382,13 +398,15 @@ __global__ __launch_bounds__(64) void k_inv_hsq2_ycocg(Bases b, PlaneRef pa0, Pl
         __syncthreads();   // the next tile's loads overwrite what the stores just read
     }
     if (!mine) return;
-    const int32_t *a0 = A[0] + (int64_t)lane * w1, *a1 = A[1] + (int64_t)lane * w1, *r0 = R[0] + (int64_t)lane * w2, *r1 = R[1] + (int64_t)lane * w2;
+    const int32_t *a0 = A[0] + (int64_t)lane * w1, *a1 = A[1] + (int64_t)lane * w1;
+    const TR *r0 = R[0] + (int64_t)lane * w2, *r1 = R[1] + (int64_t)lane * w2;
     int32_t *oy = OY + (int64_t)lane * py.w, *og = OG + (int64_t)lane * pg.w, *ob = OB + (int64_t)lane * pb.w;
     for (; x < w2; x++) {
         int P[2][2];
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            const int32_t *a = c ? a1 : a0, *r = c ? r1 : r0;
+            const int32_t *a = c ? a1 : a0;
+            const TR *r = c ? r1 : r0;
             const int next_avg = x + 1 < w1 ? a[x + 1] : avg[c];   // squeeze.h:100
             const int diff = r[x] + smooth_tendency(left[c], avg[c], next_avg);
             unsqueeze_pair(avg[c], diff, P[c][0], P[c][1]);
@@ -914,33 +932,48 @@ void launch_widen(const coef_t *src, int32_t *dst, int64_t n, hipStream_t stream
     hipLaunchKernelGGL(k_widen16, dim3((unsigned)blocks), dim3(256), 0, stream, src, dst, n);
 }
 
+// one launch for the planes of Plan::widen: blockIdx.y = plane, blockIdx.z = image
+__global__ __launch_bounds__(256) void k_widen_planes(const coef_t *src, int32_t *dst, int64_t stride, const int64_t *pairs) {
+    const int64_t off = pairs[2 * blockIdx.y], n = pairs[2 * blockIdx.y + 1];
+    const coef_t *s = src + (int64_t)blockIdx.z * stride + off;
+    int32_t *d = dst + (int64_t)blockIdx.z * stride + off;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) d[i] = s[i];
+}
+void launch_widen_planes(const coef_t *src, int32_t *dst, int64_t stride, const int64_t *dev_pairs, int n_planes, int64_t max_elems, int n_images, hipStream_t stream) {
+    if (n_planes <= 0 || n_images <= 0) return;
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((max_elems + 1023) / 1024, 512));
+    hipLaunchKernelGGL(k_widen_planes, dim3((unsigned)blocks, (unsigned)n_planes, (unsigned)n_images), dim3(256), 0, stream, src, dst, stride, dev_pairs);
+}
+
 void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMeta *meta, int n_channels, int img_first,
                int n_images, hipStream_t stream, int32_t *status) {
     switch (op.kind) {
         case OP_VSQUEEZE: {
             const int w = op.src[0].w;
             if (w <= 0 || op.dst[0].h <= 0) break;
-            hipLaunchKernelGGL(k_inv_vsqueeze, dim3((w + 255) / 256, 1, n_images), dim3(256), 0, stream, b, op.src[0], op.src[1], op.dst[0],
-                               op.clamp_out, op.lo, op.hi);
+            if (op.r16) hipLaunchKernelGGL(k_inv_vsqueeze<coef_t>, dim3((w + 255) / 256, 1, n_images), dim3(256), 0, stream, b, op.src[0], op.src[1], op.dst[0], op.clamp_out, op.lo, op.hi);
+            else hipLaunchKernelGGL(k_inv_vsqueeze<int32_t>, dim3((w + 255) / 256, 1, n_images), dim3(256), 0, stream, b, op.src[0], op.src[1], op.dst[0], op.clamp_out, op.lo, op.hi);
             break;
         }
         case OP_HSQUEEZE: {
             const int h = op.src[0].h;
             if (h <= 0 || op.dst[0].w <= 0) break;
             static const int tiles = [] { const char *e = getenv("FUIFGPU_HSQUEEZE_TILES"); return e ? atoi(e) : 1; }();   // 0: the lane-per-row kernel for every width (A/B measurements)
-            if (tiles && op.src[1].w >= 2 * HL_P)
-                hipLaunchKernelGGL(k_inv_hsqueeze_tiles, dim3((h + 63) / 64, 1, n_images), dim3(64), 0, stream, b, op.src[0], op.src[1],
-                                   op.dst[0], op.clamp_out, op.lo, op.hi);
-            else
-                hipLaunchKernelGGL(k_inv_hsqueeze_rows, dim3((h + 255) / 256, 1, n_images), dim3(256), 0, stream, b, op.src[0], op.src[1],
-                                   op.dst[0], op.clamp_out, op.lo, op.hi);
+            if (tiles && op.src[1].w >= 2 * HL_P) {
+                if (op.r16) hipLaunchKernelGGL(k_inv_hsqueeze_tiles<coef_t>, dim3((h + 63) / 64, 1, n_images), dim3(64), 0, stream, b, op.src[0], op.src[1], op.dst[0], op.clamp_out, op.lo, op.hi);
+                else hipLaunchKernelGGL(k_inv_hsqueeze_tiles<int32_t>, dim3((h + 63) / 64, 1, n_images), dim3(64), 0, stream, b, op.src[0], op.src[1], op.dst[0], op.clamp_out, op.lo, op.hi);
+            } else {
+                if (op.r16) hipLaunchKernelGGL(k_inv_hsqueeze_rows<coef_t>, dim3((h + 255) / 256, 1, n_images), dim3(256), 0, stream, b, op.src[0], op.src[1], op.dst[0], op.clamp_out, op.lo, op.hi);
+                else hipLaunchKernelGGL(k_inv_hsqueeze_rows<int32_t>, dim3((h + 255) / 256, 1, n_images), dim3(256), 0, stream, b, op.src[0], op.src[1], op.dst[0], op.clamp_out, op.lo, op.hi);
+            }
             break;
         }
         case OP_HSQ2_YCOCG: {
             const int h = op.src[0].h;
             if (h <= 0 || op.p0 <= 0) break;
-            hipLaunchKernelGGL(k_inv_hsq2_ycocg, dim3((h + 63) / 64, 1, n_images), dim3(64), 0, stream, b, op.src[0], op.src[1], op.src[2], op.ext[0],
-                               op.dst[0], op.dst[1], op.dst[2], op.hi);
+            if (op.r16) hipLaunchKernelGGL(k_inv_hsq2_ycocg<coef_t>, dim3((h + 63) / 64, 1, n_images), dim3(64), 0, stream, b, op.src[0], op.src[1], op.src[2], op.ext[0], op.dst[0], op.dst[1], op.dst[2], op.hi);
+            else hipLaunchKernelGGL(k_inv_hsq2_ycocg<int32_t>, dim3((h + 63) / 64, 1, n_images), dim3(64), 0, stream, b, op.src[0], op.src[1], op.src[2], op.ext[0], op.dst[0], op.dst[1], op.dst[2], op.hi);
             break;
         }
         case OP_YCOCG:

@@ -82,6 +82,14 @@ def gather_checksums(local, dist):
     return torch.stack(parts)
 
 
+def byte_sum(t, piece=1 << 28):
+    """int64 sum of a uint8 tensor in pieces: torch widens the whole operand for one sum (8 bytes per byte of input)"""
+    total = 0
+    for o in range(0, t.numel(), piece):
+        total += int(torch.sum(t[o:o + piece], dtype=torch.int64).item())
+    return total
+
+
 def gather_packed(local, dist, root=0, chunk_bytes=256 << 20, keep=True):
     """Final gather: `local` is this rank's packed output, a 1-D uint8 tensor (any length, lengths may
     differ between ranks: mixed geometries, uneven shards).  Returns on the root a list with every rank's bytes in rank
@@ -91,7 +99,7 @@ def gather_packed(local, dist, root=0, chunk_bytes=256 << 20, keep=True):
     keep=False: the root does not store what it receives (a consumer would write it out chunk by chunk) but returns
     one int64 byte sum per rank instead -- for payloads that would not fit next to the root's own decode state."""
     if dist is None:
-        return [local] if keep else [int(torch.sum(local, dtype=torch.int64).item())]
+        return [local] if keep else [byte_sum(local)]
     world, rank = dist.get_world_size(), dist.get_rank()
     sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([local.numel()], dtype=torch.int64, device=local.device))
@@ -102,7 +110,7 @@ def gather_packed(local, dist, root=0, chunk_bytes=256 << 20, keep=True):
             out = [local if r == root else torch.empty(sizes[r], dtype=torch.uint8, device=local.device) for r in range(world)]
         else:
             out = [0] * world
-            out[root] = int(torch.sum(local, dtype=torch.int64).item())
+            out[root] = byte_sum(local)
     longest = max(sizes)
     for off in range(0, longest, chunk_bytes):
         # equal-sized slots per step (gather needs them): a rank past its end sends an empty tail padded in the slot
@@ -120,7 +128,7 @@ def gather_packed(local, dist, root=0, chunk_bytes=256 << 20, keep=True):
                     if keep:
                         out[r][off:off + n_r] = slots[r][:n_r]
                     else:
-                        out[r] += int(torch.sum(slots[r][:n_r], dtype=torch.int64).item())
+                        out[r] += byte_sum(slots[r][:n_r])
     return out
 
 

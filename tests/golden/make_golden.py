@@ -50,6 +50,9 @@ SPECS = [
     ("rgb8_128x128_E0", dict(w=128, h=128, channels=3, bits=8, seed=6), ["-E", "0"]),
     # 18 reference properties = 9 earlier channels in every context tree: the most the GPU path's 32 property lanes hold (2*9+13 = 31)
     ("rgb8_112x96_E18", dict(w=112, h=96, channels=3, bits=8, seed=61), ["-E", "18"]),
+    # round 4: more than 31 properties -- 65-word property rows, half-length chunks, references beyond the unrolled nine (2*25 + 13 = 63 of 64 lanes at -E 50)
+    ("rgb8_112x96_E24", dict(w=112, h=96, channels=3, bits=8, seed=62), ["-E", "24"]),
+    ("rgb8_120x88_E50", dict(w=120, h=88, channels=3, bits=8, seed=63), ["-E", "50"]),
     ("rgb8_64x64_U", dict(w=64, h=64, channels=3, bits=8, seed=7), ["-U"]),
     ("rgb8_160x120_Q80", dict(w=160, h=120, channels=3, bits=8, seed=8), ["-Q", "80"]),
     ("rgb8_96x96_nosqueeze", dict(w=96, h=96, channels=3, bits=8, seed=9), ["-R", "0"]),
@@ -113,7 +116,7 @@ PERMUTE_SPECS = [
 PREVIEWS = {"c1_rgb8_512x512": [0, 1, 2, 3, 4], "rgb8_97x61": [0, 2, 4], "jpeg420_256x192_q90": [0, 1, 2, 3, 4],
             "pal_rgb_graphic_120x90": [1, 3], "approx_rgb8_96x80_A3": [2], "approx_quant_rgb8_40x30": [3], "match_rgb_graphic_96x80": [3]}
 TRUNCATE_EXTRA = {"approx_on_palette_gray12_24x50": [0.8], "match_rgb_graphic_96x80": [0.6]}
-TRUNCATE = {"permute_channel_rgb8_48x40": [0.5], "permute_explicit_rgb8_48x40": [0.6], "rgb8_97x61": [0.2, 0.55, 0.93], "rgb8_128x128_I0": [0.5], "rgb8_112x96_E18": [0.7], "jpeg420_256x192_q90": [0.4], "rgb8_64x64_U": [0.6],
+TRUNCATE = {"permute_channel_rgb8_48x40": [0.5], "permute_explicit_rgb8_48x40": [0.6], "rgb8_97x61": [0.2, 0.55, 0.93], "rgb8_128x128_I0": [0.5], "rgb8_112x96_E18": [0.7], "rgb8_120x88_E50": [0.6], "jpeg420_256x192_q90": [0.4], "rgb8_64x64_U": [0.6],
             "pal_rgba_graphic_72x64": [0.5], "pal_rgb_sparse_128x96": [0.7],
             "gray8_nosqueeze_60x40": [0.6], "rgb8_96x96_nosqueeze": [0.45]}
 

@@ -57,7 +57,7 @@ def main():
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", *flags,
                         os.path.join(ROOT, "fuif_amd/csrc/maniac_decode.hip"), "-o", out], check=True, stderr=subprocess.DEVNULL)
         lines = open(out).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if re.match(r"_ZN7fuifgpu15k_maniac_decodeILi2ELb1EEEvNS_12DecodeParamsE:", l))
+    start = next(i for i, l in enumerate(lines) if re.match(r"_ZN7fuifgpu15k_maniac_decodeILi0ELb1EEEvNS_12DecodeParamsE:", l))
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     body = lines[start:end + 1]
     # basic blocks: label -> (loop header it is in, is itself a header, parents)
