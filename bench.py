@@ -929,7 +929,7 @@ def main():
                             "run), calibrated on the kernel's two access patterns",
                     "transforms": {"ms": round(t_avg * 1e3, 3), "achieved": round(args.batch * (2.0 * N + 4.0 * P) / t_avg / 1e9, 1),
                                    "unit": "GB/s", "algorithmic_bytes": int(args.batch * (2.0 * N + 4.0 * P)),
-                                   "note": "int16 coefficients in, int32 planes out; the kernels work on an int32 copy of a chunk's coefficients (k_widen16: +6 N bytes of traffic)"},
+                                   "note": "int16 coefficients in, int32 planes out; squeeze residuals are read as int16 straight from the slab, the few other coded planes through a widened copy (Plan::widen)"},
                     "path_bytes_per_image": int(S + 4.0 * N + 4.0 * P)}
         res = {"metric": "Mpixels/s decode (4K Squeeze+YCoCg)" if args.workload == "c2" else "Mpixels/s decode (%s)" % args.workload, "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,

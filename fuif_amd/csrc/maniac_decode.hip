@@ -30,11 +30,15 @@
 //   * decoded pixels are collected in a VGPR and stored 64 at a time.
 // A single wave issues one instruction every ~4.6 cycles, a taken branch costs ~25 and a
 // VALU<->SALU hand-over ~14 (tools/ubench.hip), so the kernel is bound by the instruction count of
-// the per-symbol chain; every item above trades scalar instructions for vector ones.
-// Two LDS configurations are built: "wide" = 39 KB per wave (29 KB of supernodes, 8.4 KB of chunk
-// properties, small state; 4 waves per CU) and "dense" = 10 KB (2 supernodes; 16 waves per CU, four per
-// SIMD, which fill each other's stalls when tiles outnumber SIMDs).  The 16 KB chance transition table is read
-// through L1/L2 instead: its lookups are off the dependency chain thanks to the batched update.
+// the per-symbol chain (and by two dependent HBM round trips per symbol: a supernode, the leaf); every
+// item above trades scalar instructions for vector ones.  Measured on the 1024 x 4K launch (round 4,
+// profiles/r4_instruction_probes.txt): one more scalar instruction per symbol costs 0.37 % of the launch,
+// a vector one 0.19 %, a taken branch 0.44 % -- ~165 instructions per symbol since round 4 (was 202).
+// Two LDS configurations are built: "wide" = 38.9 KB per wave (29 KB of supernodes, 8.4 KB of chunk
+// properties, small state; one wave per SIMD) and "dense" = 5.7 KB (no supernode slots, 32-pixel chunks;
+// 80 VGPRs: 24 waves per CU, six per SIMD, which fill each other's stalls when tiles outnumber SIMDs).
+// The 16 KB chance transition table is read through L1/L2 instead: its lookups are off the dependency
+// chain thanks to the batched update.
 //
 // What it replaces in the reference:
 //   fuif_decode channel loop            encoding/encoding.cpp:708-717
@@ -80,9 +84,9 @@ constexpr int CH_ZERO = 0, CH_SIGN = 1, CH_EXP = 2, CH_MANT = 16, CH_N = 31;
 // Supernodes (512 B each) of the context tree kept in LDS: the kernel is built twice.
 //   kLdsWide  : 29 KB of tree per wavefront, 1 wavefront per SIMD -- best when there are no more
 //               tiles than SIMDs (streams without a group index: one tile per image)
-//   kLdsDense : 1 KB of tree, 4 wavefronts per SIMD -- best when tiles abound (group index): the
-//               kernel is issue bound, co-resident wavefronts fill each other's stalls (measured
-//               1024 x 4K: 305 -> 470 Mpx/s) and hide the extra L2 trips of the deeper levels
+//   kLdsDense : no tree in LDS (the root supernode lives in registers), 6 wavefronts per SIMD -- best when
+//               tiles abound (group index): co-resident wavefronts fill each other's stalls and every round
+//               behind the root is one memory fetch (rounds 1-3 kept two slots that served 0.9 % of the rounds)
 #ifndef FUIF_LDS_WIDE
 #define FUIF_LDS_WIDE 58
 #endif
