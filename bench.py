@@ -458,7 +458,10 @@ def run_streamed(args, wl, inputs, blobs, dev, dist, rank, world, W, H, C, BITS,
                             "algorithmic_bytes_per_launch": int(alg), "note": "kernel_ms / bytes are per step = the sum over the step's chunk launches",
                             "transforms_ms": round(float(np.mean(tr_ms)), 3)}}
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline([b for _, b in inputs], W, H)
+            # (lossless workloads: the checker's own decode of stream 0 is compared with the generator's pixels as well -- at C4's real
+            # size: real reference == source == every GPU-decoded picture)
+            res["cpu_baseline"] = cpu_baseline([b for _, b in inputs], W, H, source=(inputs[0][0], C, BITS) if wl["lossless"] else None)
+            res["speedup_vs_cpu_1thread"] = round(value / res["cpu_baseline"]["value"], 2)
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()

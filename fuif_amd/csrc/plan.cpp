@@ -714,22 +714,37 @@ struct Builder {
         };
         auto clean_coded = [&](const PlaneRef &r) { return r.buf == BUF_COEF && !is_dirty(r); };
         static const bool enabled = [] { const char *e = getenv("FUIFGPU_INT16_RESIDUALS"); return !e || atoi(e) != 0; }();   // 0: widen everything (A/B, tests)
+        std::vector<int64_t> made;   // coded planes whose int32 copy a dequantisation WRITES from the int16 samples (nothing to widen for them)
+        auto is_made = [&](const PlaneRef &r) { for (int64_t o : made) if (o == r.off) return true; return false; };
+        auto want_unless_made = [&](const PlaneRef &r) { if (!(r.buf == BUF_COEF && is_made(r))) want(r); };
         for (Op &op : plan.ops) {
             op.r16 = 0;
             const bool squeeze = op.kind == OP_HSQUEEZE || op.kind == OP_VSQUEEZE;
-            if (squeeze && enabled && clean_coded(op.src[1])) { op.r16 = 1; want(op.src[0]); }
-            else if (op.kind == OP_HSQ2_YCOCG && enabled && clean_coded(op.src[1]) && clean_coded(op.ext[0])) { op.r16 = 1; want(op.src[0]); want(op.src[2]); }
-            else { for (int d = 0; d < 3; d++) want(op.src[d]); want(op.ext[0]); }
-            for (int d = 0; d < 3; d++) { want(op.dst[d]); if (op.dst[d].buf == BUF_COEF) dirty.push_back(op.dst[d].off); }
+            const PlaneRef *list = plan.idct_src.data() + op.idct_first;   // the op's side list: iDCT sources, dequantisation / match / permute planes
+            const int n_list = op.pad > 0 && (size_t)op.idct_first + (size_t)op.pad <= plan.idct_src.size() ? op.pad : 0;
+            if (squeeze && enabled && clean_coded(op.src[1])) { op.r16 = 1; want_unless_made(op.src[0]); }
+            else if (op.kind == OP_HSQ2_YCOCG && enabled && clean_coded(op.src[1]) && clean_coded(op.ext[0])) { op.r16 = 1; want_unless_made(op.src[0]); want_unless_made(op.src[2]); }
+            else if (op.kind == OP_QUANT && enabled && n_list > 0) {
+                // dequantisation of coded planes nobody has touched (the DCT coefficients of a JPEG-transcoded stream): the kernel reads the int16
+                // samples and writes sample * q into the int32 copy -- widening and scaling in one pass (quantize.h:32-49)
+                bool all_clean = true;
+                for (int k = 0; k < n_list; k++) all_clean = all_clean && clean_coded(list[k]) && !is_made(list[k]);
+                for (int k = 0; k < n_list && all_clean; k++) for (int m = 0; m < k; m++) all_clean = all_clean && list[m].off != list[k].off;
+                if (all_clean) { op.r16 = 1; for (int k = 0; k < n_list; k++) made.push_back(list[k].off); }
+            }
+            if (!op.r16) { for (int d = 0; d < 3; d++) want_unless_made(op.src[d]); want_unless_made(op.ext[0]); }
+            if (!(op.kind == OP_QUANT && op.r16)) for (int k = 0; k < n_list; k++) want_unless_made(list[k]);
+            for (int k = 0; k < n_list; k++) if (list[k].buf == BUF_COEF && (op.kind == OP_QUANT || op.kind == OP_MATCH || op.kind == OP_MATCH_APPLY)) dirty.push_back(list[k].off);
+            for (int d = 0; d < 3; d++) { want_unless_made(op.dst[d]); if (op.dst[d].buf == BUF_COEF) dirty.push_back(op.dst[d].off); }
             if (op.kind == OP_APPROX && op.src[0].buf == BUF_COEF) dirty.push_back(op.src[0].off);   // quotient * q + remainder in place
         }
-        // planes named through the side list (iDCT sources, dequantisation / match / permute lists): read or rewritten as int32, widened up front.
-        // They never are squeeze residuals of a LATER op in a valid chain, but if one is, that op must not read the pristine samples:
-        for (const PlaneRef &r : plan.idct_src) want(r);
+        // (a squeeze whose residual is named in some op's side list reads the int32 copy: conservative)
+        for (const PlaneRef &r : plan.idct_src) if (!(r.buf == BUF_COEF && is_made(r))) want(r);
         for (Op &op : plan.ops) {
             if (!op.r16) continue;
             auto listed = [&](const PlaneRef &r) { for (const PlaneRef &l : plan.idct_src) if (l.buf == BUF_COEF && l.off == r.off) return true; return false; };
-            if (listed(op.src[1]) || (op.kind == OP_HSQ2_YCOCG && listed(op.ext[0]))) { op.r16 = 0; want(op.src[1]); want(op.ext[0]); }
+            if (op.kind == OP_QUANT) continue;
+            if (listed(op.src[1]) || (op.kind == OP_HSQ2_YCOCG && listed(op.ext[0]))) { op.r16 = 0; want_unless_made(op.src[1]); want_unless_made(op.ext[0]); }
         }
         plan.widen.clear();
         for (auto &n : need) { plan.widen.push_back(n.first); plan.widen.push_back(n.second); }

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "fuifgpu_internal.h"
 #include "transforms.h"
@@ -471,13 +472,18 @@ __global__ __launch_bounds__(256) void k_inv_ycbcr(Bases b, PlaneRef p0, PlaneRe
 // ---------------------------------------------------------------------------------------------
 // transform/quantize.h:32-49: plane *= q, q = ChannelMeta::q of the plane's source channel.
 // grid.y walks the op's plane list.
+// TR = coef_t (Op::r16): the planes are coded planes nobody has touched -- read the int16 samples from the coefficient slab and write
+// sample * q into the int32 copy (widening and scaling in one pass, also when q == 1); TR = int32_t: in place on the int32 copy.
+template <typename TR>
 __global__ __launch_bounds__(256) void k_dequant(Bases b, const PlaneRef *list, const ChannelMeta *meta, int n_channels, int img_first) {
     const PlaneRef p = list[blockIdx.y];
     const int q = meta[(int64_t)(img_first + blockIdx.z) * n_channels + p.qsrc].q;
-    if (q == 1) return;
+    constexpr bool kFrom16 = !std::is_same<TR, int32_t>::value;
+    if (q == 1 && !kFrom16) return;
     const int64_t n = (int64_t)p.w * p.h;
     int32_t *d = plane_ptr(b, p, blockIdx.z);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] *= q;
+    const TR *s = residual_ptr<TR>(b, p, blockIdx.z);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = (int)s[i] * q;
 }
 
 __global__ __launch_bounds__(256) void k_clamp(Bases b, PlaneRef src, PlaneRef dst, int lo, int hi) {
@@ -986,8 +992,8 @@ void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMe
             break;
         case OP_QUANT: {
             // grid.y = plane of the op's list; 64 grid-striding blocks per plane
-            hipLaunchKernelGGL(k_dequant, dim3(64, op.pad, n_images), dim3(256), 0, stream, b, dev_list + op.idct_first, meta, n_channels,
-                               img_first);
+            if (op.r16) hipLaunchKernelGGL(k_dequant<coef_t>, dim3(64, op.pad, n_images), dim3(256), 0, stream, b, dev_list + op.idct_first, meta, n_channels, img_first);
+            else hipLaunchKernelGGL(k_dequant<int32_t>, dim3(64, op.pad, n_images), dim3(256), 0, stream, b, dev_list + op.idct_first, meta, n_channels, img_first);
             break;
         }
         case OP_IDCT:

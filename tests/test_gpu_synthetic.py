@@ -142,8 +142,11 @@ def test_c4_shape_at_4096_matches_oracle(gpulib, port):
 def test_c4_full_size_image_matches_oracle(gpulib, port):
     """BASELINE config C4 at its real geometry: ONE 8192x8192, 4-channel, 14-bit, Squeeze-only lossless stream (268 M
     symbols, 2.1 GB of planes) through the C-ABI with the group index, every coded plane and every output plane against the
-    CPU oracle.  Takes minutes (the oracle alone ~2) and ~12 GB of host memory, so it only runs when FUIF_TEST_C4_FULL=1;
-    profiles/r2_c4_full_size.txt records the round-2 run.  The same shape at 1024x768 is part of the routine suite above."""
+    CPU oracle.  Takes minutes (one 8192x8192 launch lasts a minute -- its longest group is 33.5 M symbols on one range coder --
+    the writer and two oracle decodes another two) and ~12 GB of host memory, so it only runs when FUIF_TEST_C4_FULL=1.  The
+    routine suite has the same shape at 4096x4096 against the oracle (above); at the real size the streamed bench compares ALL 256
+    pictures with the generator's pixels and has the real reference decode stream 0 to the same pixels (bench.py --workload c4,
+    profiles/r4_c4_full_size.txt)."""
     import os
     if not os.environ.get("FUIF_TEST_C4_FULL"):
         pytest.skip("set FUIF_TEST_C4_FULL=1 (minutes of CPU for the writer and the oracle)")
