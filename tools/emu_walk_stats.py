@@ -4,8 +4,9 @@ Emulator builds count it (fuifgpu_emu_walk_stats).  Used to judge supernode numb
 
   FUIF_AMD_LIB=<emulated library> python tools/emu_walk_stats.py [w h] [--deep]
 
-With a -DFUIF_SPEC_WALK build of the emulated library "from LDS" means: found in a slot the speculative walk of the previous pixel
-had filled."""
+(Round 3 used it to compare the speculative-walk variants with the CPU simulation; those variants were timed on hardware in round 4,
+were slower, and are gone from the kernel: profiles/r4_spec_walk_experiment.txt.  The dense configuration has no LDS slots any more:
+every round behind the root is "from scratch memory" there.)"""
 import ctypes as C
 import os
 import sys
@@ -25,7 +26,7 @@ img = photographic(w, h, 3, 8, seed=1000)
 blob = fuif_amd.encode_image(img, 8, tree_mode=1, index=True, split_bits=split)
 L = fuif_amd.lib()
 st = (C.c_ulonglong * 6)()
-for parallel, name in ((False, "wide  (58 supernodes in LDS, one tile per image)"), (True, "dense ( 2 supernodes in LDS, one tile per group)")):
+for parallel, name in ((False, "wide  (58 supernodes in LDS, one tile per image)"), (True, "dense (no supernodes in LDS, one tile per group)")):
     plan = fuif_amd.Plan(blob)
     b = fuif_amd.Batch(plan, 1, len(blob))
     b.set_group_parallel(parallel)
@@ -38,5 +39,3 @@ for parallel, name in ((False, "wide  (58 supernodes in LDS, one tile per image)
     sym, lds, glob = st[0], st[1], st[2]
     print("%s: %d symbols, %.3f rounds/symbol behind the root, %.1f %% of them from LDS, %.3f scratch fetches per symbol (lossless %s)" % (
         name, sym, (lds + glob) / max(sym, 1), 100.0 * lds / max(lds + glob, 1), glob / max(sym, 1), ok))
-    if st[4]:
-        print("    -DFUIF_SPEC_LEAF: %d leaf switches, %.1f %% of them served from a speculated LDS leaf slot" % (st[4], 100.0 * st[5] / st[4]))

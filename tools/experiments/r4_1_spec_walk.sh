@@ -1,4 +1,6 @@
 #!/bin/bash
+# RECORD of the first GPU session of round 4 (result: profiles/r4_spec_walk_experiment.txt).  The -DFUIF_SPEC_WALK / -DFUIF_SPEC_LEAF code this
+# script builds was DELETED from maniac_decode.hip right after it (both variants were slower); the script runs as written only at commit 6e77e44.
 # Round 4, experiment prepared at the end of round 3 (no GPU minutes were left to run it): the speculative early walk,
 # -DFUIF_SPEC_WALK (fuif_amd/csrc/maniac_decode.hip; profiles/r3_first_left_dependent_test.txt).
 # The release kernel is bit-identical with and without the macro's code in the source (checked on the ISA); the variant is
