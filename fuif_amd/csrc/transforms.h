@@ -17,8 +17,7 @@ struct Bases {
 void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMeta *meta, int n_channels, int img_first,
                int n_images, hipStream_t stream, int32_t *status = nullptr);   // status: per-image FUIFGPU_ST_* words (optional)
 
-// coefficient samples as the entropy kernel stores them (int16, fuifgpu_internal.h) -> the int32 planes the inverse kernels work on
-void launch_widen(const coef_t *src, int32_t *dst, int64_t n, hipStream_t stream);
+// coefficient samples as the entropy kernel stores them (int16, fuifgpu_internal.h) -> the int32 planes the inverse kernels work on:
 // the planes of Plan::widen ({element offset, elements} pairs, device array) of n_images images: src / dst advance by `stride` elements per image
 void launch_widen_planes(const coef_t *src, int32_t *dst, int64_t stride, const int64_t *dev_pairs, int n_planes, int64_t max_elems, int n_images, hipStream_t stream);
 

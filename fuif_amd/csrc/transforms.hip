@@ -917,27 +917,8 @@ static inline dim3 grid1d(int64_t n, int block, int z, int y = 1) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// int16 coefficient samples -> int32: 8 samples per lane and step (one 16-byte load, two 16-byte stores); streaming, HBM bound
-// (6 bytes per sample).  Slabs and plane offsets are 256-byte aligned, the tail is done sample by sample.
-__global__ __launch_bounds__(256) void k_widen16(const coef_t *src, int32_t *dst, int64_t n) {
-    const int64_t n8 = n >> 3;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
-        const int4 v = reinterpret_cast<const int4 *>(src)[i];
-        int4 lo, hi;
-        lo.x = (int)(int16_t)(v.x & 0xFFFF); lo.y = v.x >> 16; lo.z = (int)(int16_t)(v.y & 0xFFFF); lo.w = v.y >> 16;
-        hi.x = (int)(int16_t)(v.z & 0xFFFF); hi.y = v.z >> 16; hi.z = (int)(int16_t)(v.w & 0xFFFF); hi.w = v.w >> 16;
-        reinterpret_cast<int4 *>(dst)[2 * i] = lo;
-        reinterpret_cast<int4 *>(dst)[2 * i + 1] = hi;
-    }
-    for (int64_t i = (n8 << 3) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
-}
-void launch_widen(const coef_t *src, int32_t *dst, int64_t n, hipStream_t stream) {
-    if (n <= 0) return;
-    const int64_t blocks = std::min<int64_t>(((n >> 3) + 255) / 256 + 1, 256 * 32);
-    hipLaunchKernelGGL(k_widen16, dim3((unsigned)blocks), dim3(256), 0, stream, src, dst, n);
-}
-
+// int16 coefficient samples -> int32 for the coded planes the inverse kernels want as int32 (Plan::widen: the few planes that are not
+// squeeze residuals or freshly dequantised DCT coefficients); streaming, HBM bound (6 bytes per sample).
 // one launch for the planes of Plan::widen: blockIdx.y = plane, blockIdx.z = image
 __global__ __launch_bounds__(256) void k_widen_planes(const coef_t *src, int32_t *dst, int64_t stride, const int64_t *pairs) {
     const int64_t off = pairs[2 * blockIdx.y], n = pairs[2 * blockIdx.y + 1];

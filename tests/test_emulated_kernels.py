@@ -92,11 +92,11 @@ def test_pinned_tiles_with_concurrent_emulated_wavefronts(ctx_kb):
         pytest.skip("the emulator's context switch is x86-64 SysV assembly")
     lib = build_emulated_library()
     env = dict(os.environ)
-    env.update(FUIF_AMD_LIB=lib, FUIF_TEST_MAX_PIXELS="50000", FUIF_TEST_BATCH="12", FUIF_TEST_PINNED_BATCH="3", EMU_ALARM="1500", EMU_WAVES="4", EMU_THREADS="4",
+    # (the small fixtures only: the hand-off protocol at full fixture size is the test above; this one is about where a tile's context lives)
+    env.update(FUIF_AMD_LIB=lib, FUIF_TEST_MAX_PIXELS="12000", FUIF_TEST_BATCH="9", FUIF_TEST_PINNED_BATCH="3", EMU_ALARM="1500", EMU_WAVES="4", EMU_THREADS="4",
                FUIFGPU_CTX_KB=ctx_kb)
     cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
            "tests/test_gpu_group_parallel.py::test_reference_written_files_indexed_after_the_fact",
-           "tests/test_gpu_group_parallel.py::test_mixed_batch_with_more_tiles_than_wavefronts",
            "tests/test_gpu_group_parallel.py::test_writer_indexed_streams_vs_oracle[97-61-3-8-2]"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1700)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -98,7 +98,7 @@ def random_case(rng, tmp):
     if rng.random() < 0.5:
         flags += ["-P", "".join(str(int(rng.integers(0, 7))) for _ in range(int(rng.integers(1, 4))))]
     if rng.random() < 0.5:
-        flags += ["-E", str(int(rng.choice([0, 2, 4, 6, 12, 16])))]
+        flags += ["-E", str(int(rng.choice([0, 2, 4, 6, 12, 16, 24, 40, 50])))]
     if rng.random() < 0.3:
         flags += ["-G", str(int(rng.integers(1, 6)))]
     if rng.random() < 0.1:
