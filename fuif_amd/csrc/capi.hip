@@ -558,7 +558,7 @@ int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
     {
         uint32_t *w = b->d_sched;
         P.q_head = w; P.done_total = w + 1; P.sched_stats = reinterpret_cast<unsigned long long *>(w + 2); P.started_total = w + 18; P.heartbeat = w + 19; w += 20;
-        P.yield_slack = 8;
+        P.yield_slack = 4;   // (round 4, profiles/r4_scheduler_knobs.txt: 4 -> 7.30 s, 8 -> 7.37 s, 16 -> 7.60 s, 32 -> 7.83 s on the trimmed kernel)
         if (const char *e = getenv("FUIFGPU_YIELD_SLACK")) P.yield_slack = (uint32_t)std::max(0, atoi(e));
         P.prio_base = kDefaultPrioBase;   // size classes <= base run at wavefront priority 3, base+1 at 2, base+2 at 1; negative: all 0
         if (const char *e = getenv("FUIFGPU_PRIO_BASE")) P.prio_base = atoi(e);
