@@ -467,7 +467,7 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
     {
         // scheduler state, zeroed before every launch: q_head | done_total | statistics | started_total | heartbeat | cu claim table |
         // cu_alive | cu_live | cu_foreign | img_next | img_done | ctx_used | tile records
-        const size_t words = 20 + (2 * 4096 + 1) + 3 * 4096 + 2 * (size_t)n_images + 2 * (size_t)b->n_queues + (b->sched ? (size_t)b->n_tiles * (sizeof(TileRec) / 4) : 0);
+        const size_t words = 20 + (2 * 4096 + 1) + 3 * 4096 + 4 * 4096 + 2 * (size_t)n_images + 2 * (size_t)b->n_queues + (b->sched ? (size_t)b->n_tiles * (sizeof(TileRec) / 4) : 0);
         if (words > b->sched_words) {
             hipFree(b->d_sched); b->d_sched = nullptr; b->sched_words = 0;
             HIPCHK(hipMalloc((void **)&b->d_sched, words * 4));
@@ -564,6 +564,9 @@ int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
         if (const char *e = getenv("FUIFGPU_PRIO_BASE")) P.prio_base = atoi(e);
         P.simd_claim = w; w += 2 * 4096 + 1;
         P.cu_alive = w; w += 4096; P.cu_live = w; w += 4096; P.cu_foreign = w; w += 4096;
+        P.simd_long = w; w += 4 * 4096;
+        P.long_per_simd = 3;
+        if (const char *e = getenv("FUIFGPU_LONG_PER_SIMD")) P.long_per_simd = std::max(0, atoi(e));
         P.img_next = w; w += b->n_loaded;
         P.img_done = w; w += b->n_loaded;
         P.ctx_used = w; w += b->n_queues;

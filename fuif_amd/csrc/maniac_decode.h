@@ -69,6 +69,10 @@ struct DecodeParams {
     uint32_t *cu_alive;          // sched 1: [4096] per CU key: wavefronts that have arrived and not retired
     uint32_t *cu_live;           // sched 1: [4096] per CU key: tiles started on that CU and not finished (running or suspended)
     uint32_t *cu_foreign;        // sched 1: [4096] per CU key: those of them that belong to another queue than the CU's home queue
+    uint32_t *simd_long;         // sched 1: [4096 * 4] per CU key and SIMD: long tiles (>= 1/8 of their picture) running on that SIMD right now
+    int32_t long_per_simd;       // a wavefront does not start / resume a long tile while its SIMD runs this many already, unless it has been idle for a
+                                 // while (0: no such rule).  Long tiles are the launch's critical path; by chance a SIMD got 1 to 7 of them and each extra
+                                 // one costs the others ~1 % (profiles/r3_stragglers.txt)
     TileRec *tile_rec;           // sched 1: [n_tiles]; zeroed before the launch
     uint8_t *ctx_scratch;        // sched 1: one arena per queue for the context areas (supernodes | leaf chances) of its images' tiles
     uint32_t ctx_units_per_queue; //         arena size in 256-byte units

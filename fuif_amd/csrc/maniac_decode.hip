@@ -790,7 +790,8 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
     const int n_queues = P.n_queues;
     const bool sched = P.sched != 0;
     int home_q = 0;
-    uint32_t simd_key = 0;
+    uint32_t simd_key = 0, simd_slot = 0;   // simd_slot: this wavefront's entry of P.simd_long (CU key x 4 + SIMD)
+    constexpr uint32_t kLongClass = 2, kRecLong = 1u << 12;   // size class of a long tile (>= 1/8 of its picture's samples); its mark in TileRec::flags
     if (sched) {
         // home queue = dense index of the CU this wavefront sits on (the first arrival numbers it)
 #ifdef FUIF_EMU
@@ -801,6 +802,11 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         const uint32_t key = ((hw >> 8) & 0xFFu) | ((xcc & 15u) << 8);
 #endif
         simd_key = key;
+#ifdef FUIF_EMU
+        simd_slot = key * 4u + ((uint32_t)blockIdx.x & 3u);
+#else
+        simd_slot = key * 4u + ((hw >> 4) & 3u);   // HW_ID[5:4] = SIMD
+#endif
         uint32_t idx = 0;
         if (lane == 0) {
             atomicAdd(&P.cu_alive[key], 1u);
@@ -826,8 +832,11 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
     uint32_t my_turn = (uint32_t)blockIdx.x;   // which active image of the queue a look starts with (wavefront-local: no shared counter to hammer)
     // sched == 1: work in queue q -- the next unstarted tile of the first image that has one, else (resume_ok) a suspended tile of
     // this CU whose awaited rows have arrived
-    auto scan_queue = [&](int q, bool fresh_ok, bool resume_ok) -> uint32_t {
+    auto scan_queue = [&](int q, bool fresh_ok, bool resume_ok, bool patient) -> uint32_t {
         const uint32_t ib = P.q_img_begin[q], ie = P.q_img_begin[q + 1];
+        // long tiles spread evenly over the SIMDs: while this SIMD runs its share already, a long tile is left to a wavefront of another SIMD of
+        // the CU -- unless this wavefront has found nothing else for a while (`patient` false): a runnable tile never waits for long
+        const bool simd_full = patient && P.long_per_simd > 0 && rflu(ld_agent(&P.simd_long[simd_slot])) >= (uint32_t)P.long_per_simd;
         // 1. an unstarted tile of one of the first kActiveImages unfinished images of the queue (stream order inside an
         //    image).  Starting comes first: the long final groups of an image must be under way early, and a tile that
         //    has nothing to do yet suspends itself at its first row.
@@ -839,7 +848,10 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
             if (rflu(ld_agent(&P.img_done[im])) >= tn) continue;
             active++;
             uint32_t fresh = kNoWork;
-            if (fresh_ok && lane == 0 && ld_agent(&P.img_next[im]) < tn) {
+            uint32_t peek = lane == 0 ? ld_agent(&P.img_next[im]) : 0u;
+            peek = rflu(peek);
+            const bool next_is_long = simd_full && peek < tn && ((rflu(P.tiles[tb + peek].flags) >> kTileSizeClassShift) & 15u) <= kLongClass;
+            if (fresh_ok && !next_is_long && lane == 0 && peek < tn) {
                 const uint32_t n = atomicAdd(&P.img_next[im], 1u);
                 if (n < tn) {
                     fresh = tb + n;
@@ -876,7 +888,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                     // release / acquire fences at every suspension cost an L2 write-back each: measured, 1.3x slower).
                     if (ld_agent(&r->state) == TS_READY && ld_agent(&r->owner) == simd_key + 1u) {
                         const uint32_t pin = ld_agent(&r->pin);
-                        if (pin == 0u || pin == my_pin) {
+                        if ((pin == 0u || pin == my_pin) && !(simd_full && (ld_agent(&r->flags) & kRecLong))) {
                             const uint32_t wc = ld_agent(&r->wait_chan), wv = ld_agent(&r->wait_val);
                             run = ld_agent(&P.progress[(size_t)im * nch + wc]) >= wv;
                         }
@@ -915,13 +927,14 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         // measured), so a foreign queue is a last resort, reached after a long idle spell.
         STATS(const unsigned long long sc0 = realtime(); if (st_pick_t) { st_busy += sc0 - st_pick_t; st_pick_t = 0; })
         const bool can_start = pinned_tix == kNoWork;
-        tix = scan_queue(home_q, can_start, true);
+        const bool patient = idle_rounds < 8u;
+        tix = scan_queue(home_q, can_start, true, patient);
         const bool all_started = rflu(ld_agent(P.started_total)) >= (uint32_t)P.n_tiles;
         if (tix == kNoWork && idle_rounds > 4096u) {
             const bool foreign_mine = rflu(ld_agent(&P.cu_foreign[simd_key])) != 0u;
             if ((!all_started && can_start) || foreign_mine)
                 for (int d = 1; d < n_queues && tix == kNoWork; d++)
-                    tix = scan_queue(home_q + d < n_queues ? home_q + d : home_q + d - n_queues, can_start && !all_started, foreign_mine);
+                    tix = scan_queue(home_q + d < n_queues ? home_q + d : home_q + d - n_queues, can_start && !all_started, foreign_mine, false);
         }
         if (tix == kNoWork) {
             STATS(if (idle_rounds == 0) st_t0 = sc0;)
@@ -965,6 +978,8 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         tix &= ~kResume;
     }
     const Tile tile = P.tiles[tix];
+    const bool long_tile = sched && ((rflu(tile.flags) >> kTileSizeClassShift) & 15u) <= kLongClass;
+    if (long_tile && lane == 0) atomicAdd(&P.simd_long[simd_slot], 1u);   // (taken back at the suspension or the end of the tile)
     TLOG(const unsigned long long tile_t0 = realtime();)
 #ifndef FUIF_EMU
     {
@@ -1726,7 +1741,8 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
             if (lane == 0) {
                 rec->wait_chan = yield_chan; rec->wait_val = yield_val; rec->y = resume_y;
                 rec->range = rac.range; rec->low = rac.low; rec->pos = s.pos;
-                rec->flags = ((uint32_t)status & 0xFFu) | ((uint32_t)(s.eof_flag & 1) << 8) | ((uint32_t)predictor << 9);
+                rec->flags = ((uint32_t)status & 0xFFu) | ((uint32_t)(s.eof_flag & 1) << 8) | ((uint32_t)predictor << 9) | (long_tile ? kRecLong : 0u);
+                if (long_tile) atomicAdd(&P.simd_long[simd_slot], 0xFFFFFFFFu);
                 rec->ctx = (uint32_t)ctx_slot; rec->ctx_leaves = ctx_leaves_units; rec->tree_size = (uint32_t)tree_size; rec->n_super = (uint32_t)n_super; rec->cur_leaf = (uint32_t)cur_leaf;
                 rec->pin = ctx_slot >= 0 ? 0u : my_pin;
                 rec->owner = simd_key + 1u;
@@ -1772,6 +1788,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         if (lane == 0) {
             st_agent(&rec->state, (uint32_t)TS_DONE);
             if (ld_agent(&rec->foreign)) atomicAdd(&P.cu_foreign[simd_key], 0xFFFFFFFFu);
+            if (long_tile) atomicAdd(&P.simd_long[simd_slot], 0xFFFFFFFFu);
             atomicAdd(&P.cu_live[simd_key], 0xFFFFFFFFu);
             atomicAdd(&P.img_done[img], 1u);
             atomicAdd(P.done_total, 1u);
