@@ -928,8 +928,8 @@ def main():
                     "note": "serial range decoders, one wavefront per channel group, 6 per SIMD, suspended while they wait for other groups' rows: "
                             "bound by the latency of two dependent memory round trips per symbol (supernode, leaf: ~980 cycles each when ~3000 long "
                             "groups share HBM, profiles/r3_fetch_latency_and_leaf_experiment.txt) and by what the wavefronts of a SIMD issue together, not by "
-                            "HBM bandwidth (DESIGN.md 4.1); traffic = PMC bytes of the committed profile named in traffic_source (NOT measured in this "
-                            "run), calibrated on the kernel's two access patterns",
+                            "HBM bandwidth (DESIGN.md 4.1); traffic = HBM bytes of one launch by the PMC counters, measured as traffic_source says (live in this "
+                            "run unless it names the committed profile), with one calibration factor per access pattern of the kernel",
                     "transforms": {"ms": round(t_avg * 1e3, 3), "achieved": round(args.batch * (2.0 * N + 4.0 * P) / t_avg / 1e9, 1),
                                    "unit": "GB/s", "algorithmic_bytes": int(args.batch * (2.0 * N + 4.0 * P)),
                                    "note": "int16 coefficients in, int32 planes out; squeeze residuals are read as int16 straight from the slab, the few other coded planes through a widened copy (Plan::widen)"},

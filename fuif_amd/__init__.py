@@ -88,7 +88,7 @@ ABI_SYMBOLS = [
     "fuifgpu_batch_decode", "fuifgpu_batch_undo_transforms", "fuifgpu_batch_sync", "fuifgpu_batch_status",
     "fuifgpu_batch_create_streaming", "fuifgpu_batch_undo_transforms_to", "fuifgpu_batch_channel_meta", "fuifgpu_batch_coef_ptr", "fuifgpu_batch_out_ptr", "fuifgpu_batch_download_coef",
     "fuifgpu_batch_download_out", "fuifgpu_batch_last_timing", "fuifgpu_batch_profile", "fuifgpu_batch_tile_log", "fuifgpu_batch_sched_stats", "fuifgpu_inv_hsqueeze", "fuifgpu_inv_vsqueeze",
-    "fuifgpu_inv_ycocg", "fuifgpu_inv_ycbcr", "fuifgpu_inv_quantize", "fuifgpu_idct8x8", "fuifgpu_upsample", "fuifgpu_fwd_ycocg", "fuifgpu_fwd_hsqueeze", "fuifgpu_fwd_vsqueeze", "fuifgpu_encode_image", "fuifgpu_encode_channels", "fuifgpu_free_blob",
+    "fuifgpu_inv_ycocg", "fuifgpu_inv_ycbcr", "fuifgpu_inv_quantize", "fuifgpu_idct8x8", "fuifgpu_upsample", "fuifgpu_inv_palette", "fuifgpu_inv_approximate", "fuifgpu_inv_match", "fuifgpu_fwd_ycocg", "fuifgpu_fwd_hsqueeze", "fuifgpu_fwd_vsqueeze", "fuifgpu_encode_image", "fuifgpu_encode_channels", "fuifgpu_free_blob",
     "fuifgpu_index_parse", "fuifgpu_index_append", "fuifgpu_batch_group_index", "fuifgpu_batch_set_group_parallel",
     "fuifgpu_plan_packed_bytes", "fuifgpu_batch_pack_out", "fuifgpu_batch_download_packed",
     "fuifgpu_dev_alloc", "fuifgpu_dev_free", "fuifgpu_dev_upload", "fuifgpu_dev_download",
@@ -162,6 +162,9 @@ def lib():
     L.fuifgpu_inv_quantize.argtypes = [vp, C.c_int64, C.c_int, vp]
     L.fuifgpu_idct8x8.argtypes = [C.POINTER(vp), C.c_int, C.c_int, vp, C.c_int, vp]
     L.fuifgpu_upsample.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.fuifgpu_inv_palette.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp]
+    L.fuifgpu_inv_approximate.argtypes = [vp, vp, C.c_int64, C.c_int, vp]
+    L.fuifgpu_inv_match.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.fuifgpu_fwd_ycocg.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
     L.fuifgpu_fwd_hsqueeze.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.fuifgpu_fwd_vsqueeze.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]

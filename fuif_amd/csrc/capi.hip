@@ -85,6 +85,10 @@ static int hip_fail(hipError_t e, const char *what) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
     return FUIFGPU_E_HIP;
 }
+static int fail_msg(int code, const char *what) {
+    g_last_error = what;
+    return code;
+}
 #define HIPCHK(call)                                      \
     do {                                                  \
         hipError_t e__ = (call);                          \
@@ -945,6 +949,113 @@ int fuifgpu_fwd_vsqueeze(const int32_t *in, int w, int h, int32_t *avg, int32_t 
     if (!in || !avg || (h > 1 && !res) || w < 1 || h < 1) return FUIFGPU_E_ARG;
     launch_fwd_squeeze(false, in, w, h, avg, res, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
+    return FUIFGPU_OK;
+}
+// a plane anywhere in device memory as an element offset from a null base (every plane pointer is 4-byte aligned)
+static PlaneRef raw_plane_at(const int32_t *ptr, int w, int h) {
+    PlaneRef p = raw_plane(0, w, h);
+    p.off = (int64_t)(reinterpret_cast<uintptr_t>(ptr) / 4);
+    return p;
+}
+int fuifgpu_inv_palette(const int32_t *index, int w, int h, const int32_t *palette_row, int colours, int32_t *out, void *stream) {
+    if (!index || !out || out == index || w < 0 || h < 0 || colours < 0 || (colours > 0 && !palette_row)) return FUIFGPU_E_ARG;
+    if ((int64_t)w * h == 0) return FUIFGPU_OK;
+    Bases b{};
+    Op op = raw_op(OP_PALETTE);
+    op.src[0] = raw_plane_at(index, w, h);
+    op.src[1] = raw_plane_at(colours > 0 ? palette_row : index, colours, 1);
+    op.dst[0] = raw_plane_at(out, w, h);
+    op.p0 = 0; op.p1 = colours;
+    launch_op(op, b, nullptr, nullptr, 0, 0, 1, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return FUIFGPU_OK;
+}
+int fuifgpu_inv_approximate(int32_t *plane, const int32_t *remainder, int64_t n_samples, int q, void *stream) {
+    if (!plane || n_samples < 0 || n_samples > 0x7fffffffLL * 32768) return FUIFGPU_E_ARG;
+    if (n_samples == 0) return FUIFGPU_OK;
+    // the kernel walks w*h samples linearly: any factorisation with both factors in int range will do
+    int h = 1;
+    int64_t w = n_samples;
+    while (w > 0x7fffffffLL) { h *= 2; w = (n_samples + h - 1) / h; }
+    if (w * h != n_samples) {   // not a clean factorisation: a head of w*(h-1) samples and a tail
+        const int64_t head = w * (h - 1);
+        int rc = fuifgpu_inv_approximate(plane, remainder, head, q, stream);
+        if (rc != FUIFGPU_OK) return rc;
+        return fuifgpu_inv_approximate(plane + head, remainder ? remainder + head : nullptr, n_samples - head, q, stream);
+    }
+    Bases b{};
+    Op op = raw_op(OP_APPROX);
+    op.src[0] = op.dst[0] = raw_plane_at(plane, (int)w, h);
+    op.src[1] = raw_plane_at(remainder ? remainder : plane, (int)w, h);
+    op.p0 = q; op.p1 = remainder ? 1 : 0;   // p1: "the remainder has samples" (no per-image ChannelMeta here: qsrc = -1)
+    launch_op(op, b, nullptr, nullptr, 0, 0, 1, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return FUIFGPU_OK;
+}
+int fuifgpu_inv_match(const int32_t *match, int w, int h, int32_t *const *planes, int n_planes, int softmatch, int match_q, int match_maxval, int nb_frames,
+                      void *stream) {
+    if (!match || !planes || w < 0 || h < 0 || n_planes < 1 || n_planes > 64 || nb_frames < 1) return FUIFGPU_E_ARG;
+    for (int k = 0; k < n_planes; k++) if (!planes[k]) return FUIFGPU_E_ARG;
+    const int64_t n = (int64_t)w * h;
+    if (n == 0) return FUIFGPU_OK;
+    if (n > 0x7fffffffLL) return fail_msg(FUIFGPU_E_UNSUPPORTED, "match over more than 2^31 samples");
+    const int fh = h / nb_frames;
+    if (match_q != 1 && match_q != 2 * fh * fh + (fh & 1)) return fail_msg(FUIFGPU_E_CORRUPT, "match transform with unexpected quantization factor");   // 2dmatch.h:172-175
+    hipStream_t st = (hipStream_t)stream;
+    const bool free_mode = match_q == 1, soft = softmatch != 0;
+    // device side: the plane list (a soft free-offset match appends two copies of one accumulator per plane), one ChannelMeta for the
+    // match channel (its q and maxval are what the kernels decide on), one status word, and for the free-offset mode two maps of source indices
+    struct Side { PlaneRef list[192]; ChannelMeta meta; int32_t status; } *d_side = nullptr;
+    Side side{};
+    int32_t *d_work = nullptr;
+    if (free_mode) {
+        hipError_t ea = hipMalloc((void **)&d_work, (size_t)n * 4 * (2 + (soft ? 2 * n_planes : 0)));
+        if (ea != hipSuccess) return hip_fail(ea, "hipMalloc");
+    }
+    for (int k = 0; k < n_planes; k++) side.list[k] = raw_plane_at(planes[k], w, h);
+    if (free_mode && soft) for (int k = 0; k < 2 * n_planes; k++) side.list[n_planes + k] = raw_plane_at(d_work + (int64_t)(2 + k) * n, w, h);
+    const int n_list = free_mode && soft ? 3 * n_planes : n_planes;
+    side.meta = ChannelMeta{0, match_maxval, match_q, 1};
+    side.status = 0;
+    auto cleanup = [&]() { hipFree(d_side); hipFree(d_work); };
+    hipError_t e = hipMalloc((void **)&d_side, sizeof(Side));
+    if (e != hipSuccess) { cleanup(); return hip_fail(e, "hipMalloc"); }
+    e = hipMemcpyAsync(d_side, &side, sizeof(Side), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) { cleanup(); return hip_fail(e, "hipMemcpyAsync"); }
+    ChannelMeta *d_meta = &d_side->meta;
+    int32_t *d_status = &d_side->status;
+    const PlaneRef *d_list = d_side->list;
+    Bases b{};
+    PlaneRef pm = raw_plane_at(match, w, h);
+    pm.qsrc = 0;
+    if (!free_mode) {
+        Op op = raw_op(OP_MATCH);
+        op.src[0] = pm; op.p0 = soft; op.p1 = fh; op.idct_first = 0; op.pad = n_planes;
+        launch_op(op, b, d_list, d_meta, 1, 0, 1, st, d_status);
+    } else {   // the same op sequence Plan builds (plan.cpp, inv_match)
+        PlaneRef cur = raw_plane_at(d_work, w, h), other = raw_plane_at(d_work + n, w, h);
+        Op init = raw_op(OP_MATCH_INIT);
+        init.src[0] = pm; init.dst[0] = cur; init.p0 = soft; init.idct_first = 0; init.pad = soft ? n_list : 0;
+        launch_op(init, b, d_list, d_meta, 1, 0, 1, st, d_status);
+        int steps = 1;
+        while ((1LL << steps) < n) steps++;
+        for (int k = 0; k < steps; k++) {
+            Op j = raw_op(OP_MATCH_JUMP);
+            j.src[0] = cur; j.src[1] = pm; j.dst[0] = other; j.p0 = soft; j.p1 = k & 1; j.idct_first = 0; j.pad = soft ? n_list : 0;
+            launch_op(j, b, d_list, d_meta, 1, 0, 1, st, d_status);
+            std::swap(cur, other);
+        }
+        Op ap = raw_op(OP_MATCH_APPLY);
+        ap.src[0] = cur; ap.src[1] = pm; ap.p0 = soft; ap.p1 = steps & 1; ap.idct_first = 0; ap.pad = n_list;
+        launch_op(ap, b, d_list, d_meta, 1, 0, 1, st, d_status);
+    }
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&side.status, d_status, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    cleanup();
+    if (e != hipSuccess) return hip_fail(e, "inv_match");
+    if (side.status & ST_UNSUPPORTED) return fail_msg(FUIFGPU_E_UNSUPPORTED, "2D match with a forward reference (an image narrower than the offset spiral)");
+    if (side.status & ST_CORRUPT) return fail_msg(FUIFGPU_E_CORRUPT, "2D match channel holds an offset code outside its table");
     return FUIFGPU_OK;
 }
 int fuifgpu_upsample(const int32_t *in, int w, int h, int srh, int srv, int32_t *out, void *stream) {

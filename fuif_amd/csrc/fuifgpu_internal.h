@@ -99,6 +99,8 @@ enum : int {
     OP_MATCH_INIT = 13,   // dst[0] = linear index every sample copies from (itself / -1 = before the first sample); src[0] match plane, p0 softmatch
     OP_MATCH_JUMP = 14,   // dst[0][p] = src[0][src[0][p]]: one doubling step; src[1] match plane (mode check)
     OP_MATCH_APPLY = 15,  // listed planes[p] = planes[src[0][p]] in place; src[1] match plane (mode check)
+    // soft matches (p0 = 1 on all three): the list is [planes (n), accumulators (n), accumulators (n)], pad = 3n; INIT fills the first copy of the
+    // accumulators, JUMP reads copy p1 and writes the other, APPLY adds copy p1 to the root's sample
     OP_PERMUTE = 16,      // dst[0] = listed plane number perm[p0], perm = the samples of the 1-row meta plane src[0] (p1 = its length): transform/permute.h:31-54
     // the last three ops of a default YCoCg + Squeeze chain in one pass (planner peephole, plan.cpp finalize()): the horizontal
     // unsqueeze of Co (src[0] avg, src[1] residual) and of Cg (src[2] avg, ext[0] residual) followed by the inverse YCoCg with

@@ -621,8 +621,11 @@ struct Builder {
             // free-offset mode (match channel q == 1): every sample copies from an EARLIER sample in scan order, which may
             // itself be a copy.  The chains are resolved with pointer jumping on a map of linear source indices:
             // ceil(log2(samples)) doubling steps, then one gather per matched plane.  In the other mode these ops return at once.
+            // A soft match (value += source) carries one accumulator per matched plane along the chains, in two copies (a doubling
+            // step reads one and writes the other): transforms.hip, k_match_*.
             const std::vector<int> channel_planes = op.list;
             const int mq = op.src_q[0];
+            const bool soft = op.p0 != 0;
             int steps = 1;
             while ((1LL << steps) < (int64_t)w * h) steps++;
             ProtoOp init;
@@ -632,6 +635,13 @@ struct Builder {
             int cur = new_plane(w, h, -1, k);
             init.dst[0] = cur;
             touch(m.plane, k);
+            std::vector<int> soft_list;   // [planes, accumulators copy 0, accumulators copy 1]
+            if (soft) {
+                soft_list = channel_planes;
+                for (size_t c = 0; c < 2 * channel_planes.size(); c++) soft_list.push_back(new_plane(w, h, -1, k));
+                init.list = soft_list;
+                for (int pl : soft_list) touch(pl, k);
+            }
             ops.push_back(init);
             int other = -1;
             for (int sidx = 0; sidx < steps; sidx++) {
@@ -640,16 +650,19 @@ struct Builder {
                 k = (int)ops.size();
                 if (other < 0) other = new_plane(w, h, -1, k);
                 j.src[0] = cur; j.src[1] = m.plane; j.src_q[1] = mq; j.dst[0] = other;
+                j.p0 = op.p0; j.p1 = sidx & 1; j.list = soft_list;
                 touch(cur, k); touch(other, k); touch(m.plane, k);
+                for (int pl : soft_list) touch(pl, k);
                 ops.push_back(j);
                 std::swap(cur, other);
             }
             ProtoOp ap;
             ap.kind = OP_MATCH_APPLY;
             k = (int)ops.size();
-            ap.src[0] = cur; ap.src[1] = m.plane; ap.src_q[1] = mq; ap.list = channel_planes;
+            ap.src[0] = cur; ap.src[1] = m.plane; ap.src_q[1] = mq; ap.list = soft ? soft_list : channel_planes;
+            ap.p0 = op.p0; ap.p1 = steps & 1;
             touch(cur, k); if (other >= 0) touch(other, k); touch(m.plane, k);
-            for (int pl : channel_planes) touch(pl, k);
+            for (int pl : ap.list) touch(pl, k);
             ops.push_back(ap);
         }
         nb_meta--;

@@ -535,15 +535,15 @@ __global__ __launch_bounds__(256) void k_permute_plane(Bases b, PlaneRef pperm, 
 // done here on the ChannelMeta the later k_dequant reads.
 __global__ __launch_bounds__(256) void k_inv_approx(Bases b, PlaneRef pc, PlaneRef pr, int q, int ctor_data, ChannelMeta *meta, int n_channels,
                                                     int img_first) {
-    ChannelMeta *m = meta + (int64_t)(img_first + blockIdx.z) * n_channels;
-    const bool reached = pr.qsrc >= 0 && m[pr.qsrc].decoded != 0;
+    ChannelMeta *m = meta ? meta + (int64_t)(img_first + blockIdx.z) * n_channels : nullptr;
+    const bool reached = m && pr.qsrc >= 0 && m[pr.qsrc].decoded != 0;
     const bool have = reached || ctor_data;
     const int64_t n = (int64_t)pc.w * pc.h;
     int32_t *d = plane_ptr(b, pc, blockIdx.z);
     const int32_t *r = plane_ptr(b, pr, blockIdx.z);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         d[i] = d[i] * q + (have ? r[i] : 0);
-    if (have && blockIdx.x == 0 && threadIdx.x == 0 && pc.qsrc >= 0 && pr.qsrc >= 0) m[pc.qsrc].q = reached ? m[pr.qsrc].q : 1;
+    if (have && m && blockIdx.x == 0 && threadIdx.x == 0 && pc.qsrc >= 0 && pr.qsrc >= 0) m[pc.qsrc].q = reached ? m[pr.qsrc].q : 1;
 }
 
 // transform/2dmatch.h:147-171, the previous-frame mode (match channel q == 2*fh*fh + (fh&1), :147-149): frames are
@@ -583,8 +583,12 @@ __global__ __launch_bounds__(256) void k_inv_match_frames(Bases b, PlaneRef pm, 
 // Channel::value() only checks the LINEAR index (image.h:82-85), so the source is sample p + oy*w + ox, and a
 // source before the first sample reads Channel::zero.  Parallel form: S[p] = p for unmatched samples, else the
 // source index; ceil(log2(n)) rounds of S[p] = S[S[p]] make every S[p] a root; one gather finishes the job.
-// Soft matches (value += source, never written by the CLI, fuif.cpp:445) and forward references (only possible in
-// images narrower than the spiral) are flagged FUIFGPU_ST_UNSUPPORTED and the image is left unmatched.
+// Soft matches (value += source, :136-140; the CLI never writes them, fuif.cpp:445) take the same route with one accumulator
+// per listed plane: value(p) = residual(p) + value(source(p)), so A[p] = residual(p) for a matched sample and 0 for a root,
+// every doubling step adds A[S[p]] to A[p] (two copies of the accumulators, read one / write the other), and the gather adds
+// the root's sample.  Forward references (only possible in images narrower than the spiral) are flagged
+// FUIFGPU_ST_UNSUPPORTED and the image is left unmatched.
+// The list of a soft match is [planes (n), accumulators (n), accumulators (n)]; Op::p1 of a jump / apply op = which copy it reads.
 DEV void match_offset(int code, int &xo, int &yo) {   // 2dmatch.h:50-78
     int layer = 0, size = 4;
     while (code > size) { code -= size; layer++; size += 4; }
@@ -601,8 +605,8 @@ DEV void match_offset(int code, int &xo, int &yo) {   // 2dmatch.h:50-78
 DEV bool match_free_mode(const PlaneRef &pm, const ChannelMeta *meta, int n_channels, int img) {
     return meta && pm.qsrc >= 0 && meta[(int64_t)img * n_channels + pm.qsrc].q == 1;
 }
-__global__ __launch_bounds__(256) void k_match_init(Bases b, PlaneRef pm, PlaneRef ps, int softmatch, const ChannelMeta *meta, int n_channels,
-                                                    int img_first, int32_t *status) {
+__global__ __launch_bounds__(256) void k_match_init(Bases b, PlaneRef pm, PlaneRef ps, int softmatch, const PlaneRef *list, int n_list,
+                                                    const ChannelMeta *meta, int n_channels, int img_first, int32_t *status) {
     const int img = img_first + blockIdx.z;
     if (!match_free_mode(pm, meta, n_channels, img)) return;
     const int maxz = meta[(int64_t)img * n_channels + pm.qsrc].maxval;
@@ -615,8 +619,7 @@ __global__ __launch_bounds__(256) void k_match_init(Bases b, PlaneRef pm, PlaneR
         const int z = m[p];
         int64_t s = p;
         if (z) {
-            if (softmatch) flag |= ST_UNSUPPORTED;
-            else if (z < 0 || z > maxz) flag |= ST_UNSUPPORTED | ST_CORRUPT;   // offsets_table[z] out of range in the reference
+            if (z < 0 || z > maxz) flag |= ST_UNSUPPORTED | ST_CORRUPT;   // offsets_table[z] out of range in the reference
             else {
                 int xo, yo;
                 match_offset(z, xo, yo);
@@ -627,11 +630,13 @@ __global__ __launch_bounds__(256) void k_match_init(Bases b, PlaneRef pm, PlaneR
             }
         }
         S[p] = (int32_t)s;
+        if (softmatch)
+            for (int k = 0; k < n_list; k++) plane_ptr(b, list[n_list + k], blockIdx.z)[p] = s != p ? plane_ptr(b, list[k], blockIdx.z)[p] : 0;
     }
     if (flag && status) atomicOr(&status[img], flag);
 }
-__global__ __launch_bounds__(256) void k_match_jump(Bases b, PlaneRef pm, PlaneRef pin, PlaneRef pout, const ChannelMeta *meta, int n_channels,
-                                                    int img_first) {
+__global__ __launch_bounds__(256) void k_match_jump(Bases b, PlaneRef pm, PlaneRef pin, PlaneRef pout, int softmatch, const PlaneRef *list, int n_list,
+                                                    int from, const ChannelMeta *meta, int n_channels, int img_first) {
     if (!match_free_mode(pm, meta, n_channels, img_first + blockIdx.z)) return;
     const int64_t n = (int64_t)pin.w * pin.h;
     const int32_t *S = plane_ptr(b, pin, blockIdx.z);
@@ -639,10 +644,15 @@ __global__ __launch_bounds__(256) void k_match_jump(Bases b, PlaneRef pm, PlaneR
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
         const int s = S[p];
         T[p] = s >= 0 ? S[s] : s;
+        if (softmatch)
+            for (int k = 0; k < n_list; k++) {
+                const int32_t *a = plane_ptr(b, list[n_list * (1 + from) + k], blockIdx.z);
+                plane_ptr(b, list[n_list * (2 - from) + k], blockIdx.z)[p] = a[p] + (s >= 0 ? a[s] : 0);
+            }
     }
 }
-__global__ __launch_bounds__(256) void k_match_apply(Bases b, PlaneRef pm, PlaneRef ps, const PlaneRef *list, int n_list, const ChannelMeta *meta,
-                                                     int n_channels, int img_first, const int32_t *status) {
+__global__ __launch_bounds__(256) void k_match_apply(Bases b, PlaneRef pm, PlaneRef ps, int softmatch, const PlaneRef *list, int n_list, int from,
+                                                     const ChannelMeta *meta, int n_channels, int img_first, const int32_t *status) {
     const int img = img_first + blockIdx.z;
     if (!match_free_mode(pm, meta, n_channels, img)) return;
     if (status && (status[img] & ST_UNSUPPORTED)) return;   // flagged by k_match_init: leave the planes alone
@@ -653,7 +663,8 @@ __global__ __launch_bounds__(256) void k_match_apply(Bases b, PlaneRef pm, Plane
         if (s == p) continue;                                // roots are never written: the gather below only reads roots
         for (int k = 0; k < n_list; k++) {
             int32_t *pl = plane_ptr(b, list[k], blockIdx.z);
-            pl[p] = s < 0 ? 0 : pl[s];
+            const int root = s < 0 ? 0 : pl[s];
+            pl[p] = softmatch ? plane_ptr(b, list[n_list * (1 + from) + k], blockIdx.z)[p] + root : root;
         }
     }
 }
@@ -1012,20 +1023,20 @@ void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMe
         case OP_MATCH_INIT:
             if (!meta || (int64_t)op.dst[0].w * op.dst[0].h <= 0) break;
             hipLaunchKernelGGL(k_match_init, grid1d((int64_t)op.dst[0].w * op.dst[0].h, 256, n_images), dim3(256), 0, stream, b, op.src[0], op.dst[0],
-                               op.p0, meta, n_channels, img_first, status);
+                               op.p0, dev_list + op.idct_first, op.pad / 3, meta, n_channels, img_first, status);
             break;
         case OP_MATCH_JUMP:
             if (!meta || (int64_t)op.dst[0].w * op.dst[0].h <= 0) break;
             hipLaunchKernelGGL(k_match_jump, grid1d((int64_t)op.dst[0].w * op.dst[0].h, 256, n_images), dim3(256), 0, stream, b, op.src[1], op.src[0],
-                               op.dst[0], meta, n_channels, img_first);
+                               op.dst[0], op.p0, dev_list + op.idct_first, op.pad / 3, op.p1, meta, n_channels, img_first);
             break;
         case OP_MATCH_APPLY:
             if (!meta || (int64_t)op.src[0].w * op.src[0].h <= 0) break;
             hipLaunchKernelGGL(k_match_apply, grid1d((int64_t)op.src[0].w * op.src[0].h, 256, n_images), dim3(256), 0, stream, b, op.src[1], op.src[0],
-                               dev_list + op.idct_first, op.pad, meta, n_channels, img_first, status);
+                               op.p0, dev_list + op.idct_first, op.p0 ? op.pad / 3 : op.pad, op.p1, meta, n_channels, img_first, status);
             break;
         case OP_APPROX:
-            if (!meta || (int64_t)op.dst[0].w * op.dst[0].h <= 0) break;
+            if ((!meta && (op.src[0].qsrc >= 0 || op.src[1].qsrc >= 0)) || (int64_t)op.dst[0].w * op.dst[0].h <= 0) break;   // raw planes carry no ChannelMeta
             hipLaunchKernelGGL(k_inv_approx, grid1d((int64_t)op.dst[0].w * op.dst[0].h, 256, n_images), dim3(256), 0, stream, b, op.src[0],
                                op.src[1], op.p0, op.p1, meta, n_channels, img_first);
             break;

@@ -24,7 +24,7 @@ extern "C" {
 #define FUIFGPU_OK 0
 #define FUIFGPU_E_NOT_FUIF 1      /* bad magic / short header */
 #define FUIFGPU_E_CORRUPT 2       /* header or transform list is inconsistent */
-#define FUIFGPU_E_UNSUPPORTED 3   /* feature outside the hot-path scope (more than 18 reference properties -- `-E k` > 18; the CLI default is 12 --, a data-driven Permute over channels of unequal geometry, soft 2D matches) */
+#define FUIFGPU_E_UNSUPPORTED 3   /* feature outside the hot-path scope (`-E k` > 50: more than 25 reference channels per context tree, the CLI default is 12; a data-driven Permute over channels of unequal geometry) */
 #define FUIFGPU_E_ARG 4
 #define FUIFGPU_E_HIP 5           /* a HIP runtime call failed; see fuifgpu_last_error() */
 #define FUIFGPU_E_MISMATCH 6      /* image does not share the batch's plan signature */
@@ -219,6 +219,18 @@ int fuifgpu_inv_quantize(int32_t *plane, int64_t n_samples, int q, void *stream)
 int fuifgpu_idct8x8(const int32_t *const *src64_dev, int bw, int bh, int32_t *out, int maxval, void *stream);
 /* transform/subsample.h:90-126 chroma upsampling: the "fancy" filter for srh, srv in {1,2}, plain replication when either is larger (4:1:1) */
 int fuifgpu_upsample(const int32_t *in, int w, int h, int srh, int srv, int32_t *out, void *stream);
+/* transform/palette.h:57-64 inv_palette, one component per call: out[i] = palette_row[CLAMP(index[i], 0, colours-1)] over w x h samples
+ * (palette_row = row `component` of the palette meta-channel; colours == 0 reads Channel::zero, image.h:82). out may not be index. */
+int fuifgpu_inv_palette(const int32_t *index, int w, int h, const int32_t *palette_row, int colours, int32_t *out, void *stream);
+/* transform/approximate.h:44-57 inv_approximate of one channel, in place: plane[i] = plane[i] * q + remainder[i] (q = parameter + 1);
+ * remainder == NULL = "the remainder channel is not available" (:49,54): nothing is added */
+int fuifgpu_inv_approximate(int32_t *plane, const int32_t *remainder, int64_t n_samples, int q, void *stream);
+/* transform/2dmatch.h:112-177 inv_match, in place on n_planes (<= 64) w x h planes; match = the match meta-channel, match_q / match_maxval its
+ * Channel::q and ::maxval (the mode is data: q == 1 free offsets :136-146, q == 2*fh*fh+(fh&1) previous frames :147-171, anything else
+ * FUIFGPU_E_CORRUPT like :172-175). Synchronous. FUIFGPU_E_UNSUPPORTED (planes untouched) for a forward reference (an image narrower than the
+ * offset spiral: the one case where the reference's scan order matters). */
+int fuifgpu_inv_match(const int32_t *match, int w, int h, int32_t *const *planes, int n_planes, int softmatch, int match_q, int match_maxval,
+                      int nb_frames, void *stream);
 /* ---- forward transforms of the writer, raw device planes, contiguous rows ----
  * transform/ycocg.h:65-95 fwd_YCoCg, in place on three w x h planes */
 int fuifgpu_fwd_ycocg(int32_t *c0, int32_t *c1, int32_t *c2, int w, int h, void *stream);

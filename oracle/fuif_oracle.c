@@ -1872,6 +1872,23 @@ int fo_kat_inv_dct(const int32_t *planes64, int bw, int bh, int maxval, int32_t 
     fo_free(img);
     return ok;
 }
+/* transform/2dmatch.h:123-177 on raw planes: match w x h (its Channel::q and ::maxval given), planes = n_planes x (w x h) rewritten in place;
+ * returns 0 where the reference returns false */
+int fo_kat_inv_match(const int32_t *match, int w, int h, int32_t *planes, int n_planes, int softmatch, int q, int maxval, int nb_frames) {
+    fo_image *img = kat_image(1 + n_planes, 255);
+    img->nb_meta_channels = 1; img->nb_channels = n_planes; img->nb_frames = nb_frames;
+    kat_plane(&img->ch[0], match, w, h, 0, maxval);
+    img->ch[0].q = q;
+    for (int k = 0; k < n_planes; k++) kat_plane(&img->ch[1 + k], planes + (size_t)k * w * h, w, h, -32768, 32767);
+    fo_transform t; t.id = TR_2DMATCH; t.nparams = 4;
+    t.params = (int *)malloc(sizeof(int) * 4);
+    t.params[0] = 0; t.params[1] = n_planes - 1; t.params[2] = softmatch; t.params[3] = 1000000;
+    int ok = inv_match(img, &t);
+    if (ok) for (int k = 0; k < n_planes; k++) memcpy(planes + (size_t)k * w * h, img->ch[k].data, sizeof(int32_t) * (size_t)w * h);
+    free(t.params);
+    fo_free(img);
+    return ok;
+}
 void fo_kat_zigzag(int32_t *out64) { for (int i = 0; i < 64; i++) out64[i] = fo_zigzag[i]; }
 /* transform/subsample.h:73-127 for one plane that is smaller than the first (luma) plane; srh, srv in {1,2} */
 int fo_kat_upsample(const int32_t *in, int w, int h, int srh, int srv, int32_t *out) {

@@ -75,6 +75,7 @@ int fo_kat_read_bits(const uint8_t *buf, size_t n, int count, int32_t *out);
 int fo_kat_inv_squeeze(int horizontal, const int32_t *avg, int aw, int ah, const int32_t *res, int rw, int rh, int32_t *out);
 int fo_kat_inv_color(int ycbcr, int32_t *c0, int32_t *c1, int32_t *c2, int w, int h, int minval, int maxval);
 int fo_kat_inv_dct(const int32_t *planes64, int bw, int bh, int maxval, int32_t *out);
+int fo_kat_inv_match(const int32_t *match, int w, int h, int32_t *planes, int n_planes, int softmatch, int q, int maxval, int nb_frames);
 void fo_kat_zigzag(int32_t *out64);
 int fo_kat_upsample(const int32_t *in, int w, int h, int srh, int srv, int32_t *out);
 

@@ -1,5 +1,6 @@
 """GPU parity (-m gpu) of the single-transform entry points of the C-ABI (include/fuifgpu.h: fuifgpu_inv_hsqueeze,
-fuifgpu_inv_vsqueeze, fuifgpu_inv_ycocg, fuifgpu_inv_ycbcr, fuifgpu_inv_quantize, fuifgpu_idct8x8, fuifgpu_upsample) -- what
+fuifgpu_inv_vsqueeze, fuifgpu_inv_ycocg, fuifgpu_inv_ycbcr, fuifgpu_inv_quantize, fuifgpu_idct8x8, fuifgpu_upsample, fuifgpu_inv_palette,
+fuifgpu_inv_approximate, fuifgpu_inv_match) -- what
 Transform::apply(image, true) (transform/transform.cpp:48-63) dispatches to in the boundary layer.
 
 Each is run on raw device planes (random, incl. negative values, odd and tiny sizes, several planes per launch) and
@@ -202,6 +203,89 @@ def test_upsample_export(glib, olib, w, h, srh, srv):
     d_in, d_out = Dev(src), Dev(np.zeros((h * srv, w * srh), np.int32))
     assert glib.fuifgpu_upsample(d_in.ptr, w, h, srh, srv, d_out.ptr, None) == 0
     assert np.array_equal(d_out.get().reshape(h * srv, w * srh), want)
+
+
+@pytest.mark.parametrize("w,h,colours", [(1, 1, 1), (7, 5, 3), (64, 33, 200), (33, 2, 0), (300, 7, 19)])
+def test_inv_palette_export(glib, w, h, colours):
+    """transform/palette.h:57-64, one component: out = palette_row[CLAMP(index, 0, colours-1)]; an empty palette reads Channel::zero"""
+    rng = np.random.default_rng(w * 7 + h + colours)
+    idx = rng.integers(-3, colours + 4, (h, w), dtype=np.int32)       # indices on both sides of the palette are clamped
+    row = rng.integers(-500, 1500, max(colours, 1), dtype=np.int32)
+    want = row[np.clip(idx, 0, max(colours - 1, 0))] if colours else np.zeros((h, w), np.int32)
+    d_idx, d_row, d_out = Dev(idx), Dev(row), Dev(np.full((h, w), -7, np.int32))
+    assert glib.fuifgpu_inv_palette(d_idx.ptr, w, h, d_row.ptr, colours, d_out.ptr, None) == 0
+    assert np.array_equal(d_out.get().reshape(h, w), want)
+    assert glib.fuifgpu_inv_palette(d_idx.ptr, w, h, d_row.ptr, colours, d_idx.ptr, None) != 0    # in place is refused
+
+
+@pytest.mark.parametrize("n,q,have", [(1, 2, True), (1000, 4, True), (257 * 33, 10, False), (5, 1, True)])
+def test_inv_approximate_export(glib, n, q, have):
+    """transform/approximate.h:44-57: value * q + remainder; a remainder channel that is not available adds nothing (:49,54)"""
+    rng = np.random.default_rng(n + q)
+    a = rng.integers(-700, 700, n).astype(np.int32)
+    r = rng.integers(0, q, n).astype(np.int32)
+    d, dr = Dev(a), Dev(r)
+    assert glib.fuifgpu_inv_approximate(d.ptr, dr.ptr if have else None, n, q, None) == 0
+    _sync()
+    assert np.array_equal(d.get(), a * q + (r if have else 0))
+
+
+def _match_case(rng, w, h, n_planes, maxz, density):
+    z = rng.integers(1, maxz + 1, (h, w), dtype=np.int32)
+    z[rng.random((h, w)) >= density] = 0
+    planes = rng.integers(-40, 300, (n_planes, h, w), dtype=np.int32)
+    return z, planes
+
+
+@pytest.mark.parametrize("soft", [0, 1])
+@pytest.mark.parametrize("w,h,n_planes,maxz,density", [(40, 30, 3, 24, 0.5), (64, 64, 1, 60, 0.9), (97, 13, 4, 12, 0.2), (33, 50, 2, 1, 1.0)])
+def test_inv_match_free_offsets_export(glib, olib, w, h, n_planes, maxz, density, soft):
+    """transform/2dmatch.h:136-146 (match channel q == 1): every matched sample copies (soft: adds) an EARLIER sample, which may
+    itself be matched -- chains up to the whole row long at density 1.0 -- incl. sources before the first sample (Channel::zero)"""
+    rng = np.random.default_rng(w * 31 + h + maxz + soft)
+    z, planes = _match_case(rng, w, h, n_planes, maxz, density)
+    want = planes.copy()
+    assert olib.fo_kat_inv_match(z.ctypes.data_as(C.c_void_p), w, h, want.ctypes.data_as(C.c_void_p), n_planes, soft, 1, maxz, 1)
+    d_z, d_p = Dev(z), Dev(planes)
+    ptrs = (C.c_void_p * n_planes)(*[d_p.ptr + k * w * h * 4 for k in range(n_planes)])
+    assert glib.fuifgpu_inv_match(d_z.ptr, w, h, ptrs, n_planes, soft, 1, maxz, 1, None) == 0
+    assert np.array_equal(d_p.get().reshape(n_planes, h, w), want)
+
+
+@pytest.mark.parametrize("soft", [0, 1])
+@pytest.mark.parametrize("w,fh,frames,n_planes", [(24, 10, 4, 3), (70, 7, 3, 1), (5, 3, 6, 2)])
+def test_inv_match_previous_frames_export(glib, olib, w, fh, frames, n_planes, soft):
+    """transform/2dmatch.h:147-171 (match channel q == 2*fh*fh + (fh&1)): z frames up in the vertical film strip; a source above the
+    first frame reads Channel::zero"""
+    rng = np.random.default_rng(w + fh * 100 + soft)
+    h = fh * frames
+    z, planes = _match_case(rng, w, h, n_planes, frames, 0.6)
+    q = 2 * fh * fh + (fh & 1)
+    want = planes.copy()
+    assert olib.fo_kat_inv_match(z.ctypes.data_as(C.c_void_p), w, h, want.ctypes.data_as(C.c_void_p), n_planes, soft, q, 1, frames)
+    d_z, d_p = Dev(z), Dev(planes)
+    ptrs = (C.c_void_p * n_planes)(*[d_p.ptr + k * w * h * 4 for k in range(n_planes)])
+    assert glib.fuifgpu_inv_match(d_z.ptr, w, h, ptrs, n_planes, soft, q, 1, frames, None) == 0
+    assert np.array_equal(d_p.get().reshape(n_planes, h, w), want)
+
+
+def test_inv_match_export_refusals(glib):
+    """a match channel whose q names neither mode is the reference's `return false` (2dmatch.h:172-175); a forward reference (an image
+    narrower than the offset spiral) and an offset code beyond the table are refused with the planes untouched"""
+    w, h = 3, 8
+    planes = np.arange(w * h, dtype=np.int32).reshape(1, h, w)
+    z = np.zeros((h, w), np.int32)
+    z[4, 0] = 4             # layer 0, code 4: (x+1, y-1), an earlier sample
+    d_z, d_p = Dev(z), Dev(planes)
+    ptrs = (C.c_void_p * 1)(d_p.ptr)
+    assert glib.fuifgpu_inv_match(d_z.ptr, w, h, ptrs, 1, 0, 5, 100, 1, None) == 2          # FUIFGPU_E_CORRUPT: q = 5 is no mode
+    z2 = z.copy(); z2[4, 0] = 200                                                        # beyond maxval = the offsets table
+    assert glib.fuifgpu_inv_match(Dev(z2).ptr, w, h, ptrs, 1, 0, 1, 100, 1, None) == 3      # FUIFGPU_E_UNSUPPORTED
+    # a forward reference needs yo*w + xo > 0: layer 5 (odd), code 1: (x+6, y-1) in a 3-wide image = +3
+    code = 4 + 8 + 12 + 16 + 20 + 1
+    z4 = np.zeros((h, w), np.int32); z4[2, 0] = code
+    assert glib.fuifgpu_inv_match(Dev(z4).ptr, w, h, ptrs, 1, 0, 1, 100, 1, None) == 3
+    assert np.array_equal(d_p.get().reshape(1, h, w), planes)
 
 
 # ---- forward transforms (the writer's GPU path, SURVEY.md §8 f-3) -----------------------------------------------------
