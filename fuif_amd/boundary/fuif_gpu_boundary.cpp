@@ -12,9 +12,9 @@
 // The reference's own definitions of these three are kept in the link under the names
 // fuif_decode_file_cpu / fuif_decode_cpu / Image::undo_transforms_cpu (the Makefile compiles
 // encoding.cpp and image.cpp with -Dname=name_cpu) and are used for what is outside the GPU
-// scope: -i/--identify (header only), undo_transforms(keep != 0), and the streams the library
-// reports as FUIFGPU_E_UNSUPPORTED / FUIFGPU_ST_UNSUPPORTED (a data-driven Permute over channels of different geometry; soft 2D
-// matches).  Stills and
+// scope: -i/--identify (header only), the loop of undo_transforms(keep != 0) (its Transform::apply calls come back here), and the streams the library
+// reports as FUIFGPU_E_UNSUPPORTED / FUIFGPU_ST_UNSUPPORTED (a data-driven Permute over channels of different geometry; a 2D
+// match with a forward reference).  Stills and
 // animations (FUAF), Squeeze / YCoCg / YCbCr / DCT / Quantize / Subsample / Palette / Approximate / 2D-match / Permute
 // chains all decode on the GPU.  By DEFAULT nothing is ever routed to the reference's CPU decoder: an
 // unsupported stream is a loud error (so a planner regression cannot hide behind a fallback);
@@ -162,13 +162,14 @@ bool gpu_decode_bytes(const std::vector<uint8_t> &bytes, Image &image, const fui
         for (int k = 0; k < np && k < (int)params.size(); k++) tr.parameters.push_back(params[k]);
         image.transform.push_back(tr);
     }
-    // Image::nb_meta_channels / nb_channels as the meta steps leave them (transform/palette.h:87-88, 2dmatch.h:191)
+    // Image::nb_meta_channels / nb_channels as the meta steps leave them (transform/palette.h:87-88, 2dmatch.h:191, permute.h:60)
     for (const Transform &tr : image.transform) {
         if (tr.ID == TRANSFORM_PALETTE && tr.parameters.size() == 3) {
             image.nb_meta_channels++;
             image.nb_channels -= tr.parameters[1] - tr.parameters[0];
         }
         if (tr.ID == TRANSFORM_2DMATCH) image.nb_meta_channels++;
+        if (tr.ID == TRANSFORM_PERMUTE && tr.parameters.empty()) image.nb_meta_channels++;   // the permutation is a meta-channel (permute.h:58-63)
     }
     image.error = false;
     res->bytes = bytes;
@@ -369,7 +370,7 @@ void fuifgpu_boundary_undo_transforms(Image *self, int keep) {
         registry().erase(it);
         return;
     }
-    // the inverse kernels can still flag the image (soft 2D matches, forward references: k_match_init / k_inv_match_frames)
+    // the inverse kernels can still flag the image (forward references of a 2D match, a match channel of neither mode: k_match_init / k_inv_match_frames)
     int32_t status = 0;
     fuifgpu_batch_status(res.batch, &status, nullptr);
     if (status & FUIFGPU_ST_UNSUPPORTED) {
@@ -421,7 +422,8 @@ void fuifgpu_boundary_undo_transforms(Image *self, int keep) {
 // Transform::apply(image, inverse) -- transform/transform.cpp:48-63.  The reference's own definition is kept in the
 // link as Transform::apply_cpu (the Makefile compiles transform.cpp with -Dapply=apply_cpu, and this file too, so the
 // class declares it under that name here); the symbol Transform::apply is bound to the function below.  The INVERSE of
-// Squeeze, YCoCg, YCbCr, DCT, Quantize and ChromaSubsample runs on the MI355X through the single-transform entry points of the C-ABI: this is the path
+// Squeeze, YCoCg, YCbCr, DCT, Quantize, ChromaSubsample, Palette, Approximate and 2D-match runs on the MI355X through the single-transform
+// entry points of the C-ABI (the inverse of Permute only reorders the channel list; it stays the reference's statement): this is the path
 // of Image::undo_transforms(keep != 0) (fuif.cpp:220,230, image.cpp:94-115 calls t.apply(*this, true) per transform),
 // while a plain undo_transforms() replays the whole chain on the planes that are still resident (above).  Everything
 // else -- forward transforms, the other inverses, an image a kernel precondition does not hold for -- goes to apply_cpu.
@@ -439,6 +441,10 @@ struct DevPlane {
         return d && fuifgpu_dev_upload(d, wide.data(), n * 4) == FUIFGPU_OK;
     }
     bool alloc(size_t count) { n = count; d = (int32_t *)fuifgpu_dev_alloc(n * 4); return d != nullptr; }
+    bool zeros(size_t count) {   // a channel a partial decode never reached: every Channel::value() of it reads zero (image.h:82)
+        std::vector<int32_t> z(count, 0);
+        return alloc(count) && fuifgpu_dev_upload(d, z.data(), n * 4) == FUIFGPU_OK;
+    }
     bool get(Channel &ch) const {   // D2H, int32 -> pixel_type
         std::vector<int32_t> wide(n);
         if (fuifgpu_dev_download(wide.data(), d, n * 4) != FUIFGPU_OK) return false;
@@ -557,8 +563,9 @@ bool gpu_inv_dct(Image &img, std::vector<int> par) {
         const int32_t *src[64];
         for (int i = 0; i < 64; i++) {
             const Channel &sc = img.channel[i == 0 ? c : offset - nb + ordering[c - beginc][refdct::jpeg_zigzag[i]]];
-            if (sc.w != bw || sc.h < bh || sc.data.size() < (size_t)sc.w * sc.h) return false;
-            if (!planes[i].put(sc)) return false;
+            if (sc.data.size() == 0) { if (!planes[i].zeros((size_t)bw * bh)) return false; }   // responsive decode: coefficients not loaded are zero (dct.h:285-286 via value())
+            else if (sc.w != bw || sc.h < bh || sc.data.size() < (size_t)sc.w * sc.h) return false;
+            else if (!planes[i].put(sc)) return false;
             src[i] = planes[i].d;
         }
         DevPlane o;
@@ -599,6 +606,105 @@ bool gpu_inv_subsample(Image &img, std::vector<int> par) {
     img.channel.swap(work);
     return true;
 }
+
+// transform/palette.h:32-68.  The palette is meta-channel 0 (colours wide, one row per component); the index channel becomes
+// component 0 and nb-1 new channels follow it.  One gather per component (fuifgpu_inv_palette).
+bool gpu_inv_palette(Image &img, const std::vector<int> &par) {
+    if (img.nb_meta_channels < 1 || par.size() != 3 || img.channel.empty()) return false;
+    const int nb = img.channel[0].h, colours = img.channel[0].w;
+    const int c0 = img.nb_meta_channels + par[0];
+    if (nb < 1 || colours < 0 || c0 < 1 || c0 >= (int)img.channel.size()) return false;
+    const int w = img.channel[c0].w, h = img.channel[c0].h;
+    if (w < 0 || h < 0 || img.channel[c0].data.size() != (size_t)w * h) return false;   // a partly decoded index channel: the reference's loop has its own reading of that
+    std::vector<Channel> work = img.channel;
+    for (int i = 1; i < nb; i++) {      // palette.h:52-55, statement by statement (which of the new channels ends up labelled follows from it)
+        work.insert(work.begin() + c0 + 1, Channel(w, h, 0, 1));
+        work[c0 + i].component = par[0] + i;
+    }
+    if ((size_t)w * h > 0) {
+        const Channel &palette = work[0];
+        DevPlane idx;
+        if (!idx.put(img.channel[c0])) return false;
+        for (int c = 0; c < nb; c++) {
+            Channel row(std::max(colours, 1), 1, 0, 0);
+            for (int i = 0; i < colours; i++) row.data[i] = palette.value(c, i);   // Channel::value: samples a partial decode never reached read as zero
+            DevPlane pr, out;
+            if (!pr.put(row) || !out.alloc((size_t)w * h)) return false;
+            if (fuifgpu_inv_palette(idx.d, w, h, pr.d, colours, out.d, nullptr) != FUIFGPU_OK || !out.get(work[c0 + c])) return false;
+        }
+    }
+    work.erase(work.begin(), work.begin() + 1);
+    img.channel.swap(work);
+    img.nb_channels += nb - 1;
+    img.nb_meta_channels--;
+    return true;
+}
+
+// transform/approximate.h:32-62: channel = channel * (parameter + 1) + remainder, the remainder channels sit at the end of the list
+bool gpu_inv_approximate(Image &img, const std::vector<int> &par) {
+    if (par.size() < 3) return false;
+    const int beginc = par[0], endc = par[1];
+    if (beginc < 0 || endc < beginc || endc >= (int)img.channel.size()) return false;
+    auto factor = [&](int c) { return (c + 2 - beginc < (int)par.size() ? par[c + 2 - beginc] : par.back()); };
+    int offset = (int)img.channel.size() - (endc - beginc + 1);
+    for (int c = beginc; c <= endc; c++) if (!factor(c)) offset++;
+    if (offset <= endc || offset > (int)img.channel.size()) return false;
+    std::vector<Channel> work = img.channel;
+    int i = 0;
+    for (int c = beginc; c <= endc; c++) {
+        const int q = factor(c) + 1;
+        if (q == 1) continue;
+        if (offset + i >= (int)work.size()) return false;
+        Channel &ch = work[c];
+        const Channel &chr = work[offset + i];
+        i++;
+        const size_t n = (size_t)ch.w * ch.h;
+        const bool have = chr.data.size() != 0;
+        // a responsive decode that reached neither channel: every read is Channel::zero and every store goes to it (image.h:82-85); 0*q + 0 changes nothing
+        if (ch.data.size() == 0 && !have && ch.zero == 0) continue;
+        if (ch.w < 0 || ch.h < 0 || ch.data.size() != n || (have && (chr.w != ch.w || chr.h != ch.h || chr.data.size() != n))) return false;
+        if (have) ch.q = chr.q;
+        if (n == 0) continue;
+        DevPlane p, r;
+        if (!p.put(ch) || (have && !r.put(chr))) return false;
+        if (fuifgpu_inv_approximate(p.d, have ? r.d : nullptr, (int64_t)n, q, nullptr) != FUIFGPU_OK || !p.get(ch)) return false;
+    }
+    work.erase(work.begin() + offset, work.end());
+    img.channel.swap(work);
+    return true;
+}
+
+// transform/2dmatch.h:112-177: the match meta-channel says, per sample, which earlier sample (free offsets, q == 1) or which earlier
+// frame (q == 2*fh*fh + (fh&1)) it repeats -- or, for a soft match, is a difference to.  Chains are resolved on the GPU by pointer
+// jumping (fuifgpu_inv_match); the mode is data (Channel::q of the match channel).
+bool gpu_inv_match(Image &img, std::vector<int> par) {
+    if (img.nb_meta_channels < 1 || img.channel.empty()) return false;
+    if (par.empty()) { par = {0, img.nb_channels - 1, 0, 1000000}; }   // default_match_parameters, 2dmatch.h:104-110
+    if (par.size() < 3) return false;
+    const Channel &m = img.channel[0];
+    const int c0 = img.nb_meta_channels + par[0], cn = img.nb_meta_channels + par[1];
+    if (c0 < 1 || cn < c0 || cn >= (int)img.channel.size() || cn - c0 + 1 > 64 || img.nb_frames < 1) return false;
+    const int w = img.channel[c0].w, h = img.channel[c0].h;
+    const size_t n = (size_t)w * h;
+    if (w < 0 || h < 0 || m.w != w || m.h != h || m.data.size() != n) return false;
+    std::vector<Channel> work = img.channel;
+    if (n > 0) {
+        std::vector<DevPlane> planes(cn - c0 + 1);
+        std::vector<int32_t *> ptrs;
+        for (int c = c0; c <= cn; c++) {
+            if (work[c].w != w || work[c].h != h || work[c].data.size() != n || !planes[c - c0].put(work[c])) return false;
+            ptrs.push_back(planes[c - c0].d);
+        }
+        DevPlane dm;
+        if (!dm.put(m)) return false;
+        if (fuifgpu_inv_match(dm.d, w, h, ptrs.data(), (int)ptrs.size(), par[2] ? 1 : 0, m.q, m.maxval, img.nb_frames, nullptr) != FUIFGPU_OK) return false;
+        for (int c = c0; c <= cn; c++) if (!planes[c - c0].get(work[c])) return false;
+    }
+    work.erase(work.begin(), work.begin() + 1);
+    img.channel.swap(work);
+    img.nb_meta_channels--;
+    return true;
+}
 }  // namespace
 
 bool fuifgpu_boundary_transform_apply(Transform *self, Image &input, bool inverse) __asm__("_ZN9Transform5applyER5Imageb");
@@ -612,7 +718,10 @@ bool fuifgpu_boundary_transform_apply(Transform *self, Image &input, bool invers
             case TRANSFORM_DCT: done = gpu_inv_dct(input, self->parameters); break;
             case TRANSFORM_QUANTIZE: done = gpu_inv_quantize(input); break;
             case TRANSFORM_ChromaSubsample: done = gpu_inv_subsample(input, self->parameters); break;
-            default: claimed = false; break;
+            case TRANSFORM_PALETTE: done = gpu_inv_palette(input, self->parameters); break;
+            case TRANSFORM_APPROXIMATE: done = gpu_inv_approximate(input, self->parameters); break;
+            case TRANSFORM_2DMATCH: done = gpu_inv_match(input, self->parameters); break;
+            default: claimed = false; break;   // Permute (permute.h:31-54) reorders the channel list and touches no sample: nothing for a kernel to do
         }
         if (done) {
             if (env_flag("FUIFGPU_VERBOSE")) fprintf(stderr, "fuifgpu: inverse %s on the GPU (Transform::apply)\n", self->name());

@@ -811,6 +811,8 @@ struct Builder {
                 if (pl >= 0 && planes[pl].birth == (int)k && !planes[pl].is_final)
                     planes[pl].off = arena.alloc((int64_t)planes[pl].w * planes[pl].h);
             }
+            for (int pl : ops[k].list)   // work planes an op brings along in its side list (the accumulators of a soft match)
+                if (pl >= 0 && planes[pl].birth == (int)k && !planes[pl].is_final) planes[pl].off = arena.alloc((int64_t)planes[pl].w * planes[pl].h);
             for (int pl : dying[k]) arena.release(planes[pl].off, (int64_t)planes[pl].w * planes[pl].h);
         }
         plan.tmp_elems = arena.peak;

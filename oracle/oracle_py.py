@@ -154,12 +154,14 @@ class Ref(_Lib):
         self.lib.fuifref_free_blob.argtypes = [C.c_void_p]
 
     def encode(self, planes, maxval=255, colorspace=-1, squeeze=1, max_group=-1, nb_repeats=0.5,
-               max_properties=12, compress=1, predictor=-1, permute=0, permutation=()):
-        """permute: 0 none, 1 explicit form, 2 channel form (oracle/ref_driver.cpp); permutation = new order of the channels"""
+               max_properties=12, compress=1, predictor=-1, permute=0, permutation=(), softmatch=0, match_distance=0, frames=1, quant=0):
+        """permute: 0 none, 1 explicit form, 2 channel form (oracle/ref_driver.cpp); permutation = new order of the channels;
+        match_distance != 0: a 2D-match transform with explicit parameters (soft if softmatch; negative = previous frames, then frames >= 2);
+        quant > 1: one quantization constant for every non-meta channel"""
         planes = np.ascontiguousarray(planes, dtype=np.int32)
         c, h, w = planes.shape
         perm = list(permutation) + [0] * (4 - len(permutation))
-        opts = np.array([colorspace, squeeze, max_group, int(round(nb_repeats * 1000)), max_properties, compress, predictor, permute] + perm[:4], np.int32)
+        opts = np.array([colorspace, squeeze, max_group, int(round(nb_repeats * 1000)), max_properties, compress, predictor, permute] + perm[:4] + [softmatch, match_distance, frames, quant], np.int32)
         out = C.c_void_p()
         n = self.lib.fuifref_encode(w, h, c, maxval, planes.ctypes.data, opts.ctypes.data, C.byref(out))
         if not n:

@@ -93,7 +93,13 @@ void fuifref_transform_info(void *h, int t, int32_t *out, int cap) {
 // opts[4] max_properties (CLI default 12)
 // opts[5] compress (1 default; 0 = -U uncompressed groups)
 // opts[6] predictor override for all channels (-1 = CLI defaults)
-// opts[7], opts[8..11]: Permute (see below); callers pass at least 12 ints
+// opts[7], opts[8..11]: Permute (see below)
+// opts[12], opts[13]: 2D match with explicit parameters {0, nch-1, opts[12] = softmatch, opts[13] = max distance} when opts[13] != 0, applied where the
+//            CLI applies its (never soft) match: after the colour transform, before Squeeze (fuif.cpp:438-448).  A negative distance = the
+//            previous-frame mode, which needs opts[14] = number of frames (>= 2; the planes are the vertical film strip, h = frames * frame height)
+// opts[15]: one quantization constant for every non-meta channel (0 / 1 = none): Transform(TRANSFORM_QUANTIZE) with explicit parameters, after
+//            Squeeze like the CLI's (fuif.cpp:458-505) -- a lossy stream whose soft matches carry non-zero differences
+// callers pass at least 16 ints
 // returns malloc'd blob in *out (caller frees with fuifref_free_blob), size as return value; 0 on failure
 size_t fuifref_encode(int w, int h, int nch, int maxval, const int32_t *planes, const int32_t *opts, uint8_t **out) {
     *out = nullptr;
@@ -121,10 +127,28 @@ size_t fuifref_encode(int w, int h, int nch, int maxval, const int32_t *planes, 
     }
     // fuif.cpp:380-393 (no palette here: photographic inputs)
     if (opts[0] < 0) img.do_transform(Transform(TRANSFORM_YCoCg));
+    if (opts[14] >= 2) {
+        if (h % opts[14]) return 0;
+        img.nb_frames = opts[14];
+    }
+    if (opts[13] != 0) {
+        Transform match(TRANSFORM_2DMATCH);
+        match.parameters.push_back(0);
+        match.parameters.push_back(img.nb_channels - 1);
+        match.parameters.push_back(opts[12] ? 1 : 0);
+        match.parameters.push_back(opts[13]);
+        if (!img.do_transform(match)) return 0;
+    }
     // fuif.cpp:449-455
     if (opts[1] && img.channel[0].w * img.channel[0].h > 20) {
         img.do_transform(Transform(TRANSFORM_SQUEEZE));
         if (options.max_group < 0) options.max_group = 1;
+    }
+    if (opts[15] > 1) {
+        Transform quantize(TRANSFORM_QUANTIZE);
+        for (int i = 0; i < img.nb_meta_channels; i++) quantize.parameters.push_back(1);
+        for (size_t i = img.nb_meta_channels; i < img.channel.size(); i++) quantize.parameters.push_back(opts[15]);
+        if (!img.do_transform(quantize)) return 0;
     }
     // fuif.cpp:580-588
     if (opts[6] >= 0) {

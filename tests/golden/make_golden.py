@@ -113,9 +113,18 @@ PERMUTE_SPECS = [
     ("permute_explicit_rgba14_40x36", dict(w=40, h=36, channels=4, bits=14, seed=84), dict(permute=1, permutation=(3, 1, 0, 2))),
     ("permute_channel_rgba14_40x36", dict(w=40, h=36, channels=4, bits=14, seed=85), dict(permute=2, permutation=(2, 3, 1, 0), colorspace=0)),
 ]
-PREVIEWS = {"c1_rgb8_512x512": [0, 1, 2, 3, 4], "rgb8_97x61": [0, 2, 4], "jpeg420_256x192_q90": [0, 1, 2, 3, 4],
+# Soft 2D matches (transform/2dmatch.h:136-140,150-158: the match channel marks a sample as a DIFFERENCE to an earlier sample or frame):
+# the CLI never sets the flag (fuif.cpp:445), so these too come from the reference's library calls in oracle/ref_driver.cpp -- Transform
+# (TRANSFORM_2DMATCH) with parameters {0, n-1, 1, distance}.  A lossless stream's differences are all zero; with a quantization constant
+# on every channel behind the match (or a truncated file) the decoder adds up non-zero differences along the chains.
+SOFTMATCH_SPECS = [
+    ("softmatch_rgb_graphic_96x80_q3", dict(w=96, h=80, channels=3, bits=8, seed=51, colors=400), dict(softmatch=1, match_distance=40, quant=3)),
+    ("softmatch_rgb_graphic_nosqueeze_72x60", dict(w=72, h=60, channels=3, bits=8, seed=53, colors=300), dict(softmatch=1, match_distance=200, squeeze=0)),
+    ("softmatch_anim4_40x28_q2", dict(w=40, h=28, channels=3, bits=8, seed=710, static=True), dict(softmatch=1, match_distance=-2, frames=4, quant=2)),
+]
+PREVIEWS = {"softmatch_rgb_graphic_96x80_q3": [2], "c1_rgb8_512x512": [0, 1, 2, 3, 4], "rgb8_97x61": [0, 2, 4], "jpeg420_256x192_q90": [0, 1, 2, 3, 4],
             "pal_rgb_graphic_120x90": [1, 3], "approx_rgb8_96x80_A3": [2], "approx_quant_rgb8_40x30": [3], "match_rgb_graphic_96x80": [3]}
-TRUNCATE_EXTRA = {"approx_on_palette_gray12_24x50": [0.8], "match_rgb_graphic_96x80": [0.6]}
+TRUNCATE_EXTRA = {"softmatch_rgb_graphic_nosqueeze_72x60": [0.7], "softmatch_anim4_40x28_q2": [0.6], "approx_on_palette_gray12_24x50": [0.8], "match_rgb_graphic_96x80": [0.6]}
 TRUNCATE = {"permute_channel_rgb8_48x40": [0.5], "permute_explicit_rgb8_48x40": [0.6], "rgb8_97x61": [0.2, 0.55, 0.93], "rgb8_128x128_I0": [0.5], "rgb8_112x96_E18": [0.7], "rgb8_120x88_E50": [0.6], "jpeg420_256x192_q90": [0.4], "rgb8_64x64_U": [0.6],
             "pal_rgba_graphic_72x64": [0.5], "pal_rgb_sparse_128x96": [0.7],
             "gray8_nosqueeze_60x40": [0.6], "rgb8_96x96_nosqueeze": [0.45]}
@@ -132,7 +141,7 @@ def main():
             manifest = json.load(f)
         manifest["fixtures"] = [e for e in manifest["fixtures"] if e["name"] not in only]
     tmp = tempfile.mkdtemp()
-    for name, gen, flags in SPECS + GRAPHIC_SPECS + [(n, g, j) for n, g, j in JPEG_SPECS] + ANIM_SPECS + PERMUTE_SPECS:
+    for name, gen, flags in SPECS + GRAPHIC_SPECS + [(n, g, j) for n, g, j in JPEG_SPECS] + ANIM_SPECS + PERMUTE_SPECS + SOFTMATCH_SPECS:
         if only and name not in only:
             continue
         gen = dict(gen)
@@ -147,7 +156,15 @@ def main():
                 img = img // poster * poster   # more than 256 colours, sparse per-channel histograms
         maxval = (1 << gen["bits"]) - 1
         out = os.path.join(HERE, name + ".fuif")
-        if isinstance(flags, dict) and "permute" in flags:
+        if isinstance(flags, dict) and ("permute" in flags or "softmatch" in flags):
+            if flags.get("frames", 1) > 1:     # the vertical film strip of an animation whose frames share most pixels with the first one
+                strip = []
+                for i in range(flags["frames"]):
+                    g2 = dict(gen); g2["seed"] = gen["seed"] + i
+                    fr = photographic(**g2)
+                    keep = np.ones(fr.shape[1:], bool); keep[4 + 3 * i: 14 + 3 * i, 6 + 5 * i: 20 + 5 * i] = False
+                    strip.append(np.where(keep[None], img, fr))
+                img = np.concatenate(strip, axis=1)
             blob = ref.encode(img, maxval=maxval, **flags)
             with open(out, "wb") as f:
                 f.write(blob)
@@ -186,7 +203,7 @@ def main():
                 raise SystemExit("reference CLI failed for %s: %s %s" % (name, r.stdout[-400:], r.stderr[-400:]))
         blob = open(out, "rb").read()
         entry = {"name": name, "file": name + ".fuif", "bytes": len(blob), "file_sha256": hashlib.sha256(blob).hexdigest(),
-                 "source": gen, "cli_flags": cli_flags if not isinstance(flags, dict) else (["<library: oracle/ref_driver.cpp fuifref_encode>", json.dumps(flags)] if "permute" in flags else ["<stream written by fuif_amd/jpeglike.py; expected planes = the reference decoding it>", json.dumps(flags)] if "writer_factors" in flags else ["<jpeg/anim>", json.dumps(flags)] + cli_flags), "cases": []}
+                 "source": gen, "cli_flags": cli_flags if not isinstance(flags, dict) else (["<library: oracle/ref_driver.cpp fuifref_encode>", json.dumps(flags)] if ("permute" in flags or "softmatch" in flags) else ["<stream written by fuif_amd/jpeglike.py; expected planes = the reference decoding it>", json.dumps(flags)] if "writer_factors" in flags else ["<jpeg/anim>", json.dumps(flags)] + cli_flags), "cases": []}
         cases = [("full", -1, len(blob))]
         cases += [("preview%d" % k, k, len(blob)) for k in PREVIEWS.get(name, [])]
         cases += [("trunc%02d" % int(f * 100), -1, int(len(blob) * f)) for f in TRUNCATE.get(name, []) + TRUNCATE_EXTRA.get(name, [])]

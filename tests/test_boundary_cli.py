@@ -173,6 +173,63 @@ OUTSIDE = os.path.join(GOLDEN, "outside_gpu_scope_rgb8_64x48_E64.fuif")   # writ
 OUTSIDE_PPM_SHA256 = "5200e0a07cf1683c449896c13553d91b9f1881553aba0d98cd7aaee9ecedc274"   # what the unmodified reference CLI decodes it to (= the source picture)
 
 
+# fixture -> the inverses that must be reported as run on the GPU through Transform::apply when the chain is undone one transform at a
+# time (fuif_amd/boundary/fuif_stepwise_main.cpp): every transform but the first goes through the per-transform binding; the inverse
+# of Permute moves no sample and stays the reference's statement
+STEPWISE = {
+    "match_rgb_graphic_nosqueeze_72x60": ["Matching", "Palette", "YCoCg"],
+    "match_rgb_graphic_96x80": ["Squeeze", "Matching", "Palette", "YCoCg"],
+    "anim4_match_40x28": ["Squeeze", "Matching", "YCoCg"],
+    "pal_rgb_channelwise_96x72": ["Squeeze", "Palette", "YCoCg"],
+    "pal_rgba_graphic_72x64": ["Squeeze", "Palette", "YCoCg"],
+    "approx_quant_rgb8_40x30": ["Approximation", "Quantization", "Squeeze", "YCoCg"],
+    "approx_on_palette_gray12_24x50": ["Approximation", "Palette"],
+    "jpeg420_256x192_q90": ["Squeeze", "Quantization", "DCT", "ChromaSubsampling", "YCbCr"],
+    "softmatch_rgb_graphic_96x80_q3": ["Quantization", "Squeeze", "Matching", "YCoCg"],
+    "softmatch_rgb_graphic_nosqueeze_72x60": ["Matching"],
+    "softmatch_anim4_40x28_q2": ["Quantization", "Squeeze", "Matching", "YCoCg"],
+    "permute_channel_rgb8_48x40": ["YCoCg"],
+    "permute_explicit_rgba14_40x36": ["Squeeze", "YCoCg"],
+}
+
+
+def check_stepwise_undo(run_stepwise, run_ref, tmp_path):
+    """shared with tests/test_emulated_kernels.py (CPU, emulated library).  Image::undo_transforms(k) for k = n-1 .. 0: every call undoes
+    one transform through Transform::apply(image, true) (image/image.cpp:94-115), which the binding sends to the single-transform
+    entry points of the C-ABI -- Palette, Approximate and 2D-match included.  The PAM file must be the unmodified CLI's, also for a
+    responsive decode (undecoded channels read as zeros in every inverse)."""
+    for name, expected in STEPWISE.items():
+        src = os.path.join(GOLDEN, name + ".fuif")
+        for extra in ([], ["-R", "2"], ["-R", "0"]):
+            a, b = str(tmp_path / "step.pam"), str(tmp_path / "ref.pam")
+            for f in (a, b):
+                if os.path.exists(f):
+                    os.remove(f)
+            ra = run_stepwise(extra + [src, a])
+            assert ra.returncode == 0, (name, extra, ra.stderr[-600:])
+            rb = run_ref(["-d"] + extra + [src, b])
+            assert rb.returncode == 0, (name, extra, rb.stderr[-300:])
+            assert open(a, "rb").read() == open(b, "rb").read(), (name, extra)
+            assert "with the reference's CPU code" not in ra.stderr, (name, ra.stderr[-600:])
+            for t in expected:
+                assert "inverse %s on the GPU (Transform::apply)" % t in ra.stderr, (name, extra, t, ra.stderr[-600:])
+
+
+@pytest.mark.gpu
+def test_undoing_the_chain_one_transform_at_a_time_runs_every_inverse_on_the_gpu(tmp_path):
+    need_cli()
+    stepwise = os.path.join(ROOT, "fuif_amd", "boundary", "_build", "fuif_gpu_stepwise")
+    ref_cli = os.path.join(ROOT, "oracle", "_ref", "fuif")
+    if not (os.path.exists(stepwise) and os.path.exists(ref_cli)):
+        pytest.skip("fuif_gpu_stepwise / oracle/_ref/fuif not built")
+    env = dict(os.environ, FUIFGPU_VERBOSE="1")
+    if os.path.exists("/opt/conda/lib/libjpeg.so.9"):
+        env["LD_PRELOAD"] = "/opt/conda/lib/libjpeg.so.9"
+    env.pop("FUIFGPU_ALLOW_CPU_FALLBACK", None)
+    check_stepwise_undo(lambda args: subprocess.run([stepwise] + args, env=env, capture_output=True, text=True, timeout=300),
+                        lambda args: subprocess.run([ref_cli] + args, env=env, capture_output=True, text=True, timeout=300), tmp_path)
+
+
 def check_cpu_route_is_opt_in(run, tmp_path):
     """shared with tests/test_emulated_kernels.py (CPU): default = loud error and no output file; FUIFGPU_ALLOW_CPU_FALLBACK=1 = the
     reference's own decoder, announced on stderr, writing the file the unmodified reference CLI writes"""

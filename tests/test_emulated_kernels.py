@@ -161,11 +161,17 @@ def test_reference_cli_through_the_boundary_writes_the_reference_files(tmp_path)
     env_gpu = dict(env, LD_LIBRARY_PATH=str(libdir), EMU_ALARM="600")   # no switch set: by default it is the GPU path or nothing
     names = ["rgb8_97x61", "pal_rgb_graphic_120x90", "pal_rgba_graphic_72x64", "pal_rgb_channelwise_96x72", "approx_quant_rgb8_40x30",
              "approx_on_palette_gray12_24x50", "match_rgb_graphic_96x80", "gray8_nosqueeze_60x40", "jpeg420_256x192_q90", "rgba14_80x72",
-             "anim3_48x32", "anim4_match_40x28"]
+             "anim3_48x32", "anim4_match_40x28", "softmatch_rgb_graphic_96x80_q3", "softmatch_anim4_40x28_q2"]
     # the reference's CPU decoder behind the binding is opt-in: a stream outside the GPU scope is a loud error by default
     from test_boundary_cli import check_cpu_route_is_opt_in
     check_cpu_route_is_opt_in(lambda args, fb: subprocess.run([gpu_cli] + args, env=dict(env_gpu, FUIFGPU_VERBOSE="1", **({"FUIFGPU_ALLOW_CPU_FALLBACK": "1"} if fb else {})),
                                                               capture_output=True, text=True, timeout=600), tmp_path)
+    # the chain undone one transform at a time: every inverse through the binding's Transform::apply and the single-transform entry points
+    stepwise = os.path.join(ROOT, "fuif_amd", "boundary", "_build", "fuif_gpu_stepwise")
+    if os.path.exists(stepwise):
+        from test_boundary_cli import check_stepwise_undo
+        check_stepwise_undo(lambda args: subprocess.run([stepwise] + args, env=dict(env_gpu, FUIFGPU_VERBOSE="1"), capture_output=True, text=True, timeout=600),
+                            lambda args: subprocess.run([ref_cli] + args, env=env, capture_output=True, text=True, timeout=600), tmp_path)
     for name in names:
         src = os.path.join(ROOT, "tests", "golden", name + ".fuif")
         for extra in ([], ["-R", "2"]):
