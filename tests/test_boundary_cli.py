@@ -193,14 +193,14 @@ STEPWISE = {
 }
 
 
-def check_stepwise_undo(run_stepwise, run_ref, tmp_path):
+def check_stepwise_undo(run_stepwise, run_ref, tmp_path, previews=([], ["-R", "2"], ["-R", "0"])):
     """shared with tests/test_emulated_kernels.py (CPU, emulated library).  Image::undo_transforms(k) for k = n-1 .. 0: every call undoes
     one transform through Transform::apply(image, true) (image/image.cpp:94-115), which the binding sends to the single-transform
     entry points of the C-ABI -- Palette, Approximate and 2D-match included.  The PAM file must be the unmodified CLI's, also for a
     responsive decode (undecoded channels read as zeros in every inverse)."""
     for name, expected in STEPWISE.items():
         src = os.path.join(GOLDEN, name + ".fuif")
-        for extra in ([], ["-R", "2"], ["-R", "0"]):
+        for extra in previews:
             a, b = str(tmp_path / "step.pam"), str(tmp_path / "ref.pam")
             for f in (a, b):
                 if os.path.exists(f):
@@ -227,7 +227,8 @@ def test_undoing_the_chain_one_transform_at_a_time_runs_every_inverse_on_the_gpu
         env["LD_PRELOAD"] = "/opt/conda/lib/libjpeg.so.9"
     env.pop("FUIFGPU_ALLOW_CPU_FALLBACK", None)
     check_stepwise_undo(lambda args: subprocess.run([stepwise] + args, env=env, capture_output=True, text=True, timeout=300),
-                        lambda args: subprocess.run([ref_cli] + args, env=env, capture_output=True, text=True, timeout=300), tmp_path)
+                        lambda args: subprocess.run([ref_cli] + args, env=env, capture_output=True, text=True, timeout=300), tmp_path,
+                        previews=([], ["-R", "2"]))   # (every process start pays the HIP runtime's second; -R 0 runs in the CPU suite on the emulator)
 
 
 def check_cpu_route_is_opt_in(run, tmp_path):
