@@ -68,6 +68,14 @@ CONCURRENT = [
 ]
 
 
+def _workers(n):
+    try:
+        import xdist  # noqa: F401
+        return ["-n", str(n)]
+    except ImportError:
+        return []
+
+
 def test_tile_hand_off_with_concurrent_emulated_wavefronts():
     """the same group-parallel tests with FOUR persistent wavefronts running at once (one OS thread each, EMU_WAVES /
     EMU_THREADS): tiles really wait for each other's headers and rows here.  x86 is more strongly ordered than the
@@ -77,7 +85,7 @@ def test_tile_hand_off_with_concurrent_emulated_wavefronts():
     lib = build_emulated_library()
     env = dict(os.environ)
     env.update(FUIF_AMD_LIB=lib, FUIF_TEST_MAX_PIXELS="50000", FUIF_TEST_BATCH="12", EMU_ALARM="1500", EMU_WAVES="4", EMU_THREADS="4")
-    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + CONCURRENT
+    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + CONCURRENT + _workers(2)   # (x 4 emulator threads each)
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1700)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
@@ -97,7 +105,7 @@ def test_pinned_tiles_with_concurrent_emulated_wavefronts(ctx_kb):
                FUIFGPU_CTX_KB=ctx_kb)
     cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
            "tests/test_gpu_group_parallel.py::test_reference_written_files_indexed_after_the_fact",
-           "tests/test_gpu_group_parallel.py::test_writer_indexed_streams_vs_oracle[97-61-3-8-2]"]
+           "tests/test_gpu_group_parallel.py::test_writer_indexed_streams_vs_oracle[97-61-3-8-2]"] + _workers(2)
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1700)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
@@ -132,7 +140,7 @@ def test_node_by_node_walk_beyond_the_supernode_cap():
            "tests/test_gpu_synthetic.py::test_deep_trees_walk_through_chained_supernodes", "tests/test_gpu_parity.py::test_golden_fixtures_bit_exact"]
     try:
         import xdist  # noqa: F401
-        cmd += ["-n", "3"]
+        cmd += ["-n", "5"]
     except ImportError:
         pass
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1700)

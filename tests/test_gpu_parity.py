@@ -26,9 +26,12 @@ def _decode_case(gpulib, blob, preview):
         batch.close()
 
 
-def test_golden_fixtures_bit_exact(gpulib, manifest, port):
+@pytest.mark.parametrize("shard", range(8))      # (eight tests so that the emulator run of the CPU suite spreads them over its workers)
+def test_golden_fixtures_bit_exact(gpulib, manifest, port, shard):
     failures = []
-    for e, c in all_cases(manifest):
+    for k, (e, c) in enumerate(all_cases(manifest)):
+        if k % 8 != shard:
+            continue
         blob = golden_blob(e, c)
         what = "%s/%s" % (e["name"], c["case"])
         pre, meta, post, st, used = _decode_case(gpulib, blob, c["preview"])
@@ -90,11 +93,14 @@ def test_mixed_streams_scheduler(gpulib, manifest):
         assert [plane_hash(p) for p in planes] == [c["sha256"] for c in by[n]["cases"][0]["post"]], n
 
 
-def test_packed_output_is_the_pam_payload(gpulib, manifest, port):
+@pytest.mark.parametrize("shard", range(4))
+def test_packed_output_is_the_pam_payload(gpulib, manifest, port, shard):
     """fuifgpu_batch_download_packed: the bytes export/write_pam.h:136-150 would put behind the PNM/PAM header
     (interleaved, clamped, 8 bit or 16 bit big-endian), produced by the packing kernel from the final planes"""
     checked = 0
-    for e in manifest["fixtures"]:
+    for k, e in enumerate(manifest["fixtures"]):
+        if k % 4 != shard:
+            continue
         c = e["cases"][0]
         blob = golden_blob(e, c)
         info = c["info"]
@@ -115,7 +121,7 @@ def test_packed_output_is_the_pam_payload(gpulib, manifest, port):
         want = np.stack([ch["data"][:h, :w] for ch in post.channels], axis=-1)
         assert got.shape == want.shape and np.array_equal(got.astype(np.int64), np.clip(want, 0, info["maxval"])), e["name"]
         checked += 1
-    assert checked >= 10
+    assert checked >= 2
 
 
 def test_undo_transforms_is_once_per_decode(gpulib, manifest):
