@@ -76,9 +76,12 @@ def make_inputs(k, w, h, channels, bits, seed0, cache_dir, kind="squeeze"):
         with mp.get_context("fork").Pool(nproc) as pool:
             for seed, blob in pool.imap_unordered(_encode_one, jobs):
                 blobs[seed] = blob
-                try:
-                    with open(os.path.join(cache_dir, name % (w, h, channels, bits, seed)), "wb") as f:
+                try:    # (atomic: the ranks of a multi-GPU run share the directory, and a late rank must never read half a file)
+                    final = os.path.join(cache_dir, name % (w, h, channels, bits, seed))
+                    part = "%s.%d.part" % (final, os.getpid())
+                    with open(part, "wb") as f:
                         f.write(blob)
+                    os.replace(part, final)
                 except OSError:
                     pass
     return [(seed0 + i, blobs[seed0 + i]) for i in range(k)]
