@@ -231,6 +231,55 @@ def test_undoing_the_chain_one_transform_at_a_time_runs_every_inverse_on_the_gpu
                         previews=([], ["-R", "2"]))   # (every process start pays the HIP runtime's second; -R 0 runs in the CPU suite on the emulator)
 
 
+def check_index_tool(run_index, run_gpu_cli, run_ref, tmp_path):
+    """shared with tests/test_emulated_kernels.py.  fuif_gpu_index (fuif_amd/boundary/fuif_index_main.cpp) gives files written by the
+    reference encoder the group index: output = input bytes + FGIX trailer; the unmodified reference CLI decodes it like the input;
+    the GPU path decodes it group by group to the same file; an indexed file is recognised and copied; a stream outside the GPU
+    scope is copied without index."""
+    import fuif_amd
+    names = ["rgb8_97x61", "rgba14_80x72", "jpeg420_256x192_q90", "pal_rgb_graphic_120x90", "rgb8_120x88_E50"]
+    outdir = tmp_path / "indexed"
+    outdir.mkdir()
+    files = [os.path.join(GOLDEN, n + ".fuif") for n in names] + [OUTSIDE]
+    r = run_index([str(outdir)] + files)
+    assert r.returncode == 0, r.stderr[-800:]
+    assert "%d file(s) indexed, 1 copied unchanged, 0 failed" % len(names) in r.stderr, r.stderr[-400:]
+    assert open(str(outdir / os.path.basename(OUTSIDE)), "rb").read() == open(OUTSIDE, "rb").read()
+    for n in names:
+        src = open(os.path.join(GOLDEN, n + ".fuif"), "rb").read()
+        out = open(str(outdir / (n + ".fuif")), "rb").read()
+        assert out[:len(src)] == src and out.endswith(b"FGIX") and len(out) > len(src) + 8, n
+        assert len(fuif_amd.index_parse(out)) > 1, n
+        a, b, c = str(tmp_path / "ref_plain.pam"), str(tmp_path / "ref_indexed.pam"), str(tmp_path / "gpu_indexed.pam")
+        assert run_ref(["-d", os.path.join(GOLDEN, n + ".fuif"), a]).returncode == 0
+        assert run_ref(["-d", str(outdir / (n + ".fuif")), b]).returncode == 0          # the reference never reads the trailer
+        rg = run_gpu_cli(["-d", str(outdir / (n + ".fuif")), c])
+        assert rg.returncode == 0, rg.stderr[-400:]
+        assert open(a, "rb").read() == open(b, "rb").read() == open(c, "rb").read(), n
+        tiles = [ln for ln in rg.stderr.splitlines() if " tiles, " in ln]
+        assert tiles and " 1 tiles," not in tiles[0], rg.stderr[-400:]                   # one tile per channel group, not one per image
+    again = tmp_path / "again"
+    again.mkdir()
+    r = run_index([str(again)] + [str(outdir / (n + ".fuif")) for n in names])
+    assert r.returncode == 0 and "0 file(s) indexed, %d copied unchanged" % len(names) in r.stderr, r.stderr[-400:]
+    for n in names:
+        assert open(str(again / (n + ".fuif")), "rb").read() == open(str(outdir / (n + ".fuif")), "rb").read()
+
+
+@pytest.mark.gpu
+def test_index_tool_gives_reference_written_files_the_group_index(tmp_path):
+    need_cli()
+    tool = os.path.join(ROOT, "fuif_amd", "boundary", "_build", "fuif_gpu_index")
+    ref_cli = os.path.join(ROOT, "oracle", "_ref", "fuif")
+    if not (os.path.exists(tool) and os.path.exists(ref_cli)):
+        pytest.skip("fuif_gpu_index / oracle/_ref/fuif not built")
+    env = dict(os.environ, FUIFGPU_VERBOSE="1")
+    if os.path.exists("/opt/conda/lib/libjpeg.so.9"):
+        env["LD_PRELOAD"] = "/opt/conda/lib/libjpeg.so.9"
+    check_index_tool(lambda args: subprocess.run([tool] + args, env=env, capture_output=True, text=True, timeout=300),
+                     lambda args: run_cli(args), lambda args: subprocess.run([ref_cli] + args, env=env, capture_output=True, text=True, timeout=300), tmp_path)
+
+
 def check_cpu_route_is_opt_in(run, tmp_path):
     """shared with tests/test_emulated_kernels.py (CPU): default = loud error and no output file; FUIFGPU_ALLOW_CPU_FALLBACK=1 = the
     reference's own decoder, announced on stderr, writing the file the unmodified reference CLI writes"""

@@ -180,6 +180,13 @@ def test_reference_cli_through_the_boundary_writes_the_reference_files(tmp_path)
         from test_boundary_cli import check_stepwise_undo
         check_stepwise_undo(lambda args: subprocess.run([stepwise] + args, env=dict(env_gpu, FUIFGPU_VERBOSE="1"), capture_output=True, text=True, timeout=600),
                             lambda args: subprocess.run([ref_cli] + args, env=env, capture_output=True, text=True, timeout=600), tmp_path)
+    # the indexing front end: reference-written files + FGIX trailer, decoded group by group afterwards
+    index_tool = os.path.join(ROOT, "fuif_amd", "boundary", "_build", "fuif_gpu_index")
+    if os.path.exists(index_tool):
+        from test_boundary_cli import check_index_tool
+        check_index_tool(lambda args: subprocess.run([index_tool] + args, env=dict(env_gpu, FUIFGPU_VERBOSE="1"), capture_output=True, text=True, timeout=600),
+                         lambda args: subprocess.run([gpu_cli] + args, env=dict(env_gpu, FUIFGPU_VERBOSE="1"), capture_output=True, text=True, timeout=600),
+                         lambda args: subprocess.run([ref_cli] + args, env=env, capture_output=True, text=True, timeout=600), tmp_path)
     for name in names:
         src = os.path.join(ROOT, "tests", "golden", name + ".fuif")
         for extra in ([], ["-R", "2"]):
