@@ -456,6 +456,35 @@ def index_append(blob, groups):
     return res
 
 
+def add_group_index(blobs, hbm_budget_bytes=200 << 30):
+    """Existing streams (as the reference encoder writes them) -> the same bytes + the group index trailer, in the caller's order:
+    one entropy-decode launch per geometry (a streaming batch: no output slab, no inverse transforms), the group starts the kernel
+    went through (fuifgpu_batch_group_index) appended with index_append.  A stream that already has a valid trailer, or whose decode
+    is flagged (truncated / corrupt: its group starts are not those of the whole file), comes back unchanged.  The Python form of
+    fuif_amd/boundary/fuif_index_main.cpp."""
+    out = list(blobs)
+    todo = [i for i, b in enumerate(blobs) if not index_parse(b)]
+    for sig, (plan, idx) in group_by_signature([blobs[i] for i in todo]).items():
+        idx = [todo[k] for k in idx]
+        per = 2 * plan.info.coef_elems + 19 * (1 << 20) + max(len(blobs[i]) for i in idx)
+        chunk = max(1, min(len(idx), int(hbm_budget_bytes // per), 65535))
+        for c0 in range(0, len(idx), chunk):
+            part = idx[c0:c0 + chunk]
+            sub = [blobs[i] for i in part]
+            batch = Batch(plan, len(sub), sum(len(b) for b in sub) + 4096 * len(sub), streaming=True)
+            try:
+                batch.upload(sub)
+                batch.decode()
+                batch.sync()
+                st, _ = batch.status()
+                for k, i in enumerate(part):
+                    if st[k] == 0:
+                        out[i] = index_append(blobs[i], batch.group_index(k))
+            finally:
+                batch.close()
+    return out
+
+
 def group_by_signature(blobs):
     """host-side batch scheduler, step 1: streams that share geometry + transform chain (equal
     fuifgpu_image_info::signature) can share a launch.  Returns {signature: (Plan, [indices])} in

@@ -45,6 +45,7 @@ SELECTED = [
     "tests/test_gpu_parity.py::test_invalid_permutation_flags_the_image_and_zero_fills",
     "tests/test_gpu_group_parallel.py::test_reference_written_files_indexed_after_the_fact",
     "tests/test_gpu_group_parallel.py::test_previews_of_indexed_streams",
+    "tests/test_gpu_group_parallel.py::test_add_group_index_in_one_launch_per_geometry",
     "tests/test_gpu_group_parallel.py::test_writer_indexed_streams_vs_oracle[97-61-3-8-2]",
     "tests/test_gpu_group_parallel.py::test_writer_indexed_streams_vs_oracle[301-47-1-8-42]",
     "tests/test_gpu_group_parallel.py::test_mixed_batch_with_more_tiles_than_wavefronts",

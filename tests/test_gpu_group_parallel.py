@@ -68,6 +68,27 @@ def test_reference_written_files_indexed_after_the_fact(gpulib, manifest, port, 
     assert not failures, failures
 
 
+def test_add_group_index_in_one_launch_per_geometry(gpulib, manifest, port):
+    """fuif_amd.add_group_index: a mixed list of reference-written streams (three geometries, one of them three times, one already
+    indexed, one truncated) comes back in order with the trailer the oracle's group starts spell; the truncated one unchanged"""
+    pick = ["rgb8_97x61", "rgba14_80x72", "rgb8_97x61", "pal_rgb_graphic_120x90", "rgb8_97x61"]
+    blobs = []
+    for n in pick:
+        e = next(x for x in manifest["fixtures"] if x["name"] == n)
+        blobs.append(golden_blob(e, e["cases"][0]))
+    groups0 = port.decode(blobs[0], undo=False).groups
+    blobs[2] = gpulib.index_append(blobs[2], groups0)              # already indexed
+    blobs[4] = blobs[4][: len(blobs[4]) * 2 // 3]                   # truncated: decodes, but gets no index
+    out = gpulib.add_group_index(blobs)
+    assert out[2] == blobs[2] and out[4] == blobs[4]
+    for i in (0, 1, 3):
+        want = port.decode(blobs[i], undo=False).groups
+        assert out[i][: len(blobs[i])] == blobs[i] and gpulib.index_parse(out[i]) == want, pick[i]
+        assert out[i] == gpulib.index_append(blobs[i], want)
+    seq, par = _run(gpulib, [blobs[1]], parallel=False), _run(gpulib, [out[1]])
+    assert _same(seq, par) and par["st"][0] == 0
+
+
 def test_previews_of_indexed_streams(gpulib, manifest):
     for e, c in all_cases(manifest):
         if not c["case"].startswith("preview"):
