@@ -20,7 +20,8 @@
 // unsupported stream is a loud error (so a planner regression cannot hide behind a fallback);
 // FUIFGPU_ALLOW_CPU_FALLBACK=1 opts in to the reference's code for such input; FUIFGPU_VERBOSE=1 reports
 // on stderr which path decoded.  Everything else (fuif.cpp, import/export code, the encoder) is
-// compiled and linked UNCHANGED.
+// compiled and linked UNCHANGED; fuif_encode_file is bound as well, only to append the group index to the file the
+// reference's encoder wrote when FUIFGPU_WRITE_INDEX=1 asks for it (off by default).
 //
 // Ownership: fuif_decode() fills `image` exactly like the reference (channel vector = coded
 // channels with geometry, ranges, q and samples narrowed to pixel_type; transform list with
@@ -206,6 +207,57 @@ bool fuif_decode_file(const char *filename, Image &image, fuif_options options) 
     if (!file) return false;
     FileIO fio(file, (file == stdin ? "from standard input" : filename));
     return fuif_decode(fio, image, options);
+}
+
+// fuif_encode_file (encoding/encoding.cpp:727-735, called by fuif.cpp:615).  The reference's encoder does all the work under the name
+// fuif_encode_file_cpu (the Makefile's rename); with FUIFGPU_WRITE_INDEX=1 the file it wrote is decoded once on the GPU (entropy decode
+// only) and gets the group index trailer: byte for byte the reference's stream, then the trailer its decoder never reads --
+// so that `fuif in.ppm out.fuif` produces files whose channel groups decode in parallel from then on.  Off by default: the CLI's output stays the
+// reference's file exactly; a file the GPU path cannot index (out of scope, no device) is left as it is, with a note on stderr.
+bool fuif_encode_file_cpu(const char *filename, const Image &image, fuif_options &options);
+bool fuif_encode_file(const char *filename, const Image &image, fuif_options &options) {
+    if (!fuif_encode_file_cpu(filename, image, options)) return false;
+    if (!env_flag("FUIFGPU_WRITE_INDEX") || !strcmp(filename, "-")) return true;
+    std::vector<uint8_t> bytes;
+    {
+        FILE *f = fopen(filename, "rb");
+        if (!f) return true;
+        FileIO io(f, filename);
+        bytes = slurp(io);
+    }
+    fuifgpu_plan *plan = nullptr;
+    fuifgpu_batch *batch = nullptr;
+    uint8_t *indexed = nullptr;
+    size_t indexed_size = 0;
+    int ng = 0;
+    int rc = fuifgpu_plan_create(bytes.data(), bytes.size(), &plan);
+    if (rc == FUIFGPU_OK) rc = fuifgpu_batch_create_streaming(plan, 1, bytes.size() + 4096, 1, &batch);
+    const uint8_t *ptr = bytes.data();
+    const size_t size = bytes.size();
+    if (rc == FUIFGPU_OK) rc = fuifgpu_batch_upload(batch, &ptr, &size, 1, -1, nullptr);
+    if (rc == FUIFGPU_OK) rc = fuifgpu_batch_decode(batch, nullptr);
+    if (rc == FUIFGPU_OK) rc = fuifgpu_batch_sync(batch, nullptr);
+    int32_t status = 0;
+    if (rc == FUIFGPU_OK) { fuifgpu_batch_status(batch, &status, nullptr); if (status) rc = FUIFGPU_E_CORRUPT; }
+    if (rc == FUIFGPU_OK) {
+        fuifgpu_image_info info;
+        fuifgpu_plan_info(plan, &info);
+        std::vector<int32_t> first((size_t)info.nb_coded_channels + 1);
+        std::vector<uint32_t> start((size_t)info.nb_coded_channels + 1);
+        rc = fuifgpu_batch_group_index(batch, 0, first.data(), start.data(), (int)first.size(), &ng);
+        if (rc == FUIFGPU_OK) rc = fuifgpu_index_append(bytes.data(), bytes.size(), first.data(), start.data(), ng, &indexed, &indexed_size);
+    }
+    if (rc == FUIFGPU_OK) {
+        FILE *f = fopen(filename, "wb");
+        if (f) { fwrite(indexed, 1, indexed_size, f); fclose(f); }
+        if (env_flag("FUIFGPU_VERBOSE")) fprintf(stderr, "fuifgpu: %s: group index of %d groups appended (%zu + %zu bytes)\n", filename, ng, bytes.size(), indexed_size - bytes.size());
+    } else {
+        fprintf(stderr, "fuifgpu: %s written without group index (%s)\n", filename, status ? "the decode was flagged" : fuifgpu_last_error());
+    }
+    fuifgpu_free_blob(indexed);
+    if (batch) fuifgpu_batch_destroy(batch);
+    if (plan) fuifgpu_plan_destroy(plan);
+    return true;
 }
 
 void fuifgpu_boundary_undo_transforms(Image *self, int keep) __asm__("_ZN5Image15undo_transformsEi");

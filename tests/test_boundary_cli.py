@@ -266,6 +266,41 @@ def check_index_tool(run_index, run_gpu_cli, run_ref, tmp_path):
         assert open(str(again / (n + ".fuif")), "rb").read() == open(str(outdir / (n + ".fuif")), "rb").read()
 
 
+def check_encoder_writes_index(run_gpu_cli_env, run_ref, tmp_path):
+    """shared with tests/test_emulated_kernels.py.  `fuif in.ppm out.fuif` through the binding: by default the reference's file exactly;
+    with FUIFGPU_WRITE_INDEX=1 the same bytes plus the group index trailer (fuif_encode_file bound in fuif_gpu_boundary.cpp), which the
+    unmodified CLI decodes to the source picture"""
+    import fuif_amd
+    from fuif_amd.synth import photographic, write_pnm
+    src = str(tmp_path / "in.ppm")
+    write_pnm(src, photographic(w=97, h=61, channels=3, bits=8, seed=2), 255)
+    plain, indexed, ref = str(tmp_path / "plain.fuif"), str(tmp_path / "indexed.fuif"), str(tmp_path / "ref.fuif")
+    assert run_gpu_cli_env([src, plain], {}).returncode == 0
+    r = run_gpu_cli_env([src, indexed], {"FUIFGPU_WRITE_INDEX": "1"})
+    assert r.returncode == 0 and "group index of" in r.stderr, r.stderr[-400:]
+    assert run_ref([src, ref]).returncode == 0
+    a, b, c = (open(f, "rb").read() for f in (plain, indexed, ref))
+    assert a == c                                            # the binding leaves the encoder alone
+    assert b[: len(a)] == a and b.endswith(b"FGIX") and len(fuif_amd.index_parse(b)) > 1
+    back = str(tmp_path / "back.ppm")
+    assert run_ref(["-d", indexed, back]).returncode == 0
+    assert open(back, "rb").read() == open(src, "rb").read()
+
+
+@pytest.mark.gpu
+def test_encoding_through_the_binding_can_write_the_group_index(tmp_path):
+    need_cli()
+    ref_cli = os.path.join(ROOT, "oracle", "_ref", "fuif")
+    if not os.path.exists(ref_cli):
+        pytest.skip("oracle/_ref/fuif not built")
+    env = dict(os.environ, FUIFGPU_VERBOSE="1")
+    if os.path.exists("/opt/conda/lib/libjpeg.so.9"):
+        env["LD_PRELOAD"] = "/opt/conda/lib/libjpeg.so.9"
+    env.pop("FUIFGPU_WRITE_INDEX", None)
+    check_encoder_writes_index(lambda args, extra: subprocess.run([CLI] + args, env=dict(env, **extra), capture_output=True, text=True, timeout=300),
+                               lambda args: subprocess.run([ref_cli] + args, env=env, capture_output=True, text=True, timeout=300), tmp_path)
+
+
 @pytest.mark.gpu
 def test_index_tool_gives_reference_written_files_the_group_index(tmp_path):
     need_cli()

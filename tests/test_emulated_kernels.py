@@ -188,6 +188,11 @@ def test_reference_cli_through_the_boundary_writes_the_reference_files(tmp_path)
         check_index_tool(lambda args: subprocess.run([index_tool] + args, env=dict(env_gpu, FUIFGPU_VERBOSE="1"), capture_output=True, text=True, timeout=600),
                          lambda args: subprocess.run([gpu_cli] + args, env=dict(env_gpu, FUIFGPU_VERBOSE="1"), capture_output=True, text=True, timeout=600),
                          lambda args: subprocess.run([ref_cli] + args, env=env, capture_output=True, text=True, timeout=600), tmp_path)
+    from test_boundary_cli import check_encoder_writes_index
+    enc_dir = tmp_path / "enc"
+    enc_dir.mkdir()
+    check_encoder_writes_index(lambda args, extra: subprocess.run([gpu_cli] + args, env=dict(env_gpu, FUIFGPU_VERBOSE="1", **extra), capture_output=True, text=True, timeout=600),
+                               lambda args: subprocess.run([ref_cli] + args, env=env, capture_output=True, text=True, timeout=600), enc_dir)
     for name in names:
         src = os.path.join(ROOT, "tests", "golden", name + ".fuif")
         for extra in ([], ["-R", "2"]):
