@@ -37,29 +37,56 @@ def build_emulated_library(extra=(), name="libfuifgpu_emu.so"):
     return lib
 
 
+# (node id, rough seconds on the emulator): the run below deals them to concurrent pytest processes longest first -- xdist hands every worker
+# a run of CONSECUTIVE tests to start with, which put the parametrised shards of one slow test on one worker
 SELECTED = [
-    "tests/test_gpu_parity.py::test_golden_fixtures_bit_exact",
-    "tests/test_gpu_parity.py::test_batch_of_replicas_and_distinct_streams",
-    "tests/test_gpu_parity.py::test_packed_output_is_the_pam_payload",
-    "tests/test_gpu_parity.py::test_undo_transforms_is_once_per_decode",
-    "tests/test_gpu_parity.py::test_invalid_permutation_flags_the_image_and_zero_fills",
-    "tests/test_gpu_group_parallel.py::test_reference_written_files_indexed_after_the_fact",
-    "tests/test_gpu_group_parallel.py::test_previews_of_indexed_streams",
-    "tests/test_gpu_group_parallel.py::test_add_group_index_in_one_launch_per_geometry",
-    "tests/test_gpu_group_parallel.py::test_writer_indexed_streams_vs_oracle[97-61-3-8-2]",
-    "tests/test_gpu_group_parallel.py::test_writer_indexed_streams_vs_oracle[301-47-1-8-42]",
-    "tests/test_gpu_group_parallel.py::test_mixed_batch_with_more_tiles_than_wavefronts",
-    "tests/test_gpu_group_parallel.py::test_jpeg_like_indexed",
-    "tests/test_gpu_group_parallel.py::test_truncated_indexed_stream_falls_back_and_side_index_on_truncated_blob",
-    "tests/test_gpu_group_parallel.py::test_stale_index_is_flagged_not_silently_wrong",
-    "tests/test_fuzz.py::test_gpu_agrees_with_oracle_on_corrupt_payload",
-    "tests/test_gpu_transform_exports.py",
-    "tests/test_gpu_synthetic.py::test_deep_trees_walk_through_chained_supernodes",
-    "tests/test_gpu_synthetic.py::test_sibling_batch_pipelines_uploads",
-    "tests/test_gpu_synthetic.py::test_sibling_outliving_its_primary_is_refused_not_dangling",
-    "tests/test_gpu_synthetic.py::test_unsqueeze_kernels_on_geometries_around_their_tile_edges",
-    "tests/test_zz_gpu_encoder.py",
+    ("tests/test_gpu_synthetic.py::test_deep_trees_walk_through_chained_supernodes[False]", 50),
+    ("tests/test_gpu_group_parallel.py::test_mixed_batch_with_more_tiles_than_wavefronts", 48),
+    ("tests/test_gpu_synthetic.py::test_deep_trees_walk_through_chained_supernodes[True]", 45),
+    ("tests/test_gpu_group_parallel.py::test_previews_of_indexed_streams", 38),
+    ("tests/test_zz_gpu_encoder.py", 35),
+    ("tests/test_gpu_synthetic.py::test_sibling_batch_pipelines_uploads", 27),
+    ("tests/test_fuzz.py::test_gpu_agrees_with_oracle_on_corrupt_payload", 26),
+] + [("tests/test_gpu_group_parallel.py::test_reference_written_files_indexed_after_the_fact[%d]" % k, 25) for k in range(4)] + [
+    ("tests/test_gpu_parity.py::test_packed_output_is_the_pam_payload[%d]" % k, 23) for k in range(4)] + [
+    ("tests/test_gpu_parity.py::test_batch_of_replicas_and_distinct_streams", 22),
+    ("tests/test_gpu_synthetic.py::test_unsqueeze_kernels_on_geometries_around_their_tile_edges", 40),
+    ("tests/test_gpu_transform_exports.py", 20),
+] + [("tests/test_gpu_parity.py::test_golden_fixtures_bit_exact[%d]" % k, 12) for k in range(8)] + [
+    ("tests/test_gpu_group_parallel.py::test_jpeg_like_indexed", 10),
+    ("tests/test_gpu_group_parallel.py::test_writer_indexed_streams_vs_oracle[97-61-3-8-2]", 8),
+    ("tests/test_gpu_group_parallel.py::test_writer_indexed_streams_vs_oracle[301-47-1-8-42]", 8),
+    ("tests/test_gpu_group_parallel.py::test_add_group_index_in_one_launch_per_geometry", 8),
+    ("tests/test_gpu_group_parallel.py::test_truncated_indexed_stream_falls_back_and_side_index_on_truncated_blob", 6),
+    ("tests/test_gpu_group_parallel.py::test_stale_index_is_flagged_not_silently_wrong", 5),
+    ("tests/test_gpu_parity.py::test_undo_transforms_is_once_per_decode", 5),
+    ("tests/test_gpu_parity.py::test_invalid_permutation_flags_the_image_and_zero_fills", 5),
+    ("tests/test_gpu_synthetic.py::test_sibling_outliving_its_primary_is_refused_not_dangling", 3),
 ]
+
+
+def run_dealt(weighted, env, workers, timeout=1700):
+    """the -m gpu tests `weighted` = [(node id, seconds)] in `workers` concurrent pytest processes, dealt longest first to the least
+    loaded process; every process must pass"""
+    bins = [[0, []] for _ in range(max(1, workers))]
+    for node, w in sorted(weighted, key=lambda t: -t[1]):
+        b = min(bins, key=lambda x: x[0])
+        b[0] += w
+        b[1].append(node)
+    procs = [subprocess.Popen([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + b[1], cwd=ROOT, env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for b in bins if b[1]]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+            out += "\n[timed out]"
+        outs.append((p.returncode, out))
+    for rc, out in outs:
+        assert rc == 0 and " passed" in out and "failed" not in out, out[-3000:]
+    return outs
 
 
 CONCURRENT = [
@@ -118,15 +145,7 @@ def test_gpu_parity_tests_pass_on_the_wavefront_emulator():
     lib = build_emulated_library()
     env = dict(os.environ)
     env.update(FUIF_AMD_LIB=lib, FUIF_TEST_MAX_PIXELS="50000", FUIF_TEST_BATCH="12", EMU_ALARM="1500")
-    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + SELECTED
-    try:
-        import xdist  # noqa: F401
-        cmd += ["-n", str(max(1, min(6, (os.cpu_count() or 2) - 2)))]
-    except ImportError:
-        pass
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1700)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
+    run_dealt(SELECTED, env, max(1, min(7, (os.cpu_count() or 2) - 1)))
 
 
 def test_node_by_node_walk_beyond_the_supernode_cap():
@@ -137,16 +156,9 @@ def test_node_by_node_walk_beyond_the_supernode_cap():
     lib = build_emulated_library(extra=["-DFUIF_MAX_SUPER=3"], name="libfuifgpu_emu_cap3.so")
     env = dict(os.environ)
     env.update(FUIF_AMD_LIB=lib, FUIF_TEST_MAX_PIXELS="12000", EMU_ALARM="1500")
-    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
-           "tests/test_gpu_synthetic.py::test_deep_trees_walk_through_chained_supernodes", "tests/test_gpu_parity.py::test_golden_fixtures_bit_exact"]
-    try:
-        import xdist  # noqa: F401
-        cmd += ["-n", "5"]
-    except ImportError:
-        pass
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1700)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
+    run_dealt([("tests/test_gpu_synthetic.py::test_deep_trees_walk_through_chained_supernodes[False]", 55),
+               ("tests/test_gpu_synthetic.py::test_deep_trees_walk_through_chained_supernodes[True]", 40)] +
+              [("tests/test_gpu_parity.py::test_golden_fixtures_bit_exact[%d]" % k, 7) for k in range(8)], env, 4)
 
 
 def test_reference_cli_through_the_boundary_writes_the_reference_files(tmp_path):
