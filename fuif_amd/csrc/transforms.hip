@@ -731,103 +731,6 @@ DEV void idct_1d(const double (&in)[8], double (&out)[8]) {
         out[o] = acc;
     }
 }
-#ifndef FUIF_IDCT_BARRIER
-#define FUIF_IDCT_BARRIER 0
-#endif
-#ifndef FUIF_IDCT_PAIR
-#define FUIF_IDCT_PAIR 0
-#endif
-// Two lanes per block (FUIF_IDCT_PAIR): lane `half` runs the column pass of columns 4*half .. 4*half+3 and the row pass of rows 4*half .. 4*half+3;
-// between the passes each lane hands its partner the 16 column-pass values of the partner's rows (adjacent lanes: one DPP quad_perm move per
-// 32-bit half).  32 instead of 64 live doubles per lane.  Every output is the same sum in the same order as in the one-lane kernel.
-DEV int uniform_int(int v) {
-#ifdef FUIF_EMU
-    return v;
-#else
-    return __builtin_amdgcn_readfirstlane(v);
-#endif
-}
-#ifdef FUIF_EMU
-typedef const int32_t *global_i32_ptr;
-#else
-typedef const __attribute__((address_space(1))) int32_t *global_i32_ptr;   // (a pointer rebuilt from two SGPRs has lost its address space: say it again, or the loads become flat loads)
-#endif
-DEV global_i32_ptr uniform_ptr(const int32_t *p) {
-    uint64_t a = reinterpret_cast<uint64_t>(p);
-    a = (uint64_t)(uint32_t)uniform_int((int)(uint32_t)a) | ((uint64_t)(uint32_t)uniform_int((int)(a >> 32)) << 32);
-    return (global_i32_ptr)a;
-}
-DEV int swap_with_neighbour(int v) {
-#ifdef FUIF_EMU
-    return __builtin_amdgcn_ds_bpermute((int)(threadIdx.x ^ 1u) << 2, v);
-#else
-    return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);   // quad_perm:[1,0,3,2]
-#endif
-}
-DEV double swap_with_neighbour(double v) {
-    int32_t w[2];
-    __builtin_memcpy(w, &v, 8);
-    w[0] = swap_with_neighbour(w[0]);
-    w[1] = swap_with_neighbour(w[1]);
-    __builtin_memcpy(&v, w, 8);
-    return v;
-}
-#if !defined(FUIF_EMU) && defined(FUIF_IDCT_WAVES)
-#define IDCT_PAIR_OCCUPANCY __attribute__((amdgpu_waves_per_eu(FUIF_IDCT_WAVES)))
-#else
-#define IDCT_PAIR_OCCUPANCY
-#endif
-__global__ __launch_bounds__(64) IDCT_PAIR_OCCUPANCY void k_idct8x8_pair(Bases b, const PlaneRef *list, PlaneRef po, int bw, int bh, int maxval, int clamp, int lo, int hi) {
-    const int half = threadIdx.x & 1;
-    const int bx = blockIdx.x * 32 + ((int)threadIdx.x >> 1);
-    const int by = blockIdx.y;
-    if (bx >= bw || by >= bh) return;      // (both lanes of a pair leave together)
-    const float dcoff = (float)(((double)maxval + 1.0) * 4.0);
-    double t[4][8];   // t[k][o]: column pass of column 4*half + k, output row o
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        double col[8], res[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            // both halves' plane descriptors as scalars (readfirstlane keeps the compiler from folding the two loads into one per-lane
-            // load of list[.. + 4*half ..]); the lane picks its half's plane
-            const global_i32_ptr sa = uniform_ptr(plane_ptr(b, list[u * 8 + k], blockIdx.z)), sb = uniform_ptr(plane_ptr(b, list[u * 8 + 4 + k], blockIdx.z));
-            const int wa = uniform_int(list[u * 8 + k].w), wb = uniform_int(list[u * 8 + 4 + k].w);
-            const int v = (half ? sb : sa)[(int64_t)by * (half ? wb : wa) + bx];
-            col[u] = (u == 0 && k == 0 && half == 0) ? (double)__fadd_rn((float)v, dcoff) : (double)v;
-        }
-        idct_1d(col, res);
-#pragma unroll
-        for (int o = 0; o < 8; o++) t[k][o] = res[o];
-#if !defined(FUIF_EMU) && FUIF_IDCT_BARRIER > 0
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-    }
-    int32_t *o = plane_ptr(b, po, blockIdx.z) + (int64_t)(by * 8) * po.w + bx * 8;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        // row y = 4*half + r of the block: column-pass outputs o = y of all eight columns, in column order
-        double row[8], res[8];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const double mine = half ? t[k][4 + r] : t[k][r];          // my column 4*half + k at my row
-            const double send = half ? t[k][r] : t[k][4 + r];          // my column at row r of the PARTNER's half
-            const double got = swap_with_neighbour(send);              // the partner's column 4*(1-half) + k at my row
-            row[k] = half ? got : mine;
-            row[4 + k] = half ? mine : got;
-        }
-        idct_1d(row, res);
-        int outv[8];
-#pragma unroll
-        for (int oo = 0; oo < 8; oo++) {
-            const int v = (int)round(res[oo]);
-            outv[oo] = clamp ? clampi(v, lo, hi) : v;
-        }
-        int4 *dst = reinterpret_cast<int4 *>(o + (int64_t)(4 * half + r) * po.w);
-        dst[0] = make_int4(outv[0], outv[1], outv[2], outv[3]);
-        dst[1] = make_int4(outv[4], outv[5], outv[6], outv[7]);
-    }
-}
 __global__ __launch_bounds__(64) void k_idct8x8(Bases b, const PlaneRef *list, PlaneRef po, int bw, int bh, int maxval, int clamp, int lo, int hi) {
     const int bx = blockIdx.x * blockDim.x + threadIdx.x;
     const int by = blockIdx.y;
@@ -846,8 +749,10 @@ __global__ __launch_bounds__(64) void k_idct8x8(Bases b, const PlaneRef *list, P
         idct_1d(col, res);
 #pragma unroll
         for (int o = 0; o < 8; o++) tmp[o * 8 + x] = res[o];
-#if !defined(FUIF_EMU) && FUIF_IDCT_BARRIER > 0
-        if ((x + 1) % FUIF_IDCT_BARRIER == 0) __builtin_amdgcn_sched_barrier(0);   // FUIF_IDCT_BARRIER columns' plane descriptors at a time: hoisted together, the 64 scalar loads spill 88 SGPRs
+#ifndef FUIF_EMU
+        // one column's plane descriptors at a time: with all 64 scalar descriptor loads hoisted to the top the kernel spilled 88 SGPRs; the
+        // barrier costs nothing (profiles/r4_idct_variants.txt: 0.554 ms with and without on a 1920 x 2160-block component)
+        __builtin_amdgcn_sched_barrier(0);
 #endif
     }
     int32_t *o = plane_ptr(b, po, blockIdx.z) + (int64_t)(by * 8) * po.w + bx * 8;
@@ -1089,13 +994,8 @@ void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMe
             break;
         }
         case OP_IDCT:
-#if FUIF_IDCT_PAIR
-            hipLaunchKernelGGL(k_idct8x8_pair, dim3((op.p0 + 31) / 32, op.p1, n_images), dim3(64), 0, stream, b, dev_list + op.idct_first, op.dst[0],
-                               op.p0, op.p1, op.hi, op.clamp_out, op.lo, op.hi);
-#else
             hipLaunchKernelGGL(k_idct8x8, dim3((op.p0 + 63) / 64, op.p1, n_images), dim3(64), 0, stream, b, dev_list + op.idct_first, op.dst[0],
                                op.p0, op.p1, op.hi, op.clamp_out, op.lo, op.hi);
-#endif
             break;
         case OP_UPSAMPLE:
             if (op.p0 == 2 && op.p1 == 2)
