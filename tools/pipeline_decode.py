@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""EXPERIMENT (prepared in round 4 for the first GPU session of round 5; not measured yet): cross-batch pipelining of the entropy launch.
+
+The 1024-picture launch is as long as its long channel groups (6.4-7 s); from t ~ 4.1 s on they are all that is left and HALF of every SIMD's
+wavefront slots are empty (profiles/r4_occupancy_profile_timeline.txt: 34.7 k of 44.2 k wavefront-slot-seconds are used).  A batch cannot be
+shorter than its long groups -- but the NEXT batch's launch, queued on a second HIP stream, can take the slots the retiring wavefronts of
+the current one give up (idle wavefronts leave once every tile of their launch has started).  Two batch objects (own coefficient slabs and
+context arenas: streaming batches, no output slab), launches alternating between them and their two streams; the second one starts
+`--stagger` seconds after the first, and from then on each starts when its predecessor on the same stream ends.
+
+  python tools/pipeline_decode.py [n_images] [--launches K] [--stagger S] [--distinct D] [--rounds R] [--size WxH] [--no-streams]
+
+Prints the wall time of K sequential launches and of K pipelined ones.  If the slots fill as hoped, a launch every ~5.7 s instead of
+7.2 s (+25 % Mpixels/s); what it costs is a second coefficient slab + context arena (~85 GB per 1024 x 4K batch).  ANALYSIS TOOLING."""
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import make_inputs  # noqa: E402
+import fuif_amd  # noqa: E402
+
+argv = sys.argv[1:]
+pos = [a for i, a in enumerate(argv) if not a.startswith("--") and (i == 0 or argv[i - 1] not in ("--launches", "--stagger", "--size", "--distinct", "--rounds"))]
+n = int(pos[0]) if pos else 1024
+
+
+def opt(name, default, cast):
+    return cast(argv[argv.index(name) + 1]) if name in argv else default
+
+
+K = opt("--launches", 4, int)
+stagger = opt("--stagger", 3.6, float)
+w, h = (int(x) for x in opt("--size", "3840x2160", str).split("x"))
+distinct = opt("--distinct", 8, int)
+rounds = opt("--rounds", 2, int)
+inputs = make_inputs(distinct, w, h, 3, 8, 1000, os.environ.get("FUIF_BENCH_CACHE", "/tmp/fuif_bench_cache"))
+blobs = [inputs[i % distinct][1] for i in range(n)]
+plan = fuif_amd.Plan(blobs[0])
+L = fuif_amd.lib()
+streams = [None, None]
+if "--no-streams" not in argv:
+    hip = C.CDLL("libamdhip64.so")          # (the runtime fuif_amd.lib() has loaded already)
+    for k in range(2):
+        s = C.c_void_p()
+        assert hip.hipStreamCreateWithFlags(C.byref(s), 1) == 0     # hipStreamNonBlocking
+        streams[k] = s
+cap = sum(len(b) for b in blobs) + 4096 * n
+batches = [fuif_amd.Batch(plan, n, cap, streaming=True) for _ in range(2)]
+for b, s in zip(batches, streams):
+    b.upload(blobs, stream=s)
+    b.sync(s)
+px = n * w * h
+
+
+def run(pipelined):
+    t0 = time.perf_counter()
+    for i in range(K):
+        b, s = batches[i % 2], streams[i % 2]
+        if pipelined and i == 1 and stagger > 0:
+            time.sleep(stagger)                # the second launch is queued while the first is in its busy phase
+        b.decode(s)                            # asynchronous: a launch waits for its predecessor on the same stream only
+        if not pipelined:
+            b.sync(s)
+    for b, s in zip(batches, streams):
+        b.sync(s)
+    dt = time.perf_counter() - t0
+    for b in batches:
+        st, _ = b.status()
+        assert not st.any(), st[st != 0][:8]
+    return dt
+
+
+for mode in (False, True) * rounds:
+    dt = run(mode)
+    print("%s: %d launches of %d x %dx%d in %.2f s -> %.2f s per launch, %.1f Mpixels/s (entropy only)" % (
+        "pipelined (two streams, stagger %.1f s)" % stagger if mode else "sequential", K, n, w, h, dt, dt / K, K * px / dt / 1e6), flush=True)
+print("last launches by their own events: %.0f / %.0f ms" % (batches[0].timing()[0], batches[1].timing()[0]))
