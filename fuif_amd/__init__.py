@@ -110,9 +110,19 @@ def _preload_hip_runtime():
     cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
     if os.path.exists(cand):
         try:
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            global _hip_runtime
+            _hip_runtime = C.CDLL(cand, mode=C.RTLD_GLOBAL)
         except OSError:
             pass
+
+
+_hip_runtime = None
+
+
+def hip_runtime():
+    """the HIP runtime this process uses (ctypes handle), for hosts that need a stream or an event of their own without importing torch"""
+    lib()
+    return _hip_runtime if _hip_runtime is not None else C.CDLL("libamdhip64.so")
 
 
 def lib():

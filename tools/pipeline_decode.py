@@ -42,7 +42,7 @@ plan = fuif_amd.Plan(blobs[0])
 L = fuif_amd.lib()
 streams = [None, None]
 if "--no-streams" not in argv:
-    hip = C.CDLL("libamdhip64.so")          # (the runtime fuif_amd.lib() has loaded already)
+    hip = fuif_amd.hip_runtime()            # (the runtime the library itself runs on: torch's bundled copy when torch is installed)
     for k in range(2):
         s = C.c_void_p()
         assert hip.hipStreamCreateWithFlags(C.byref(s), 1) == 0     # hipStreamNonBlocking
@@ -73,7 +73,7 @@ def run(pipelined):
     return dt
 
 
-for mode in (False, True) * rounds:
+for mode in ((True,) if "--only-pipelined" in argv else (False, True)) * rounds:
     dt = run(mode)
     print("%s: %d launches of %d x %dx%d in %.2f s -> %.2f s per launch, %.1f Mpixels/s (entropy only)" % (
         "pipelined (two streams, stagger %.1f s)" % stagger if mode else "sequential", K, n, w, h, dt, dt / K, K * px / dt / 1e6), flush=True)
