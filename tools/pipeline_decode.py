@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""EXPERIMENT (prepared in round 4 for the first GPU session of round 5; not measured yet): cross-batch pipelining of the entropy launch.
+"""EXPERIMENT (round 4, measured at 128 pictures with the round's last GPU seconds: profiles/r4_pipelined_launches.txt, two launches overlap without
+slowing each other; 1024 pictures = the first session of round 5): cross-batch pipelining of the entropy launch.
 
 The 1024-picture launch is as long as its long channel groups (6.4-7 s); from t ~ 4.1 s on they are all that is left and HALF of every SIMD's
 wavefront slots are empty (profiles/r4_occupancy_profile_timeline.txt: 34.7 k of 44.2 k wavefront-slot-seconds are used).  A batch cannot be
