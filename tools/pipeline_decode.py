@@ -9,7 +9,7 @@ the current one give up (idle wavefronts leave once every tile of their launch h
 context arenas: streaming batches, no output slab), launches alternating between them and their two streams; the second one starts
 `--stagger` seconds after the first, and from then on each starts when its predecessor on the same stream ends.
 
-  python tools/pipeline_decode.py [n_images] [--launches K] [--stagger S] [--distinct D] [--rounds R] [--size WxH] [--no-streams]
+  python tools/pipeline_decode.py [n_images] [--launches K] [--stagger S] [--distinct D] [--rounds R] [--size WxH] [--with-transforms] [--only-pipelined] [--no-streams]
 
 Prints the wall time of K sequential launches and of K pipelined ones.  If the slots fill as hoped, a launch every ~5.7 s instead of
 7.2 s (+25 % Mpixels/s); what it costs is a second coefficient slab + context arena (~85 GB per 1024 x 4K batch).  ANALYSIS TOOLING."""
@@ -54,6 +54,30 @@ for b, s in zip(batches, streams):
     b.upload(blobs, stream=s)
     b.sync(s)
 px = n * w * h
+# --with-transforms: every launch is followed, on its own stream, by the inverse transforms of its batch in slices into one slice-sized output
+# buffer per batch (fuifgpu_batch_undo_transforms_to) -- the whole step of bench.py, nothing waits on the host; the last slice is hashed at the end
+with_tr = "--with-transforms" in argv
+L.fuifgpu_dev_alloc.restype = C.c_void_p
+n_slice = max(1, min(n, (8 << 30) // (4 * max(plan.info.out_elems, 1))))
+outs = [L.fuifgpu_dev_alloc(C.c_size_t(n_slice * plan.info.out_elems * 4)) for _ in range(2)] if with_tr else [None, None]
+assert not with_tr or all(outs), "device allocation failed"
+
+
+def transforms(b, s, out):
+    for s0 in range(0, n, n_slice):
+        b.undo_transforms_to(s0, min(n_slice, n - s0), out, s)
+
+
+def last_slice_hash():
+    import hashlib
+    import numpy as np
+    hs = []
+    for out in outs:
+        buf = np.zeros(min(n_slice * plan.info.out_elems, 4 << 20), np.int32)
+        L.fuifgpu_dev_download(buf.ctypes.data_as(C.c_void_p), C.c_void_p(out), C.c_size_t(buf.size * 4))
+        hs.append(hashlib.sha256(buf.tobytes()).hexdigest()[:12])
+    return hs
+
 
 
 def run(pipelined):
@@ -63,6 +87,8 @@ def run(pipelined):
         if pipelined and i == 1 and stagger > 0:
             time.sleep(stagger)                # the second launch is queued while the first is in its busy phase
         b.decode(s)                            # asynchronous: a launch waits for its predecessor on the same stream only
+        if with_tr:
+            transforms(b, s, outs[i % 2])
         if not pipelined:
             b.sync(s)
     for b, s in zip(batches, streams):
@@ -76,6 +102,7 @@ def run(pipelined):
 
 for mode in ((True,) if "--only-pipelined" in argv else (False, True)) * rounds:
     dt = run(mode)
-    print("%s: %d launches of %d x %dx%d in %.2f s -> %.2f s per launch, %.1f Mpixels/s (entropy only)" % (
-        "pipelined (two streams, stagger %.1f s)" % stagger if mode else "sequential", K, n, w, h, dt, dt / K, K * px / dt / 1e6), flush=True)
+    print("%s: %d launches of %d x %dx%d in %.2f s -> %.2f s per launch, %.1f Mpixels/s (%s)" % (
+        "pipelined (two streams, stagger %.1f s)" % stagger if mode else "sequential", K, n, w, h, dt, dt / K, K * px / dt / 1e6,
+        "entropy + inverse transforms; last output slices %s" % "/".join(last_slice_hash()) if with_tr else "entropy only"), flush=True)
 print("last launches by their own events: %.0f / %.0f ms" % (batches[0].timing()[0], batches[1].timing()[0]))
