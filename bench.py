@@ -473,6 +473,106 @@ def run_streamed(args, wl, inputs, blobs, dev, dist, rank, world, W, H, C, BITS,
         raise SystemExit("PARITY FAILURE: decoded planes differ from the source pixels")
 
 
+def run_pipelined(args, wl, inputs, blobs, dev, dist, rank, world, W, H, C, BITS, K, t_gen):
+    """--pipeline (EXPERIMENTAL, default off; measured so far only by tools/pipeline_decode.py, profiles/r4_pipelined_launches.txt).
+    A launch is as long as its long channel groups, and for its last 45 % they are all that runs: half of every SIMD's wavefront slots are
+    empty.  Two streaming batch objects (each with its own coefficient slab and context arena; no output slab) on two HIP streams take the
+    steps in turn: step i's entropy launch is queued behind step i-2 on its own stream and runs beside step i-1 on the other one.  A step =
+    one entropy launch over all `--batch` streams + their inverse transforms in slices into a slice-sized output tensor
+    (fuifgpu_batch_undo_transforms_to), exactly the work of the resident path; nothing in the timed region waits on the host."""
+    import torch
+    import fuif_amd
+    from fuif_amd import dist as fd
+    from fuif_amd.synth import photographic
+    n = args.batch
+    plan = fuif_amd.Plan(blobs[0])
+    info = plan.info
+    n_slice = args.slice if args.slice > 0 else int(max(1, min(n, (8 << 30) // (4 * max(info.out_elems, 1)))))
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    outs = [torch.empty(n_slice * info.out_elems, dtype=torch.int32, device=dev) for _ in range(2)]
+    cap = sum(len(b) for b in blobs) + 4096 * n
+    batches = [fuif_amd.Batch(plan, n, cap, streaming=True) for _ in range(2)]
+    for b, st in zip(batches, streams):
+        b.set_group_parallel(not args.no_index)
+        b.upload(blobs, stream=st.cuda_stream)
+        b.sync(st.cuda_stream)
+    chans = plan.output_channels
+    srcs = None
+    if wl["lossless"]:
+        srcs = [torch.from_numpy(photographic(W, H, C, BITS, seed=inputs[k][0])).to(dev) for k in range(K)]
+    bad = torch.zeros(1, dtype=torch.int64, device=dev)      # images that differ from their source picture (accumulated on the device: no host wait)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def enqueue(i, check):
+        b, st, out = batches[i % 2], streams[i % 2], outs[i % 2]
+        b.decode(st.cuda_stream)
+        view = out.view(n_slice, info.out_elems)
+        for s0 in range(0, n, n_slice):
+            cnt = min(n_slice, n - s0)
+            b.undo_transforms_to(s0, cnt, out.data_ptr(), st.cuda_stream)
+            if check and srcs is not None:
+                with torch.cuda.stream(st):
+                    for k in range(cnt):
+                        for c, oc in enumerate(chans):
+                            got = view[k, oc["offset"]: oc["offset"] + oc["w"] * oc["h"]].view(oc["h"], oc["w"])
+                            bad.add_((got != srcs[(s0 + k) % K][c]).any().to(torch.int64))
+
+    def run(steps, check):
+        for i in range(steps):
+            if i == 1 and args.pipeline_stagger > 0:
+                time.sleep(args.pipeline_stagger)
+            enqueue(i, check)
+        for b, st in zip(batches, streams):
+            b.sync(st.cuda_stream)
+
+    torch.cuda.synchronize()                # (the source pictures were uploaded on the default stream)
+    run(max(args.warmup, 1), True)          # (at least one checked pass: every image of it against the generator's pixels)
+    fence()
+    ok = int(bad.item()) == 0
+    for b in batches[: max(args.warmup, 1)]:
+        st_words, _ = b.status()
+        ok = ok and not st_words.any()
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps, False)
+    fence()
+    elapsed = fd.max_over_ranks(time.perf_counter() - t0, dist, dev)
+    ok = fd.all_ok(ok, dist, dev)
+    if rank == 0:
+        S = sum(len(b) for b in blobs) / n
+        alg = n * (S + 2.0 * info.coef_elems)
+        launches = [b.timing() for b in batches[: min(2, args.steps)]]      # (the last launch of each batch object, by its own events)
+        d_avg = float(np.mean([t[0] for t in launches])) / 1e3
+        value = world * n * W * H * args.steps / 1e6 / elapsed
+        res = {"metric": "Mpixels/s decode (4K Squeeze+YCoCg)" if args.workload == "c2" else "Mpixels/s decode (%s)" % args.workload, "value": round(value, 3),
+               "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+               "config": {"workload": wl["desc"] % (n, W, H), "images_per_gpu": n, "distinct_images": K, "bytes_per_stream": int(S), "channels": C, "bits": BITS,
+                          "parity_roundtrip_ok": ok, "parity_check": "decoded == source pixels for every image of one full pass" if wl["lossless"] else "status only",
+                          "pipelined": "two streaming batch objects on two HIP streams take the steps in turn; a step = one entropy launch over all %d streams + its inverse "
+                                       "transforms in slices of %d images; consecutive steps overlap on the device (second step queued %.1f s after the first)" % (
+                                           n, n_slice, args.pipeline_stagger), "input_gen_s": round(t_gen, 1)},
+               "roofline": {"bound": "hbm", "kernel": "k_maniac_decode", "achieved": round(alg / d_avg / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(alg / d_avg / 1e9 / HBM_PEAK_GBS, 6), "traffic": None, "kernel_ms": round(d_avg * 1e3, 3),
+                            "algorithmic_bytes_per_launch": int(alg),
+                            "note": "kernel_ms = a launch's own duration by its HIP events while it shares the device with its neighbour steps: longer than a launch alone, "
+                                    "shorter than ms_per_step x 2"}}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline([b for _, b in inputs], W, H, source=(inputs[0][0], C, BITS) if wl["lossless"] else None)
+            res["speedup_vs_cpu_1thread"] = round(value / res["cpu_baseline"]["value"], 2)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("bench.py --pipeline: a decoded image differs from its source picture, or an image was flagged")
+
+
 def pmc_child(args):
     """what live_pmc_traffic() runs under `rocprofv3 --pmc <one counter>`: the headline launch once, nothing else (inputs from the
     parent's cache, no checks, no CPU legs).  Prints the launch's HIP-event time."""
@@ -609,6 +709,11 @@ def main():
                     help="images resident at a time (0 = the whole batch, -1 = as many as the device holds): the batch is streamed through ONE chunk-sized set of coefficient / "
                          "output slabs, chunk after chunk -- how C4 (256 x 8192x8192x4: 275 GB of coefficients alone) runs on one GPU")
     ap.add_argument("--slice", type=int, default=0, help="with --chunk: images per inverse-transform slice (0 = what fits 16 GiB of int32 outputs)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="EXPERIMENTAL (round 4, default off; DESIGN.md 8 item 0): consecutive steps overlap on the device -- two streaming batch objects (own coefficient "
+                         "slabs and context arenas) on two HIP streams take the steps in turn, so that a step's entropy launch fills the wavefront slots the previous "
+                         "step leaves empty while only its long channel groups run; every step still decodes all its streams in its own launch")
+    ap.add_argument("--pipeline-stagger", type=float, default=0.0, help="with --pipeline: seconds the host waits before it queues the second step (0 = both at once)")
     ap.add_argument("--cache", default=os.environ.get("FUIF_BENCH_CACHE", "/tmp/fuif_bench_cache"))
     ap.add_argument("--no-rccl-selfcheck", action="store_true",
                     help="one GPU: do not start the one-rank RCCL process group that runs the N>1 collectives on cuda:0 (outside the timed region except for the fence's barrier)")
@@ -682,6 +787,8 @@ def main():
         per_image = 2 * pinfo.coef_elems + max(len(b) for _, b in inputs) + (32 << 20)   # int16 coefficients; the outputs go through one 16 GiB slice
         free_b, _ = torch.cuda.mem_get_info(dev)
         args.chunk = int(max(1, min(args.batch, (free_b - (45 << 30) - (16 << 30) - (12 << 30)) // per_image)))
+    if args.pipeline:
+        return run_pipelined(args, wl, inputs, blobs, dev, dist, rank, world, W, H, C, BITS, K, t_gen)
     if args.chunk:   # (also when one chunk holds the whole batch: the OUTPUTS of such a batch still only fit slice by slice)
         args.chunk = min(args.chunk, args.batch)
         return run_streamed(args, wl, inputs, blobs, dev, dist, rank, world, W, H, C, BITS, K, t_gen)

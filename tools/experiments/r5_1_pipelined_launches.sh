@@ -11,3 +11,6 @@ mkdir -p $OUT
 timeout 300 python tools/pipeline_decode.py 1024 --launches 4 --stagger 3.6 --rounds 1 2>&1 | grep -v amdgpu | tee $OUT/entropy_stagger.txt
 timeout 300 python tools/pipeline_decode.py 1024 --launches 4 --stagger 0 --rounds 1 --only-pipelined 2>&1 | grep -v amdgpu | tee $OUT/entropy_at_once.txt
 timeout 300 python tools/pipeline_decode.py 1024 --launches 4 --stagger 3.6 --rounds 1 --with-transforms 2>&1 | grep -v amdgpu | tee $OUT/with_transforms.txt
+# the same through bench.py (opt-in mode written blind in round 4: first run = first test): every image of the warm-up pass is compared with its source picture
+(time timeout 600 python bench.py --pipeline --steps 4 --warmup 2 --no-cpu-baseline) > $OUT/bench_pipeline.json 2> $OUT/bench_pipeline.err; tail -c 1500 $OUT/bench_pipeline.json; tail -n 5 $OUT/bench_pipeline.err
+(time timeout 600 python bench.py --pipeline --pipeline-stagger 3.6 --steps 4 --warmup 2 --no-cpu-baseline) > $OUT/bench_pipeline_stagger.json 2> $OUT/bench_pipeline_stagger.err; tail -c 600 $OUT/bench_pipeline_stagger.json
