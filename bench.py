@@ -547,7 +547,7 @@ def run_pipelined(args, wl, inputs, blobs, dev, dist, rank, world, W, H, C, BITS
         S = sum(len(b) for b in blobs) / n
         alg = n * (S + 2.0 * info.coef_elems)
         launches = [b.timing() for b in batches[: min(2, args.steps)]]      # (the last launch of each batch object, by its own events)
-        d_avg = float(np.mean([t[0] for t in launches])) / 1e3
+        d_avg = max(float(np.mean([t[0] for t in launches])) / 1e3, 1e-9)
         value = world * n * W * H * args.steps / 1e6 / elapsed
         res = {"metric": "Mpixels/s decode (4K Squeeze+YCoCg)" if args.workload == "c2" else "Mpixels/s decode (%s)" % args.workload, "value": round(value, 3),
                "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
