@@ -14,3 +14,9 @@ timeout 300 python tools/pipeline_decode.py 1024 --launches 4 --stagger 3.6 --ro
 # the same through bench.py (opt-in mode written blind in round 4: first run = first test): every image of the warm-up pass is compared with its source picture
 (time timeout 600 python bench.py --pipeline --steps 4 --warmup 2 --no-cpu-baseline) > $OUT/bench_pipeline.json 2> $OUT/bench_pipeline.err; tail -c 1500 $OUT/bench_pipeline.json; tail -n 5 $OUT/bench_pipeline.err
 (time timeout 600 python bench.py --pipeline --pipeline-stagger 3.6 --steps 4 --warmup 2 --no-cpu-baseline) > $OUT/bench_pipeline_stagger.json 2> $OUT/bench_pipeline_stagger.err; tail -c 600 $OUT/bench_pipeline_stagger.json
+# files WITHOUT the group index (one wavefront per picture): two launches side by side need two wide wavefronts per SIMD = fewer LDS supernodes per wavefront
+# (build first, in the build container: tools/build_variant.sh wide20 -DFUIF_LDS_WIDE=20 ; the product keeps 58)
+timeout 400 python tools/pipeline_decode.py 1024 --no-index --launches 2 --stagger 0 --rounds 1 2>&1 | grep -v amdgpu | tee $OUT/noindex_product.txt
+if [ -f build/libfuifgpu_wide20.so ]; then
+  FUIF_AMD_LIB=$ROOT/build/libfuifgpu_wide20.so timeout 400 python tools/pipeline_decode.py 1024 --no-index --launches 2 --stagger 0 --rounds 1 2>&1 | grep -v amdgpu | tee $OUT/noindex_wide20.txt
+fi

@@ -9,7 +9,11 @@ the current one give up (idle wavefronts leave once every tile of their launch h
 context arenas: streaming batches, no output slab), launches alternating between them and their two streams; the second one starts
 `--stagger` seconds after the first, and from then on each starts when its predecessor on the same stream ends.
 
-  python tools/pipeline_decode.py [n_images] [--launches K] [--stagger S] [--distinct D] [--rounds R] [--size WxH] [--with-transforms] [--only-pipelined] [--no-streams]
+  python tools/pipeline_decode.py [n_images] [--launches K] [--stagger S] [--distinct D] [--rounds R] [--size WxH] [--with-transforms] [--only-pipelined] [--no-index] [--no-streams]
+
+--no-index: one wavefront per picture.  There a launch fills one wavefront slot per SIMD for its whole length (29 KB of LDS supernodes per wavefront:
+one fits a SIMD's share); two launches can only run side by side in a build with fewer LDS supernodes (tools/build_variant.sh wide20 -DFUIF_LDS_WIDE=20:
+two wavefronts per SIMD) -- if a lone wavefront's chain is latency-bound, as profiles/r4_small_batch_profile.txt says, that is up to 2x for such files.
 
 Prints the wall time of K sequential launches and of K pipelined ones.  If the slots fill as hoped, a launch every ~5.7 s instead of
 7.2 s (+25 % Mpixels/s); what it costs is a second coefficient slab + context arena (~85 GB per 1024 x 4K batch).  ANALYSIS TOOLING."""
@@ -51,6 +55,8 @@ if "--no-streams" not in argv:
 cap = sum(len(b) for b in blobs) + 4096 * n
 batches = [fuif_amd.Batch(plan, n, cap, streaming=True) for _ in range(2)]
 for b, s in zip(batches, streams):
+    if "--no-index" in argv:
+        b.set_group_parallel(False)        # files as the reference CLI writes them: one wavefront per picture (the wide configuration, one per SIMD)
     b.upload(blobs, stream=s)
     b.sync(s)
 px = n * w * h
