@@ -20,3 +20,8 @@ timeout 400 python tools/pipeline_decode.py 1024 --no-index --launches 2 --stagg
 if [ -f build/libfuifgpu_wide20.so ]; then
   FUIF_AMD_LIB=$ROOT/build/libfuifgpu_wide20.so timeout 400 python tools/pipeline_decode.py 1024 --no-index --launches 2 --stagger 0 --rounds 1 2>&1 | grep -v amdgpu | tee $OUT/noindex_wide20.txt
 fi
+# Under overlapped launches the limit is wavefront-slot-seconds of WORK, not the long groups' critical path: 7 wavefronts per SIMD (72 VGPRs, 43 spilled; "no
+# difference" for a launch alone in round 4) may pay now (build first: tools/build_variant.sh w7 -DFUIF_WAVES=7)
+if [ -f build/libfuifgpu_w7.so ]; then
+  FUIF_AMD_LIB=$ROOT/build/libfuifgpu_w7.so timeout 300 python tools/pipeline_decode.py 1024 --launches 4 --stagger 3.6 --rounds 1 --only-pipelined 2>&1 | grep -v amdgpu | tee $OUT/entropy_w7.txt
+fi
