@@ -954,6 +954,7 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
         return corrupt_or_truncated(io, &img->ch[beginc], btl);
     }
 
+    if (tree.size > img->stat_max_tree_nodes) img->stat_max_tree_nodes = tree.size;
     /* FinalPropertySymbolCoder ctor: compound.h:213-225 */
     int nleaves = (tree.size + 1) / 2;
     uint16_t *leaves = (uint16_t *)malloc(sizeof(uint16_t) * CH_N * nleaves);
@@ -1782,6 +1783,7 @@ int fo_groups(fo_image *img, int32_t *first_channel, uint32_t *start, int cap) {
     for (int g = 0; g < img->ngroups && g < cap; g++) { first_channel[g] = img->group_channel[g]; start[g] = img->group_start[g]; }
     return img->ngroups;
 }
+int fo_max_tree_nodes(fo_image *img) { return img->stat_max_tree_nodes; }
 void fo_stats(fo_image *img, uint64_t *out) {
     out[0] = img->stat_symbols; out[1] = img->stat_rac_decisions; out[2] = img->stat_tree_steps; out[3] = img->bytes_consumed;
 }

@@ -44,6 +44,7 @@ typedef struct {
     int error;
     /* statistics (not in the reference): */
     uint64_t stat_symbols, stat_rac_decisions, stat_tree_steps;
+    int stat_max_tree_nodes;            /* largest MANIAC tree of any channel group (nodes) */
     size_t bytes_consumed;
     /* byte offset / first channel of every channel group, in stream order (test aid for the group index) */
     uint32_t *group_start; int32_t *group_channel; int ngroups, groups_cap;
@@ -60,6 +61,7 @@ void fo_channel_info(fo_image *img, int c, int32_t *out12);
 void fo_channel_data(fo_image *img, int c, int32_t *out);
 void fo_transform_info(fo_image *img, int t, int32_t *out, int cap);
 void fo_stats(fo_image *img, uint64_t *out4);
+int fo_max_tree_nodes(fo_image *img);
 int fo_groups(fo_image *img, int32_t *first_channel, uint32_t *start, int cap);
 
 /* known-answer helpers for unit tests */

@@ -92,7 +92,8 @@ class _Lib:
             if isinstance(self, Port):
                 st = np.zeros(4, np.uint64)
                 self.lib.fo_stats(C.c_void_p(h), st.ctypes.data)
-                d.stats = dict(symbols=int(st[0]), rac_decisions=int(st[1]), tree_steps=int(st[2]), bytes=int(st[3]))
+                d.stats = dict(symbols=int(st[0]), rac_decisions=int(st[1]), tree_steps=int(st[2]), bytes=int(st[3]),
+                               max_tree_nodes=int(self.lib.fo_max_tree_nodes(C.c_void_p(h))))
                 gc, gs = np.zeros(4096, np.int32), np.zeros(4096, np.uint32)
                 ng = self.lib.fo_groups(C.c_void_p(h), gc.ctypes.data, gs.ctypes.data, 4096)
                 d.groups = [(int(gc[i]), int(gs[i])) for i in range(min(ng, 4096))]

@@ -63,6 +63,10 @@ SPECS = [
     # no Squeeze: the planes are the Image constructor's (already hold w*h zeros), and the channel range excludes 0 --
     # the rows a truncated stream never reaches stay 0, not Channel::zero (encoding.cpp:368, image.h:64-65,73-75)
     ("gray8_nosqueeze_60x40", dict(w=60, h=40, channels=1, bits=8, seed=14), ["-R", "0"]),
+    # round 5: context trees far beyond anything the product's own writer makes (its cap is 4095 nodes): -I 16 = sixteen tree-learning
+    # passes (fuif.cpp:110, encoding.cpp:455-573) give the largest group a tree of 19 327 nodes (compound.h:277-320 allows 65 535), i.e. more
+    # supernodes than a wavefront's scratch area holds (the node-by-node walk behind kSlowFlag) and 9 664 leaves
+    ("rgb8_512x384_I16_bigtrees", dict(w=512, h=384, channels=3, bits=8, seed=78), ["-I", "16"]),
 ]
 # screen content / sparse histograms with DEFAULT CLI flags: the reference picks Palette (transform/palette.h)
 # by itself (fuif.cpp:399-427); -A k,q adds Approximate (transform/approximate.h) on the last k channels
@@ -125,7 +129,7 @@ SOFTMATCH_SPECS = [
 PREVIEWS = {"softmatch_rgb_graphic_96x80_q3": [2], "c1_rgb8_512x512": [0, 1, 2, 3, 4], "rgb8_97x61": [0, 2, 4], "jpeg420_256x192_q90": [0, 1, 2, 3, 4],
             "pal_rgb_graphic_120x90": [1, 3], "approx_rgb8_96x80_A3": [2], "approx_quant_rgb8_40x30": [3], "match_rgb_graphic_96x80": [3]}
 TRUNCATE_EXTRA = {"softmatch_rgb_graphic_nosqueeze_72x60": [0.7], "softmatch_anim4_40x28_q2": [0.6], "approx_on_palette_gray12_24x50": [0.8], "match_rgb_graphic_96x80": [0.6]}
-TRUNCATE = {"permute_channel_rgb8_48x40": [0.5], "permute_explicit_rgb8_48x40": [0.6], "rgb8_97x61": [0.2, 0.55, 0.93], "rgb8_128x128_I0": [0.5], "rgb8_112x96_E18": [0.7], "rgb8_120x88_E50": [0.6], "jpeg420_256x192_q90": [0.4], "rgb8_64x64_U": [0.6],
+TRUNCATE = {"rgb8_512x384_I16_bigtrees": [0.8], "permute_channel_rgb8_48x40": [0.5], "permute_explicit_rgb8_48x40": [0.6], "rgb8_97x61": [0.2, 0.55, 0.93], "rgb8_128x128_I0": [0.5], "rgb8_112x96_E18": [0.7], "rgb8_120x88_E50": [0.6], "jpeg420_256x192_q90": [0.4], "rgb8_64x64_U": [0.6],
             "pal_rgba_graphic_72x64": [0.5], "pal_rgb_sparse_128x96": [0.7],
             "gray8_nosqueeze_60x40": [0.6], "rgb8_96x96_nosqueeze": [0.45]}
 
