@@ -54,6 +54,22 @@ def build(force=False, verbose=False):
     return _LIB_PATH
 
 
+def build_unit_test(force=False):
+    """tests/_bin/test_fast_symbol: the hand-written symbol decoder (inline GCN asm, what ships) against fast_symbol, its C++
+    specification (what the wavefront emulator of the CPU suite runs), on the MI355X -- tools/test_fast_symbol.hip includes the
+    kernel source itself.  Built here (hipcc cross-compiles) so that the binary travels to the GPU box; tests/test_gpu_fast_symbol.py
+    builds it there when it is missing or older than the kernel."""
+    root = os.path.dirname(_HERE)
+    src = os.path.join(root, "tools", "test_fast_symbol.hip")
+    out = os.path.join(root, "tests", "_bin", "test_fast_symbol")
+    deps = [src] + [os.path.join(_HERE, "csrc", f) for f in ("maniac_decode.hip", "maniac_decode.h", "fuifgpu_internal.h")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.check_call(["hipcc"] + HIPCC_FLAGS + ["-I", os.path.join(_HERE, "csrc"), src, "-o", out])
+    return out
+
+
 class ImageInfo(C.Structure):
     _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("bit_depth", C.c_int32), ("maxval", C.c_int32),
                 ("nb_channels", C.c_int32), ("colormodel", C.c_int32), ("max_properties", C.c_int32),
@@ -161,6 +177,7 @@ def lib():
     L.fuifgpu_batch_out_ptr.argtypes = [vp, C.c_int]; L.fuifgpu_batch_out_ptr.restype = vp
     L.fuifgpu_batch_download_coef.argtypes = [vp, C.c_int, vp, vp]
     L.fuifgpu_batch_download_out.argtypes = [vp, C.c_int, vp, vp]
+    L.fuifgpu_plane_checksums.argtypes = [vp, C.c_int64, C.c_int64, C.c_int, vp, vp]
     L.fuifgpu_batch_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.fuifgpu_batch_profile.argtypes = [vp, vp]
     L.fuifgpu_batch_tile_log.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
@@ -263,7 +280,8 @@ class Batch:
 
     def sibling(self, blob_capacity):
         """a second set of stream buffers over this Batch's slabs, scratch and arenas (fuifgpu_batch_create_sibling): upload
-        into one while the other decodes.  Upload `self` once before the sibling's first upload; close the sibling first."""
+        into one while the other decodes.  Creating a sibling freezes the launch resources the two share (ABI 2), so either may be
+        loaded first; close the sibling before the primary."""
         other = Batch.__new__(Batch)
         other.plan, other.n, other._keep = self.plan, self.n, None
         other._h = C.c_void_p()
@@ -385,6 +403,13 @@ class Batch:
         return [slab[c["offset"]: c["offset"] + c["w"] * c["h"]].reshape(c["h"], c["w"]).copy() for c in self.plan.output_channels]
 
 
+def plane_checksums(planes_device_ptr, elems_per_image, n_images, sums_device_ptr, stream=None, image_stride=None):
+    """fuifgpu_plane_checksums: one position-weighted 64-bit sum per image of a device slab of int32 planes into DEVICE memory
+    (n_images x uint64), asynchronous on `stream`"""
+    _check(lib().fuifgpu_plane_checksums(planes_device_ptr, elems_per_image, elems_per_image if image_stride is None else image_stride,
+                                        n_images, sums_device_ptr, stream))
+
+
 def decode_batch(blobs, preview=-1, undo=True):
     """Decode same-geometry streams on the GPU; returns (list of per-image output planes, status)."""
     plan = Plan(blobs[0])
@@ -470,10 +495,18 @@ def add_group_index(blobs, hbm_budget_bytes=200 << 30):
     """Existing streams (as the reference encoder writes them) -> the same bytes + the group index trailer, in the caller's order:
     one entropy-decode launch per geometry (a streaming batch: no output slab, no inverse transforms), the group starts the kernel
     went through (fuifgpu_batch_group_index) appended with index_append.  A stream that already has a valid trailer, or whose decode
-    is flagged (truncated / corrupt: its group starts are not those of the whole file), comes back unchanged.  The Python form of
+    is flagged (truncated / corrupt: its group starts are not those of the whole file), or which the planner refuses (out of scope,
+    corrupt header), comes back unchanged.  The Python form of
     fuif_amd/boundary/fuif_index_main.cpp."""
     out = list(blobs)
-    todo = [i for i, b in enumerate(blobs) if not index_parse(b)]
+    todo = []
+    for i, b in enumerate(blobs):
+        try:
+            if not index_parse(b):
+                Plan(b)                     # a stream the planner refuses (out of scope, corrupt header) is copied through, like a flagged decode
+                todo.append(i)
+        except FuifGpuError:
+            pass
     for sig, (plan, idx) in group_by_signature([blobs[i] for i in todo]).items():
         idx = [todo[k] for k in idx]
         per = 2 * plan.info.coef_elems + 19 * (1 << 20) + max(len(blobs[i]) for i in idx)
@@ -481,7 +514,8 @@ def add_group_index(blobs, hbm_budget_bytes=200 << 30):
         for c0 in range(0, len(idx), chunk):
             part = idx[c0:c0 + chunk]
             sub = [blobs[i] for i in part]
-            batch = Batch(plan, len(sub), sum(len(b) for b in sub) + 4096 * len(sub), streaming=True)
+            # (tmp_images = 1: an entropy-only run needs no transform arena; the default would reserve one for a whole chunk of images)
+            batch = Batch(plan, len(sub), sum(len(b) for b in sub) + 4096 * len(sub), streaming=True, tmp_images=1)
             try:
                 batch.upload(sub)
                 batch.decode()

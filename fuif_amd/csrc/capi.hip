@@ -769,6 +769,14 @@ int fuifgpu_batch_download_packed(fuifgpu_batch *b, int image, int components, u
     return FUIFGPU_OK;
 }
 
+int fuifgpu_plane_checksums(const int32_t *planes_device, int64_t elems_per_image, int64_t image_stride, int n_images, uint64_t *sums_device, void *stream) {
+    if (!planes_device || !sums_device || elems_per_image < 0 || image_stride < elems_per_image || n_images < 1 || n_images > 65535 ||
+        ((uintptr_t)planes_device & 15) || (image_stride & 3)) return FUIFGPU_E_ARG;
+    launch_plane_checksums(planes_device, elems_per_image, image_stride, n_images, (unsigned long long *)sums_device, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return FUIFGPU_OK;
+}
+
 int fuifgpu_batch_last_timing(fuifgpu_batch *b, float *decode_ms, float *transform_ms) {
     if (!b) return FUIFGPU_E_ARG;
     if (decode_ms) {

@@ -29,6 +29,9 @@ struct PackedPlanes {
 void launch_pack(const Bases &b, const PackedPlanes &pp, int w, int h, int lo, int hi, int bytes_per_sample, uint8_t *dst, int64_t dst_stride,
                  int n_images, hipStream_t stream);
 
+// per-image position-weighted 64-bit sums of n_images runs of `elems` int32 samples, `stride` samples apart (sums[] is zeroed on the stream first)
+void launch_plane_checksums(const int32_t *planes, int64_t elems, int64_t stride, int n_images, unsigned long long *sums, hipStream_t stream);
+
 // forward YCoCg (in place, three contiguous planes of n samples) and forward Squeeze of one plane (transform/ycocg.h:65-95,
 // transform/squeeze.h:135-170,227-263): raw device pointers, the writer's optional GPU path
 void launch_scale(int32_t *plane, int64_t n, int q, hipStream_t stream);   // transform/quantize.h:32-49 on one plane

@@ -925,6 +925,46 @@ void launch_pack(const Bases &b, const PackedPlanes &pp, int w, int h, int lo, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// Verification aid (no counterpart in the reference): one position-weighted 64-bit sum per image over a slab of int32 planes,
+// sum_i v[i] * (i mod 65521 + 1) (two's-complement wrap-around) -- what fuif_amd.dist.plane_checksums computes with torch.  A host
+// that decodes step after step (bench.py's overlapped steps, a service that re-decodes) keeps 8 bytes per image and step instead of
+// the planes and compares afterwards; streaming, HBM bound (4 bytes per sample).  16-byte loads; blockIdx.y = image.
+__global__ __launch_bounds__(256) void k_plane_checksums(const int32_t *planes, int64_t elems, int64_t stride, unsigned long long *sums) {
+    const int32_t *src = planes + (int64_t)blockIdx.y * stride;
+    unsigned long long acc = 0;
+    const int64_t quads = elems / 4;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += step) {
+        const int4 v = *reinterpret_cast<const int4 *>(src + 4 * q);
+        const unsigned long long w0 = (unsigned long long)((4 * q) % 65521);      // weights w0+1 .. w0+4, each reduced mod 65521
+        const long long vs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            unsigned long long wk = w0 + (unsigned long long)k;
+            if (wk >= 65521ull) wk -= 65521ull;
+            acc += (unsigned long long)vs[k] * (wk + 1ull);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = quads * 4; i < elems; i++) acc += (unsigned long long)(long long)src[i] * ((unsigned long long)(i % 65521) + 1ull);
+    __shared__ unsigned long long part[256];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(&sums[blockIdx.y], part[0]);
+}
+void launch_plane_checksums(const int32_t *planes, int64_t elems, int64_t stride, int n_images, unsigned long long *sums, hipStream_t stream) {
+    if (n_images <= 0) return;
+    (void)hipMemsetAsync(sums, 0, sizeof(unsigned long long) * (size_t)n_images, stream);
+    if (elems <= 0) return;
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((elems / 4 + 2047) / 2048, 256));
+    hipLaunchKernelGGL(k_plane_checksums, dim3((unsigned)blocks, (unsigned)n_images), dim3(256), 0, stream, planes, elems, stride, sums);
+}
+
+// ---------------------------------------------------------------------------------------------
 static inline dim3 grid1d(int64_t n, int block, int z, int y = 1) {
     int64_t g = (n + block - 1) / block;
     if (g > 4096) g = 4096;

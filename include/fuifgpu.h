@@ -150,6 +150,13 @@ int fuifgpu_batch_pack_out(fuifgpu_batch *batch, int first_image, int n_images, 
 /* one image into HOST memory (packs into a temporary device buffer, copies, synchronises the stream) */
 int fuifgpu_batch_download_packed(fuifgpu_batch *batch, int image, int components, uint8_t *host, void *stream);
 
+/* Verification aid -- no counterpart in the reference (its tests compare files with `cmp`): sums_device[k] = sum over the
+ * elems_per_image int32 samples of image k (image_stride samples apart, a multiple of 4; planes_device 16-byte aligned) of
+ * sample * (index mod 65521 + 1), as a wrapping 64-bit integer; asynchronous on `stream`.  A host that decodes step after step into
+ * the same planes (bench.py's overlapped steps, fuifgpu_batch_undo_transforms_to slice by slice) keeps 8 bytes per image and step
+ * and compares them when the steps are done, instead of holding or downloading the planes of every step. */
+int fuifgpu_plane_checksums(const int32_t *planes_device, int64_t elems_per_image, int64_t image_stride, int n_images, uint64_t *sums_device, void *stream);
+
 /* kernel time of the last decode / undo_transforms launch set, measured with hipEvents on the
  * caller's stream (ms); used by bench.py for the roofline */
 int fuifgpu_batch_last_timing(fuifgpu_batch *batch, float *decode_ms, float *transform_ms);

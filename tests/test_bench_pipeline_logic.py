@@ -1,7 +1,8 @@
-"""bench.py --pipeline (the opt-in mode in which consecutive steps overlap on the device) needs a GPU for its streams; its
-LOGIC -- two streaming batch objects taking the steps in turn, inverse transforms in slices (ragged last slice), every image of the checked
-pass compared with its source picture on the device, the JSON line -- runs here on the wavefront emulator with torch.cuda's stream calls
-replaced by no-ops (the emulated library treats host memory as device memory)."""
+"""bench.py's timed region lets consecutive steps overlap on the device (overlapped_steps: two streaming batch objects on two HIP
+streams) and needs a GPU for its streams; its LOGIC -- the batch objects taking the steps in turn, inverse transforms
+in slices (ragged last slice), one checksum row per step (warm-up and timed), the comparison of every row with the resident path's
+outputs (verify_overlapped) and that a wrong picture anywhere is noticed -- runs here on the wavefront emulator with torch.cuda's
+stream calls replaced by no-ops (the emulated library treats host memory as device memory)."""
 import json
 import os
 import subprocess
@@ -12,10 +13,12 @@ import pytest
 from conftest import ROOT
 
 DRIVER = r'''
-import contextlib, os, sys, types
+import contextlib, json, os, sys, types
 sys.path.insert(0, %(root)r)
+import numpy as np
 import torch
 import bench
+import fuif_amd
 
 
 class FakeStream:
@@ -26,28 +29,38 @@ class FakeStream:
 torch.cuda.Stream = FakeStream
 torch.cuda.stream = lambda s: contextlib.nullcontext()
 torch.cuda.synchronize = lambda *a, **k: None
-args = types.SimpleNamespace(batch=3, slice=2, no_index=False, warmup=1, steps=2, pipeline_stagger=0.0, workload="c2", no_cpu_baseline=True)
+args = types.SimpleNamespace(batch=5, slice=2, warmup=1, steps=3, overlap_stagger=0.0)
 wl = bench.WORKLOADS["c2"]
 W, H, C, BITS, K = 97, 61, 3, 8, 2
 inputs = bench.make_inputs(K, W, H, C, BITS, 1000, %(cache)r, wl["kind"])
-if %(damage)d:
-    inputs[1] = (inputs[1][0] + 7, inputs[1][1])      # the wrong source picture for every second image: the check must notice
 blobs = [inputs[i %% K][1] for i in range(args.batch)]
-bench.run_pipelined(args, wl, inputs, blobs, torch.device("cpu"), None, 0, 1, W, H, C, BITS, K, 0.0)
+plan = fuif_amd.Plan(blobs[0])
+dev = torch.device("cpu")
+ov = bench.overlapped_steps(args, plan, blobs, dev, None, W, H)
+assert ov["sums"].shape == (4, 5) and ov["status_ok"] and ov["n_slice"] == 2
+# the resident path: one batch with an output slab, the same streams (damage: two of them swapped -> pictures 1 and 2 differ)
+resident = list(blobs)
+if %(damage)d:
+    resident[1], resident[2] = resident[2], resident[1]
+out = torch.zeros(args.batch * plan.info.out_elems, dtype=torch.int32)
+b = fuif_amd.Batch(plan, args.batch, sum(len(x) for x in resident), out_ptr=out.data_ptr())
+b.upload(resident); b.decode(); b.undo_transforms(); b.sync()
+ok, info = bench.verify_overlapped(ov, out.data_ptr(), plan.info.out_elems, args.batch, dev, 0.0)
+print(json.dumps({"ok": ok, "info": info}))
 '''
 
 
 @pytest.mark.parametrize("damage", [0, 1])
-def test_pipelined_steps_decode_and_verify_every_image(tmp_path, damage):
+def test_overlapped_steps_decode_and_verify_every_step(tmp_path, damage):
     if sys.platform != "linux" or os.uname().machine != "x86_64":
         pytest.skip("the emulator's context switch is x86-64 SysV assembly")
     from test_emulated_kernels import build_emulated_library
     env = dict(os.environ, FUIF_AMD_LIB=build_emulated_library(), EMU_ALARM="600")
     r = subprocess.run([sys.executable, "-c", DRIVER % dict(root=ROOT, cache=str(tmp_path / "cache"), damage=damage)], env=env, capture_output=True, text=True, timeout=900)
-    if damage:
-        assert r.returncode != 0 and "differs from its source picture" in r.stderr, r.stderr[-600:]
-        return
     assert r.returncode == 0, r.stderr[-1500:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["config"]["parity_roundtrip_ok"] is True and line["steps"] == 2 and line["n_gpus"] == 1
-    assert "pipelined" in line["config"] and line["roofline"]["bound"] == "hbm"
+    assert line["info"]["steps_verified"] == 4 and line["info"]["slice_images"] == 2
+    if damage:
+        assert line["ok"] is False and line["info"]["steps_identical_to_resident_outputs"] == 0
+    else:
+        assert line["ok"] is True and line["info"]["steps_identical_to_resident_outputs"] == 4

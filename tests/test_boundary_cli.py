@@ -23,7 +23,6 @@ def run_cli(args, fallback=False):
     # FUIFGPU_VERBOSE makes the path taken visible
     env["FUIFGPU_VERBOSE"] = "1"
     env.pop("FUIFGPU_ALLOW_CPU_FALLBACK", None)
-    env.pop("FUIFGPU_NO_CPU_FALLBACK", None)
     if fallback:
         env["FUIFGPU_ALLOW_CPU_FALLBACK"] = "1"
     return subprocess.run([CLI] + args, env=env, capture_output=True, text=True, timeout=300)

@@ -89,6 +89,21 @@ def test_add_group_index_in_one_launch_per_geometry(gpulib, manifest, port):
     assert _same(seq, par) and par["st"][0] == 0
 
 
+def test_add_group_index_copies_refused_streams_through(gpulib, manifest, port):
+    """a stream the planner refuses (`fuif -E 64`: more reference properties than the GPU path takes) or cannot parse (garbage) in the
+    list must not abort the call: it comes back unchanged, like fuif_index_main.cpp copies such files through"""
+    import os
+    from conftest import GOLDEN
+    e = next(x for x in manifest["fixtures"] if x["name"] == "rgb8_97x61")
+    good = golden_blob(e, e["cases"][0])
+    with open(os.path.join(GOLDEN, "outside_gpu_scope_rgb8_64x48_E64.fuif"), "rb") as f:
+        outside = f.read()
+    garbage = b"FUIF" + bytes(range(200))
+    out = gpulib.add_group_index([outside, good, garbage])
+    assert out[0] == outside and out[2] == garbage
+    assert gpulib.index_parse(out[1]) == port.decode(good, undo=False).groups
+
+
 def test_previews_of_indexed_streams(gpulib, manifest):
     for e, c in all_cases(manifest):
         if not c["case"].startswith("preview"):

@@ -341,3 +341,20 @@ def test_writer_with_gpu_forward_transforms_writes_the_same_bytes(gpulib, w, h, 
         host = gpulib.encode_image(img, bits, tree_mode=tree_mode, index=True)
         dev = gpulib.encode_image(img, bits, tree_mode=tree_mode, index=True, gpu_forward=True)
         assert dev == host
+
+
+@pytest.mark.parametrize("elems,stride,n", [(64 * 3 + 2, 196, 3), (131075, 131076, 5), (4, 8, 1), (0, 4, 2), (65521 * 2 + 7, 65521 * 2 + 10, 2)])
+def test_plane_checksums_export(gpulib, glib, elems, stride, n):
+    """fuifgpu_plane_checksums (verification aid of the overlapped-steps bench): sum of sample * (index mod 65521 + 1) per image as a
+    wrapping 64-bit integer, against numpy -- tails that are no multiple of 4, the weight's wrap at 65521, negative samples, gaps
+    between the images"""
+    rng = np.random.default_rng(elems + n)
+    slab = rng.integers(-(1 << 31), 1 << 31, size=(n, stride), dtype=np.int64).astype(np.int32)
+    d = Dev(slab)
+    sums = Dev(np.full(2 * n, -1, np.int32))            # n x uint64, pre-filled with garbage: the call zeroes it on the stream
+    gpulib.plane_checksums(d.ptr, elems, n, sums.ptr, None, image_stride=stride)
+    got = sums.get().view(np.uint64)
+    w = (np.arange(elems, dtype=np.uint64) % np.uint64(65521)) + np.uint64(1)
+    with np.errstate(over="ignore"):
+        want = np.array([(slab[k, :elems].astype(np.int64).view(np.uint64) * w).sum(dtype=np.uint64) for k in range(n)], np.uint64)
+    assert np.array_equal(got, want)
