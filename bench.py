@@ -755,7 +755,7 @@ def main():
                          "streaming batch objects (own coefficient slabs, scratch and context arenas) on two HIP streams take the steps in turn, so that a step's entropy "
                          "launch fills the wavefront slots the previous step leaves empty while only its long channel groups run; every step decodes all its streams in "
                          "its own launch, runs its inverse transforms and is verified through per-image checksums (overlapped_steps)")
-    ap.add_argument("--overlap-stagger", type=float, default=3.6,
+    ap.add_argument("--overlap-stagger", type=float, default=0.0,
                     help="overlapped steps: seconds the host waits before it queues the SECOND step of a run (the first one's busy phase at 1024 x 4K; 0 = both at once)")
     ap.add_argument("--alone-steps", type=int, default=2,
                     help="overlapped steps: launches timed ALONE afterwards on the resident batch (HIP events: roofline.launch_ms_alone, the inverse transforms' time)")

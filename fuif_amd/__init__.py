@@ -177,6 +177,11 @@ def lib():
     L.fuifgpu_batch_out_ptr.argtypes = [vp, C.c_int]; L.fuifgpu_batch_out_ptr.restype = vp
     L.fuifgpu_batch_download_coef.argtypes = [vp, C.c_int, vp, vp]
     L.fuifgpu_batch_download_out.argtypes = [vp, C.c_int, vp, vp]
+    L.fuifgpu_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.fuifgpu_set_device.argtypes = [C.c_int]
+    L.fuifgpu_get_device.argtypes = [C.POINTER(C.c_int)]
+    L.fuifgpu_batch_device.argtypes = [vp, C.POINTER(C.c_int)]
+    L.fuifgpu_peer_copy.argtypes = [vp, C.c_int, vp, C.c_int, C.c_size_t, vp]
     L.fuifgpu_plane_checksums.argtypes = [vp, C.c_int64, C.c_int64, C.c_int, vp, vp]
     L.fuifgpu_batch_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.fuifgpu_batch_profile.argtypes = [vp, vp]
@@ -320,6 +325,12 @@ class Batch:
         _check(lib().fuifgpu_batch_status(self._h, st.ctypes.data, used.ctypes.data))
         return st, used
 
+    @property
+    def device(self):
+        d = C.c_int(0)
+        _check(lib().fuifgpu_batch_device(self._h, C.byref(d)))
+        return d.value
+
     def set_group_parallel(self, enable):
         """False: ignore group indices (one wavefront per image, as for streams that carry none); applies to the next upload"""
         _check(lib().fuifgpu_batch_set_group_parallel(self._h, int(bool(enable))))
@@ -401,6 +412,23 @@ class Batch:
         slab = np.zeros(max(self.plan.info.out_elems, 1), np.int32)
         _check(lib().fuifgpu_batch_download_out(self._h, image, slab.ctypes.data, None))
         return [slab[c["offset"]: c["offset"] + c["w"] * c["h"]].reshape(c["h"], c["w"]).copy() for c in self.plan.output_channels]
+
+
+def device_count():
+    n = C.c_int(0)
+    _check(lib().fuifgpu_device_count(C.byref(n)))
+    return n.value
+
+
+def set_device(device):
+    """the calling thread's current device (fuifgpu_set_device): batches created afterwards live there"""
+    _check(lib().fuifgpu_set_device(int(device)))
+
+
+def get_device():
+    d = C.c_int(0)
+    _check(lib().fuifgpu_get_device(C.byref(d)))
+    return d.value
 
 
 def plane_checksums(planes_device_ptr, elems_per_image, n_images, sums_device_ptr, stream=None, image_stride=None):

@@ -34,6 +34,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <thread>
 #include <memory>
 #include <utility>
 #include <vector>
@@ -295,9 +296,104 @@ bool cpu_decode_whole(const std::vector<uint8_t> &bytes, Image &img, const fuif_
 }
 }  // namespace
 
+namespace {
+// the files `idx` (one geometry + transform chain: one plan) on the calling thread's current device: one batch object, chunk by chunk
+void decode_group_here(fuifgpu_plan *plan, const std::vector<int> &idx, const std::vector<std::vector<uint8_t>> &bytes, const char *const *filenames,
+                       Image *images, const fuif_options &options, std::vector<char> &ok, std::vector<char> &cpu_route, bool verbose) {
+    fuifgpu_image_info info;
+    fuifgpu_plan_info(plan, &info);
+    int device = 0;
+    fuifgpu_get_device(&device);
+    // How many of the group's files fit on the device at once: per picture its coefficient and output slabs (int32), its
+    // stream and a context arena; a quarter of the free memory (at most 40 GiB) stays for the decoder scratch and the
+    // transform arena.  A larger group goes through ONE batch object chunk by chunk (FUIFGPU_BOUNDARY_CHUNK: tests).
+    const int n = (int)idx.size();
+    size_t max_stream = 0;
+    for (int i : idx) max_stream = std::max(max_stream, bytes[i].size());
+    int chunk = n;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (fuifgpu_dev_mem_info(&free_b, &total_b) == FUIFGPU_OK && free_b) {
+            const size_t reserve = std::min<size_t>(free_b / 4, (size_t)40 << 30);
+            const size_t per_image = 2 * (size_t)info.coef_elems + 4 * (size_t)info.out_elems + max_stream + ((size_t)16 << 20);   // int16 coefficients, int32 outputs
+            chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, (free_b - reserve) / std::max<size_t>(per_image, 1)));
+        }
+        if (const char *e = getenv("FUIFGPU_BOUNDARY_CHUNK")) chunk = std::max(1, std::min(n, atoi(e)));
+    }
+    size_t cap = 0;
+    for (int c0 = 0; c0 < n; c0 += chunk) {
+        size_t t = 0;
+        for (int k = c0; k < std::min(n, c0 + chunk); k++) t += bytes[idx[k]].size();
+        cap = std::max(cap, t);
+    }
+    fuifgpu_batch *batch = nullptr;
+    int rc = fuifgpu_batch_create(plan, chunk, cap, nullptr, nullptr, 0, &batch);
+    int n_chunks = 0;
+    for (int c0 = 0; c0 < n && rc == FUIFGPU_OK; c0 += chunk, n_chunks++) {
+        const int cnt = std::min(chunk, n - c0);
+        std::vector<const uint8_t *> ptr;
+        std::vector<size_t> len;
+        for (int k = c0; k < c0 + cnt; k++) { ptr.push_back(bytes[idx[k]].data()); len.push_back(bytes[idx[k]].size()); }
+        rc = fuifgpu_batch_upload(batch, ptr.data(), len.data(), cnt, options.preview, nullptr);
+        if (rc == FUIFGPU_OK) rc = fuifgpu_batch_decode(batch, nullptr);
+        if (rc == FUIFGPU_OK) rc = fuifgpu_batch_undo_transforms(batch, nullptr);
+        if (rc == FUIFGPU_OK) rc = fuifgpu_batch_sync(batch, nullptr);
+        if (rc != FUIFGPU_OK) break;
+        std::vector<int32_t> status((size_t)cnt, 0);
+        fuifgpu_batch_status(batch, status.data(), nullptr);
+        for (int k = 0; k < cnt; k++) {
+            const int i = idx[c0 + k];
+            if (status[k] & FUIFGPU_ST_UNSUPPORTED) { cpu_route[i] = 1; continue; }
+            if (status[k] & FUIFGPU_ST_CORRUPT) { e_printf("%s: corruption detected.\n", filenames[i]); continue; }
+            image_from_outputs(images[i], plan, batch, k, info);
+            ok[i] = 1;
+        }
+    }
+    if (rc != FUIFGPU_OK) {
+        e_printf("fuifgpu: %s (%s)\n", fuifgpu_strerror(rc), fuifgpu_last_error());
+        if (batch) fuifgpu_batch_destroy(batch);
+        return;
+    }
+    if (verbose) {
+        if (n_chunks <= 1) fprintf(stderr, "fuifgpu: %d file(s) of %dx%d decoded in one batch on the GPU (device %d)\n", n, info.w, info.h, device);
+        else fprintf(stderr, "fuifgpu: %d file(s) of %dx%d decoded in %d batches of up to %d on the GPU (device %d)\n", n, info.w, info.h, n_chunks, chunk, device);
+    }
+    fuifgpu_batch_destroy(batch);
+}
+
+// FUIFGPU_DEVICES = "all" | "0,2,3": the GPUs fuif_decode_files() spreads a list of files over (unset: the calling thread's current device)
+std::vector<int> devices_from_env() {
+    std::vector<int> out;
+    const char *e = getenv("FUIFGPU_DEVICES");
+    if (!e || !*e) return out;
+    int n = 0;
+    if (fuifgpu_device_count(&n) != FUIFGPU_OK) return out;
+    if (!strcmp(e, "all")) { for (int d = 0; d < n; d++) out.push_back(d); return out; }
+    for (const char *p = e; *p;) {
+        char *end = nullptr;
+        const long d = strtol(p, &end, 10);
+        if (end == p) break;
+        out.push_back((int)d);
+        p = *end == ',' ? end + 1 : end;
+    }
+    return out;
+}
+}  // namespace
+
 int fuif_decode_files(const char *const *filenames, int n_files, Image *images, fuif_options options, bool *ok_out) {
-    if (!filenames || !images || n_files < 1) return 0;
+    const std::vector<int> dev = devices_from_env();
+    return fuif_decode_files_on(filenames, n_files, images, options, dev.empty() ? nullptr : dev.data(), (int)dev.size(), ok_out);
+}
+
+int fuif_decode_files_on(const char *const *filenames, int n_files, Image *images, fuif_options options, const int *devices, int n_devices, bool *ok_out) {
+    if (!filenames || !images || n_files < 1 || n_devices < 0 || (n_devices > 0 && !devices)) return 0;
     const bool verbose = env_flag("FUIFGPU_VERBOSE"), no_cpu = !cpu_fallback_allowed();
+    {   // a device list is checked before anything is decoded: a typo must not quietly leave a GPU out
+        int n_dev = 0;
+        if (n_devices > 0 && fuifgpu_device_count(&n_dev) != FUIFGPU_OK) { e_printf("fuifgpu: %s\n", fuifgpu_last_error()); return 0; }
+        for (int k = 0; k < n_devices; k++)
+            if (devices[k] < 0 || devices[k] >= n_dev) { e_printf("fuifgpu: no GPU %d on this node (%d visible)\n", devices[k], n_dev); return 0; }
+    }
     std::vector<std::vector<uint8_t>> bytes((size_t)n_files);
     std::vector<fuifgpu_plan *> plans((size_t)n_files, nullptr);
     std::vector<char> ok((size_t)n_files, 0), cpu_route((size_t)n_files, 0);
@@ -315,66 +411,27 @@ int fuif_decode_files(const char *const *filenames, int n_files, Image *images, 
         if (info.nb_frames > 1) { cpu_route[i] = 2; continue; }   // animations go one by one through fuif_decode (timing header)
         groups[info.signature].push_back(i);
     }
+    // Images are independent units: the files of every signature group are dealt round-robin to the devices of the list and
+    // one host thread per device runs its share -- its own batch objects, launches and downloads; nothing is exchanged between the devices,
+    // the decoded Images land in host memory (the reference's Image owns std::vectors).  One device (or none named): the calling thread.
+    struct Share { fuifgpu_plan *plan; std::vector<int> idx; };
+    const int n_workers = std::max(1, n_devices);
+    std::vector<std::vector<Share>> work((size_t)n_workers);
     for (auto &g : groups) {
-        const std::vector<int> &idx = g.second;
-        fuifgpu_plan *plan = plans[idx[0]];
-        fuifgpu_image_info info;
-        fuifgpu_plan_info(plan, &info);
-        // How many of the group's files fit on the device at once: per picture its coefficient and output slabs (int32), its
-        // stream and a context arena; a quarter of the free memory (at most 40 GiB) stays for the decoder scratch and the
-        // transform arena.  A larger group goes through ONE batch object chunk by chunk (FUIFGPU_BOUNDARY_CHUNK: tests).
-        const int n = (int)idx.size();
-        size_t max_stream = 0;
-        for (int i : idx) max_stream = std::max(max_stream, bytes[i].size());
-        int chunk = n;
-        {
-            size_t free_b = 0, total_b = 0;
-            if (fuifgpu_dev_mem_info(&free_b, &total_b) == FUIFGPU_OK && free_b) {
-                const size_t reserve = std::min<size_t>(free_b / 4, (size_t)40 << 30);
-                const size_t per_image = 2 * (size_t)info.coef_elems + 4 * (size_t)info.out_elems + max_stream + ((size_t)16 << 20);   // int16 coefficients, int32 outputs
-                chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, (free_b - reserve) / std::max<size_t>(per_image, 1)));
-            }
-            if (const char *e = getenv("FUIFGPU_BOUNDARY_CHUNK")) chunk = std::max(1, std::min(n, atoi(e)));
-        }
-        size_t cap = 0;
-        for (int c0 = 0; c0 < n; c0 += chunk) {
-            size_t t = 0;
-            for (int k = c0; k < std::min(n, c0 + chunk); k++) t += bytes[idx[k]].size();
-            cap = std::max(cap, t);
-        }
-        fuifgpu_batch *batch = nullptr;
-        int rc = fuifgpu_batch_create(plan, chunk, cap, nullptr, nullptr, 0, &batch);
-        int n_chunks = 0;
-        for (int c0 = 0; c0 < n && rc == FUIFGPU_OK; c0 += chunk, n_chunks++) {
-            const int cnt = std::min(chunk, n - c0);
-            std::vector<const uint8_t *> ptr;
-            std::vector<size_t> len;
-            for (int k = c0; k < c0 + cnt; k++) { ptr.push_back(bytes[idx[k]].data()); len.push_back(bytes[idx[k]].size()); }
-            rc = fuifgpu_batch_upload(batch, ptr.data(), len.data(), cnt, options.preview, nullptr);
-            if (rc == FUIFGPU_OK) rc = fuifgpu_batch_decode(batch, nullptr);
-            if (rc == FUIFGPU_OK) rc = fuifgpu_batch_undo_transforms(batch, nullptr);
-            if (rc == FUIFGPU_OK) rc = fuifgpu_batch_sync(batch, nullptr);
-            if (rc != FUIFGPU_OK) break;
-            std::vector<int32_t> status((size_t)cnt, 0);
-            fuifgpu_batch_status(batch, status.data(), nullptr);
-            for (int k = 0; k < cnt; k++) {
-                const int i = idx[c0 + k];
-                if (status[k] & FUIFGPU_ST_UNSUPPORTED) { cpu_route[i] = 1; continue; }
-                if (status[k] & FUIFGPU_ST_CORRUPT) { e_printf("%s: corruption detected.\n", filenames[i]); continue; }
-                image_from_outputs(images[i], plan, batch, k, info);
-                ok[i] = 1;
-            }
-        }
-        if (rc != FUIFGPU_OK) {
-            e_printf("fuifgpu: %s (%s)\n", fuifgpu_strerror(rc), fuifgpu_last_error());
-            if (batch) fuifgpu_batch_destroy(batch);
-            continue;
-        }
-        if (verbose) {
-            if (n_chunks <= 1) fprintf(stderr, "fuifgpu: %d file(s) of %dx%d decoded in one batch on the GPU\n", n, info.w, info.h);
-            else fprintf(stderr, "fuifgpu: %d file(s) of %dx%d decoded in %d batches of up to %d on the GPU\n", n, info.w, info.h, n_chunks, chunk);
-        }
-        fuifgpu_batch_destroy(batch);
+        std::vector<std::vector<int>> dealt((size_t)n_workers);
+        for (size_t k = 0; k < g.second.size(); k++) dealt[k % (size_t)n_workers].push_back(g.second[k]);
+        for (int wkr = 0; wkr < n_workers; wkr++)
+            if (!dealt[wkr].empty()) work[wkr].push_back(Share{plans[g.second[0]], dealt[wkr]});
+    }
+    auto run = [&](int wkr) {
+        if (n_devices > 0 && fuifgpu_set_device(devices[wkr]) != FUIFGPU_OK) { e_printf("fuifgpu: GPU %d: %s\n", devices[wkr], fuifgpu_last_error()); return; }
+        for (const Share &sh : work[wkr]) decode_group_here(sh.plan, sh.idx, bytes, filenames, images, options, ok, cpu_route, verbose);
+    };
+    if (n_workers == 1) run(0);
+    else {
+        std::vector<std::thread> threads;
+        for (int wkr = 0; wkr < n_workers; wkr++) threads.emplace_back(run, wkr);
+        for (std::thread &t : threads) t.join();
     }
     for (int i = 0; i < n_files; i++) {
         if (cpu_route[i] == 2) {   // an animation: the single-file path (GPU as well)

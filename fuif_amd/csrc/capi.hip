@@ -25,6 +25,7 @@ struct fuifgpu_plan {
 
 struct fuifgpu_batch {
     Plan plan;
+    int device = 0;                   // the HIP device the batch was created on: every call on the batch runs there (DeviceGuard)
     int n = 0;
     int n_loaded = 0;
     // device state
@@ -122,6 +123,21 @@ size_t maniac_scratch_bytes(int max_nodes, size_t *bfs_off, size_t *leaves_off, 
 
 extern "C" {
 
+// A HIP device is per-thread state.  A batch lives on the device that was current when it was created (fuifgpu_set_device); every entry
+// point that takes a batch switches the calling thread to that device for the duration of the call, so one host thread per device -- or one
+// thread walking over the batches of several devices -- both work, and the caller's current device is what it was when the call returns.
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int want) {
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != want && hipSetDevice(want) == hipSuccess) prev = cur;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define ON_BATCH_DEVICE(b) DeviceGuard device_guard__((b) ? (b)->device : 0)
+
 const char *fuifgpu_strerror(int code) {
     switch (code) {
         case FUIFGPU_OK: return "ok";
@@ -195,6 +211,7 @@ int fuifgpu_plan_transform(const fuifgpu_plan *plan, int index, int32_t *id, int
 // -------------------------------------------------------------------------------------------------
 void fuifgpu_batch_destroy(fuifgpu_batch *b) {
     if (!b) return;
+    ON_BATCH_DEVICE(b);
     // the documented order is "sibling first"; the other order must not leave a sibling launching with freed memory
     for (fuifgpu_batch *s : b->siblings) { s->share = nullptr; s->orphan = true; s->n_loaded = 0; s->d_coef = nullptr; s->d_out = nullptr; }
     if (b->share) {
@@ -222,6 +239,8 @@ static int batch_create_impl(const Plan &plan_in, int n_images, size_t blob_capa
         return FUIFGPU_E_HIP;
     }
     fuifgpu_batch *b = new fuifgpu_batch();
+    if (share) b->device = share->device;                        // (a sibling lives where its primary lives: the caller holds that device, see below)
+    else if (hipGetDevice(&b->device) != hipSuccess) b->device = 0;
     b->plan = plan_in;
     b->n = n_images;
     b->share = share;
@@ -329,6 +348,7 @@ int fuifgpu_batch_create_streaming(const fuifgpu_plan *plan, int n_images, size_
 
 int fuifgpu_batch_create_sibling(fuifgpu_batch *primary, size_t blob_capacity_bytes, fuifgpu_batch **out) {
     if (!primary || primary->share || primary->no_out) return FUIFGPU_E_ARG;
+    ON_BATCH_DEVICE(primary);
     if (primary->siblings.empty()) { const int frc = freeze_launch_resources(primary); if (frc != FUIFGPU_OK) return frc; }
     const int rc = batch_create_impl(primary->plan, primary->n, blob_capacity_bytes, primary->d_coef, primary->d_out, primary->tmp_images, primary, out);
     if (rc == FUIFGPU_OK) primary->siblings.push_back(*out);
@@ -336,6 +356,7 @@ int fuifgpu_batch_create_sibling(fuifgpu_batch *primary, size_t blob_capacity_by
 }
 
 int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const size_t *sizes, int n_images, int preview, void *stream) {
+    ON_BATCH_DEVICE(b);
     if (!b || !blobs || !sizes || n_images < 1 || n_images > b->n || preview < -1 || preview > 4) return FUIFGPU_E_ARG;
     if (b->orphan) { g_last_error = "sibling batch: its primary has been destroyed"; return FUIFGPU_E_ARG; }
     hipStream_t st = (hipStream_t)stream;
@@ -534,6 +555,7 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
 }
 
 int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
+    ON_BATCH_DEVICE(b);
     if (!b || b->n_loaded < 1) return FUIFGPU_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int nch = (int)b->plan.coded.size();
@@ -616,6 +638,7 @@ static int undo_range(fuifgpu_batch *b, int first, int count, int32_t *out_base,
 }
 
 int fuifgpu_batch_undo_transforms_to(fuifgpu_batch *b, int first_image, int n_images, int32_t *out_device, void *stream) {
+    ON_BATCH_DEVICE(b);
     if (!b || b->orphan || !out_device || first_image < 0 || n_images < 1 || first_image + n_images > b->n_loaded) return FUIFGPU_E_ARG;
     if (b->coef_consumed) { g_last_error = "fuifgpu_batch_undo_transforms_to: fuifgpu_batch_undo_transforms already ran on this decode"; return FUIFGPU_E_ARG; }
     if ((int)b->undone.size() != b->n_loaded) b->undone.assign((size_t)b->n_loaded, 0);
@@ -632,6 +655,7 @@ int fuifgpu_batch_undo_transforms_to(fuifgpu_batch *b, int first_image, int n_im
 }
 
 int fuifgpu_batch_undo_transforms(fuifgpu_batch *b, void *stream) {
+    ON_BATCH_DEVICE(b);
     if (!b || b->n_loaded < 1) return FUIFGPU_E_ARG;
     if (b->no_out) { g_last_error = "fuifgpu_batch_undo_transforms: a streaming batch has no output slab (fuifgpu_batch_undo_transforms_to)"; return FUIFGPU_E_ARG; }
     for (char u : b->undone) if (u) { g_last_error = "fuifgpu_batch_undo_transforms: part of this decode went through fuifgpu_batch_undo_transforms_to already"; return FUIFGPU_E_ARG; }
@@ -649,12 +673,14 @@ int fuifgpu_batch_undo_transforms(fuifgpu_batch *b, void *stream) {
 }
 
 int fuifgpu_batch_sync(fuifgpu_batch *b, void *stream) {
+    ON_BATCH_DEVICE(b);
     if (!b) return FUIFGPU_E_ARG;
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     return FUIFGPU_OK;
 }
 
 int fuifgpu_batch_status(fuifgpu_batch *b, int32_t *status, uint32_t *bytes_consumed) {
+    ON_BATCH_DEVICE(b);
     if (!b || b->n_loaded < 1) return FUIFGPU_E_ARG;
     HIPCHK(hipDeviceSynchronize());
     if (status) HIPCHK(hipMemcpy(status, b->d_status, sizeof(int32_t) * b->n_loaded, hipMemcpyDeviceToHost));
@@ -669,6 +695,7 @@ int fuifgpu_batch_set_group_parallel(fuifgpu_batch *b, int enable) {
 }
 
 int fuifgpu_batch_group_index(fuifgpu_batch *b, int image, int32_t *first_channel, uint32_t *start, int cap, int *n_groups) {
+    ON_BATCH_DEVICE(b);
     if (!b || image < 0 || image >= b->n_loaded || !n_groups) return FUIFGPU_E_ARG;
     const int nch = (int)b->plan.coded.size();
     std::vector<uint32_t> gs(std::max(nch, 1));
@@ -688,6 +715,7 @@ int fuifgpu_batch_group_index(fuifgpu_batch *b, int image, int32_t *first_channe
 }
 
 int fuifgpu_batch_channel_meta(fuifgpu_batch *b, int image, int32_t *meta4) {
+    ON_BATCH_DEVICE(b);
     if (!b || image < 0 || image >= b->n_loaded || !meta4) return FUIFGPU_E_ARG;
     const int nch = (int)b->plan.coded.size();
     HIPCHK(hipDeviceSynchronize());
@@ -699,6 +727,7 @@ int16_t *fuifgpu_batch_coef_ptr(fuifgpu_batch *b, int image) { return (b && !b->
 int32_t *fuifgpu_batch_out_ptr(fuifgpu_batch *b, int image) { return (b && !b->orphan && !b->no_out && image >= 0 && image < b->n) ? b->d_out + (int64_t)image * b->plan.out_elems : nullptr; }
 
 int fuifgpu_batch_download_coef(fuifgpu_batch *b, int image, int32_t *host, void *stream) {
+    ON_BATCH_DEVICE(b);
     if (!b || image < 0 || image >= b->n || !host || b->orphan) return FUIFGPU_E_ARG;
     // the slab holds int16 samples; the caller gets them as int32, like every other plane of the interface
     const size_t n = (size_t)b->plan.coef_elems;
@@ -709,6 +738,7 @@ int fuifgpu_batch_download_coef(fuifgpu_batch *b, int image, int32_t *host, void
     return FUIFGPU_OK;
 }
 int fuifgpu_batch_download_out(fuifgpu_batch *b, int image, int32_t *host, void *stream) {
+    ON_BATCH_DEVICE(b);
     if (!b || image < 0 || image >= b->n || !host || b->orphan || b->no_out) return FUIFGPU_E_ARG;
     HIPCHK(hipMemcpyAsync(host, fuifgpu_batch_out_ptr(b, image), sizeof(int32_t) * (size_t)b->plan.out_elems, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
@@ -736,6 +766,7 @@ size_t fuifgpu_plan_packed_bytes(const fuifgpu_plan *plan, int components) {
     return (size_t)plan->plan.w * plan->plan.h * pp.n * bps;
 }
 int fuifgpu_batch_pack_out(fuifgpu_batch *b, int first_image, int n_images, int components, uint8_t *dst_device, void *stream) {
+    ON_BATCH_DEVICE(b);
     if (!b || !dst_device || first_image < 0 || n_images < 1 || first_image + n_images > b->n_loaded || b->no_out) return FUIFGPU_E_ARG;
     const Plan &p = b->plan;
     PackedPlanes pp; int bps = 1;
@@ -750,6 +781,7 @@ int fuifgpu_batch_pack_out(fuifgpu_batch *b, int first_image, int n_images, int 
     return FUIFGPU_OK;
 }
 int fuifgpu_batch_download_packed(fuifgpu_batch *b, int image, int components, uint8_t *host, void *stream) {
+    ON_BATCH_DEVICE(b);
     if (!b || !host || image < 0 || image >= b->n_loaded) return FUIFGPU_E_ARG;
     PackedPlanes pp; int bps = 1;
     int rc = packed_layout(b->plan, components, &pp, &bps);
@@ -778,6 +810,7 @@ int fuifgpu_plane_checksums(const int32_t *planes_device, int64_t elems_per_imag
 }
 
 int fuifgpu_batch_last_timing(fuifgpu_batch *b, float *decode_ms, float *transform_ms) {
+    ON_BATCH_DEVICE(b);
     if (!b) return FUIFGPU_E_ARG;
     if (decode_ms) {
         *decode_ms = -1.f;
@@ -792,6 +825,7 @@ int fuifgpu_batch_last_timing(fuifgpu_batch *b, float *decode_ms, float *transfo
 
 // diagnostic: per-stream phase cycle counters of the last decode (only filled by -DFUIF_PROF builds)
 int fuifgpu_batch_profile(fuifgpu_batch *b, uint64_t *out8_per_image) {
+    ON_BATCH_DEVICE(b);
     if (!b || !out8_per_image || b->n_loaded < 1) return FUIFGPU_E_ARG;
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out8_per_image, b->d_prof, sizeof(unsigned long long) * 8 * b->n_loaded, hipMemcpyDeviceToHost));
@@ -801,6 +835,7 @@ int fuifgpu_batch_profile(fuifgpu_batch *b, uint64_t *out8_per_image) {
 // diagnostic: schedule of the last decode launch.  The first call (cap 0 is fine) switches logging on for later launches.
 // Only the -DFUIF_STATS build of the library records it (the release kernel carries no statistics): FUIFGPU_E_UNSUPPORTED otherwise.
 int fuifgpu_batch_tile_log(fuifgpu_batch *b, uint64_t *out4_per_tile, int cap, int *n_tiles) {
+    ON_BATCH_DEVICE(b);
     if (!b || !n_tiles) return FUIFGPU_E_ARG;
 #if !defined(FUIF_STATS) && !defined(FUIF_PROF) && !defined(FUIF_TILELOG)
     *n_tiles = 0;
@@ -818,6 +853,7 @@ int fuifgpu_batch_tile_log(fuifgpu_batch *b, uint64_t *out4_per_tile, int cap, i
 
 // diagnostic: scheduler counters of the last dense launch {idle ticks (100 MHz) summed over wavefronts, tiles picked up, suspensions, ticks spent picking, ticks spent spinning inside tiles, suspendable tiles that found the arena full}
 int fuifgpu_batch_sched_stats(fuifgpu_batch *b, uint64_t *out8) {
+    ON_BATCH_DEVICE(b);
     if (!b || !out8 || !b->d_sched) return FUIFGPU_E_ARG;
 #ifndef FUIF_STATS
     g_last_error = "fuifgpu_batch_sched_stats: this build of libfuifgpu carries no scheduler statistics (build with -DFUIF_STATS)";
@@ -829,6 +865,59 @@ int fuifgpu_batch_sched_stats(fuifgpu_batch *b, uint64_t *out8) {
 }
 
 // ---- device memory for callers that are not HIP programs themselves (the C++ boundary layer is compiled with g++) ---
+// ---- device selection (one node, several GPUs: images are independent units) ---------------------------------------
+int fuifgpu_device_count(int *n_devices) {
+    if (!n_devices) return FUIFGPU_E_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) { *n_devices = 0; g_last_error = "no HIP device visible: libfuifgpu has no CPU fallback"; return FUIFGPU_E_HIP; }
+    *n_devices = n;
+    return FUIFGPU_OK;
+}
+int fuifgpu_set_device(int device) {
+    int n = 0;
+    const int rc = fuifgpu_device_count(&n);
+    if (rc != FUIFGPU_OK) return rc;
+    if (device < 0 || device >= n) { g_last_error = "fuifgpu_set_device: no such device"; return FUIFGPU_E_ARG; }
+    HIPCHK(hipSetDevice(device));
+    return FUIFGPU_OK;
+}
+int fuifgpu_get_device(int *device) {
+    if (!device) return FUIFGPU_E_ARG;
+    HIPCHK(hipGetDevice(device));
+    return FUIFGPU_OK;
+}
+int fuifgpu_batch_device(const fuifgpu_batch *b, int *device) {
+    if (!b || !device) return FUIFGPU_E_ARG;
+    *device = b->device;
+    return FUIFGPU_OK;
+}
+// the final gather's building block inside ONE process: bytes from one GPU's memory into another's over xGMI (peer access is enabled on
+// first use; where the platform has none the runtime stages the copy through the host).  Asynchronous on `stream` of the CURRENT device.
+int fuifgpu_peer_copy(void *dst_device_ptr, int dst_device, const void *src_device_ptr, int src_device, size_t bytes, void *stream) {
+    if ((!dst_device_ptr || !src_device_ptr) && bytes) return FUIFGPU_E_ARG;
+    int n = 0;
+    const int rc = fuifgpu_device_count(&n);
+    if (rc != FUIFGPU_OK) return rc;
+    if (dst_device < 0 || dst_device >= n || src_device < 0 || src_device >= n) { g_last_error = "fuifgpu_peer_copy: no such device"; return FUIFGPU_E_ARG; }
+    if (!bytes) return FUIFGPU_OK;
+    if (dst_device == src_device) {
+        DeviceGuard g(dst_device);
+        HIPCHK(hipMemcpyAsync(dst_device_ptr, src_device_ptr, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return FUIFGPU_OK;
+    }
+    {
+        DeviceGuard g(dst_device);
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, dst_device, src_device) == hipSuccess && can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(src_device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();   // not fatal: the copy below still works, staged
+            else (void)hipGetLastError();
+        }
+    }
+    HIPCHK(hipMemcpyPeerAsync(dst_device_ptr, dst_device, src_device_ptr, src_device, bytes, (hipStream_t)stream));
+    return FUIFGPU_OK;
+}
+
 void *fuifgpu_dev_alloc(size_t bytes) {
     void *p = nullptr;
     if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { g_last_error = "hipMalloc failed (no HIP device or out of memory): libfuifgpu has no CPU fallback"; return nullptr; }

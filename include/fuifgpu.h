@@ -197,6 +197,24 @@ int fuifgpu_batch_group_index(fuifgpu_batch *batch, int image, int32_t *first_ch
 /* enable = 0: ignore trailers from the next upload on (A/B measurements; default 1) */
 int fuifgpu_batch_set_group_parallel(fuifgpu_batch *batch, int enable);
 
+/* ---- several GPUs of one node (round 5) ---------------------------------------------------------------------
+ * The reference decodes file after file on one core (fuif.cpp:213-233: fuif_decode_file + undo_transforms per file); a batch of
+ * independent images shards across the GPUs of a node with no data-path exchange.  Inside ONE process the unit is
+ * the calling thread's current device, as in HIP: fuifgpu_set_device() selects it, a batch lives on the device that was current when
+ * it was created, and every fuifgpu_batch_* call runs on the batch's own device whatever the calling thread's current device is (it
+ * is restored on return) -- so a host runs one thread per device (fuif_decode_files in fuif_amd/boundary does) or one thread over
+ * the batches of several devices.  fuifgpu_dev_* and the single-transform entry points use the calling thread's current device.
+ * Several PROCESSES (one per GPU, torch.distributed / RCCL: bench.py, fuif_amd/dist.py) each simply see their own device. */
+int fuifgpu_device_count(int *n_devices);
+int fuifgpu_set_device(int device);                                   /* FUIFGPU_E_ARG: no such device */
+int fuifgpu_get_device(int *device);
+int fuifgpu_batch_device(const fuifgpu_batch *batch, int *device);
+/* The final gather's building block inside one process: `bytes` from src_device's memory into dst_device's over xGMI (peer access
+ * is enabled on first use; without it the runtime stages the copy), asynchronous on `stream` (a stream of the calling thread's
+ * current device; NULL = its null stream).  What a host uses to collect the packed pictures (fuifgpu_batch_pack_out) of every
+ * GPU's shard on one GPU; the multi-process form of the same gather goes through RCCL (fuif_amd/dist.py gather_packed). */
+int fuifgpu_peer_copy(void *dst_device_ptr, int dst_device, const void *src_device_ptr, int src_device, size_t bytes, void *stream);
+
 /* ---- device memory for hosts that are not HIP programs (the boundary layer is plain g++ code) ------------- */
 void *fuifgpu_dev_alloc(size_t bytes);                       /* NULL on failure (fuifgpu_last_error) */
 void fuifgpu_dev_free(void *device_ptr);

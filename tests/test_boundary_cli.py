@@ -168,6 +168,62 @@ def test_batch_entry_decodes_many_files_in_one_launch(tmp_path):
         assert open(str(outdir / (n + ".pam")), "rb").read() == expect[n], n
 
 
+def check_batch_entry_on_several_devices(run_batch, run_ref, tmp_path, devices, env_devices=False):
+    """fuif_decode_files_on (fuifgpu_boundary.h; `fuif_gpu_batch --devices a,b`, or FUIFGPU_DEVICES in the environment for plain
+    fuif_decode_files): the files of every geometry are dealt round-robin to the listed GPUs, one host thread and one batch object per
+    GPU; every output file equals what the unmodified reference CLI writes; a device that does not exist fails the call before
+    anything is decoded.  `devices` = "0,0" on the one GPU of a box (two threads, two batches on it), "0,1" on the emulated node."""
+    import shutil
+    outdir = tmp_path / "multi"
+    outdir.mkdir()
+    files = []
+    for k in range(5):
+        q = tmp_path / ("m_%02d.fuif" % k)
+        shutil.copy(os.path.join(GOLDEN, "rgb8_97x61.fuif"), q)
+        files.append(str(q))
+    others = ["jpeg420_256x192_q90", "rgba14_80x72"]
+    files += [os.path.join(GOLDEN, n + ".fuif") for n in others]
+    args = [str(outdir)] + files
+    r = run_batch(args if env_devices else ["--devices", devices] + args, {"FUIFGPU_DEVICES": devices} if env_devices else {})
+    assert r.returncode == 0, r.stderr[-800:]
+    a, b = devices.split(",")
+    assert "3 file(s) of 97x61 decoded in one batch on the GPU (device %s)" % a in r.stderr, r.stderr      # files 0, 2, 4
+    assert "2 file(s) of 97x61 decoded in one batch on the GPU (device %s)" % b in r.stderr, r.stderr      # files 1, 3
+    expect = {}
+    for src in [files[0]] + files[5:]:
+        ref_out = str(tmp_path / "ref_multi.pam")
+        rb = run_ref(["-d", src, ref_out])
+        assert rb.returncode == 0
+        expect[os.path.basename(src)[:-5]] = open(ref_out, "rb").read()
+    for k in range(5):
+        assert open(str(outdir / ("m_%02d.pam" % k)), "rb").read() == expect["m_00"]
+    for n in others:
+        assert open(str(outdir / (n + ".pam")), "rb").read() == expect[n], n
+    if not env_devices:
+        bad = tmp_path / "multi_bad"
+        bad.mkdir()
+        r = run_batch(["--devices", a + ",63", str(bad)] + files, {})
+        assert r.returncode != 0 and "no GPU 63 on this node" in r.stderr and not os.listdir(str(bad)), r.stderr[-400:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_devices", [False, True])
+def test_batch_entry_spreads_files_over_a_device_list(tmp_path, env_devices):
+    """one GPU per box here: the list names it twice -- two host threads, each with its own batch object on device 0"""
+    need_cli()
+    batch_cli = os.path.join(ROOT, "fuif_amd", "boundary", "_build", "fuif_gpu_batch")
+    ref_cli = os.path.join(ROOT, "oracle", "_ref", "fuif")
+    if not (os.path.exists(batch_cli) and os.path.exists(ref_cli)):
+        pytest.skip("fuif_gpu_batch / oracle/_ref/fuif not built")
+    env = dict(os.environ)
+    if os.path.exists("/opt/conda/lib/libjpeg.so.9"):
+        env["LD_PRELOAD"] = "/opt/conda/lib/libjpeg.so.9"
+    env.pop("FUIFGPU_DEVICES", None)
+    check_batch_entry_on_several_devices(
+        lambda args, extra: subprocess.run([batch_cli] + args, env=dict(env, FUIFGPU_VERBOSE="1", **extra), capture_output=True, text=True, timeout=600),
+        lambda args: subprocess.run([ref_cli] + args, env=env, capture_output=True, text=True, timeout=300), tmp_path, "0,0", env_devices)
+
+
 OUTSIDE = os.path.join(GOLDEN, "outside_gpu_scope_rgb8_64x48_E64.fuif")   # written by `fuif -E 64`: more reference properties than the GPU path takes
 OUTSIDE_PPM_SHA256 = "5200e0a07cf1683c449896c13553d91b9f1881553aba0d98cd7aaee9ecedc274"   # what the unmodified reference CLI decodes it to (= the source picture)
 

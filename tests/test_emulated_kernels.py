@@ -148,6 +148,18 @@ def test_gpu_parity_tests_pass_on_the_wavefront_emulator():
     run_dealt(SELECTED, env, max(1, min(7, (os.cpu_count() or 2) - 1)))
 
 
+def test_device_selection_on_an_emulated_node_of_two_devices():
+    """EMU_DEVICES=2: fuifgpu_set_device / batch_device / peer_copy between two "devices" (host memory both; the current device is
+    per-thread state in the emulator as in HIP) -- a batch created on device 1 decodes there while the caller sits on device 0"""
+    if sys.platform != "linux" or os.uname().machine != "x86_64":
+        pytest.skip("the emulator's context switch is x86-64 SysV assembly")
+    env = dict(os.environ, FUIF_AMD_LIB=build_emulated_library(), EMU_DEVICES="2", EMU_ALARM="600")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "tests/test_gpu_transform_exports.py::test_device_selection_and_peer_copy",
+                        "tests/test_gpu_group_parallel.py::test_add_group_index_copies_refused_streams_through"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
+
+
 def test_node_by_node_walk_beyond_the_supernode_cap():
     """the library built with room for three supernodes per tree (-DFUIF_MAX_SUPER=3; the product reserves thousands, so the
     path never runs in the other tests): every subtree beyond them is walked node by node from the parse-order array"""
@@ -241,6 +253,14 @@ def test_reference_cli_through_the_boundary_writes_the_reference_files(tmp_path)
         assert "2 file(s) of 97x61 decoded in 2 batches of up to 1 on the GPU" in rc.stderr
         for n in picks + ["rgb8_97x61_again"]:
             assert open(str(outdir2 / (n + ".pam")), "rb").read() == open(str(outdir / (n + ".pam")), "rb").read(), n
+        # several GPUs behind the boundary (fuif_decode_files_on): the emulated node has two "devices" (EMU_DEVICES), one host thread each
+        from test_boundary_cli import check_batch_entry_on_several_devices
+        for env_devices in (False, True):
+            md = tmp_path / ("multi_dev_%d" % env_devices)
+            md.mkdir()
+            check_batch_entry_on_several_devices(
+                lambda args, extra: subprocess.run([batch_cli] + args, env=dict(env_gpu, FUIFGPU_VERBOSE="1", EMU_DEVICES="2", **extra), capture_output=True, text=True, timeout=900),
+                lambda args: subprocess.run([ref_cli] + args, env=env, capture_output=True, text=True, timeout=600), md, "0,1", env_devices)
     # `-d x.fuif out.yuv` keeps the colour transform and the chroma subsampling: Image::undo_transforms(2) (fuif.cpp:230),
     # i.e. Transform::apply(image, true) per transform -- Squeeze, Quantization and DCT inverses through the boundary's binding to
     # fuifgpu_inv_hsqueeze / fuifgpu_inv_vsqueeze / fuifgpu_inv_quantize / fuifgpu_idct8x8

@@ -358,3 +358,45 @@ def test_plane_checksums_export(gpulib, glib, elems, stride, n):
     with np.errstate(over="ignore"):
         want = np.array([(slab[k, :elems].astype(np.int64).view(np.uint64) * w).sum(dtype=np.uint64) for k in range(n)], np.uint64)
     assert np.array_equal(got, want)
+
+
+def test_device_selection_and_peer_copy(gpulib, glib, manifest):
+    """fuifgpu_device_count / set_device / get_device / batch_device / peer_copy (include/fuifgpu.h, round 5): a batch lives on the
+    device that was current at its creation and its calls run there; a device that does not exist is refused; a peer copy moves the
+    bytes (one GPU per box: device 0 to device 0, the same-device branch; two devices on the emulated node of the CPU suite)"""
+    from conftest import golden_blob
+    n = gpulib.device_count()
+    assert n >= 1
+    with pytest.raises(gpulib.FuifGpuError):
+        gpulib.set_device(n)
+    with pytest.raises(gpulib.FuifGpuError):
+        gpulib.set_device(-1)
+    last = n - 1
+    gpulib.set_device(last)
+    assert gpulib.get_device() == last
+    e = next(x for x in manifest["fixtures"] if x["name"] == "rgb8_97x61")
+    blob = golden_blob(e, e["cases"][0])
+    plan = gpulib.Plan(blob)
+    batch = gpulib.Batch(plan, 1, len(blob))
+    try:
+        assert batch.device == last
+        gpulib.set_device(0)                      # the batch keeps decoding on ITS device whatever the caller's current device is
+        batch.upload([blob]); batch.decode(); batch.undo_transforms(); batch.sync()
+        assert gpulib.get_device() == 0           # ... and the caller's device is what it was
+        st, _ = batch.status()
+        assert not st.any()
+        from conftest import plane_hash
+        assert [plane_hash(p) for p in batch.out_planes(0)] == [c["sha256"] for c in e["cases"][0]["post"]]
+    finally:
+        batch.close()
+    src = Dev(np.arange(1000, dtype=np.int32))
+    gpulib.set_device(last)
+    dst = Dev(np.zeros(1000, np.int32))
+    gpulib.set_device(0)
+    assert glib.fuifgpu_peer_copy(dst.ptr, last, src.ptr, 0, 4000, None) == 0
+    if not EMULATED:
+        import torch
+        for d in range(n):
+            torch.cuda.synchronize(d)
+    assert np.array_equal(dst.get(), np.arange(1000, dtype=np.int32))
+    assert glib.fuifgpu_peer_copy(dst.ptr, n, src.ptr, 0, 4000, None) != 0

@@ -101,8 +101,16 @@ static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; 
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char *hipGetErrorString(hipError_t) { return "emulated HIP runtime"; }
-static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
-static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+// EMU_DEVICES=n: the emulated node has n "devices" (host memory all of them); the current device is per-thread state, as in HIP
+static inline int emu_device_count() { const char *e = getenv("EMU_DEVICES"); const int n = e ? atoi(e) : 1; return n < 1 ? 1 : n; }
+static inline int &emu_current_device() { static thread_local int d = 0; return d; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = emu_device_count(); return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = emu_current_device(); return hipSuccess; }
+static inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= emu_device_count()) return 101; emu_current_device() = d; return hipSuccess; }
+static const hipError_t hipErrorPeerAccessAlreadyEnabled = 704;
+static inline hipError_t hipDeviceCanAccessPeer(int *can, int, int) { *can = 1; return hipSuccess; }
+static inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
+static inline hipError_t hipMemcpyPeerAsync(void *d, int, const void *s, int, size_t n, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 // EMU_WAVES: persistent wavefronts of the entropy kernel (each becomes a workgroup; run them on EMU_THREADS >= EMU_WAVES threads)
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { const char *e = getenv("EMU_WAVES"); p->multiProcessorCount = e ? std::max(1, atoi(e)) : 1; return hipSuccess; }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }   // v_mul_hi_u32
