@@ -52,39 +52,56 @@ def _encode_one(args):
     from fuif_amd.synth import photographic
     if kind == "dct420":
         from fuif_amd.jpeglike import encode_jpeg_like
-        img = photographic(w, h, channels, bits, seed=seed, sigma=1.0)
+        # the C2 pixels (sigma = 3) through JPEG quality 90, 4:2:0 (rounds 1-4 used sigma = 1: a third of the bytes per stream)
+        img = photographic(w, h, channels, bits, seed=seed)
         return seed, encode_jpeg_like(img, 90, True, index=True)
     img = photographic(w, h, channels, bits, seed=seed)
     return seed, fuif_amd.encode_image(img, bits, ycocg=(kind != "squeeze_raw"), tree_mode=1, index=True)
 
 
-def make_inputs(k, w, h, channels, bits, seed0, cache_dir, kind="squeeze"):
-    """K distinct encoded streams (+ their seeds); cached on local disk inside one box session."""
+def _stream_path(cache_dir, kind, w, h, channels, bits, seed):
+    return os.path.join(cache_dir, "synth_idx3_%s_%dx%dx%d_%dbit_seed%d.fuif" % (kind, w, h, channels, bits, seed))   # streams carry the group index trailer (csrc/index.cpp)
+
+
+def make_inputs_many(specs, cache_dir):
+    """specs: [(k, w, h, channels, bits, seed0, kind)] -> one list of (seed, stream bytes) per spec; everything that is not in the cache of this box
+    session is encoded by ONE pool of host processes (largest pictures first)."""
     os.makedirs(cache_dir, exist_ok=True)
     jobs, blobs = [], {}
-    name = "synth_idx2_" + kind + "_%dx%dx%d_%dbit_seed%d.fuif"   # streams carry the group index trailer (csrc/index.cpp)
-    for i in range(k):
-        seed = seed0 + i
-        path = os.path.join(cache_dir, name % (w, h, channels, bits, seed))
-        if os.path.exists(path):
-            blobs[seed] = open(path, "rb").read()
-        else:
-            jobs.append((seed, w, h, channels, bits, kind))
+    for k, w, h, channels, bits, seed0, kind in specs:
+        for i in range(k):
+            key = (kind, w, h, channels, bits, seed0 + i)
+            path = _stream_path(cache_dir, *key)
+            if os.path.exists(path):
+                blobs[key] = open(path, "rb").read()
+            elif key not in [(j[5], j[1], j[2], j[3], j[4], j[0]) for j in jobs]:
+                jobs.append((seed0 + i, w, h, channels, bits, kind))
     if jobs:
         import multiprocessing as mp
+        jobs.sort(key=lambda j: -j[1] * j[2] * j[3])
         nproc = max(1, min(len(jobs), (os.cpu_count() or 2)))
         with mp.get_context("fork").Pool(nproc) as pool:
-            for seed, blob in pool.imap_unordered(_encode_one, jobs):
-                blobs[seed] = blob
+            for key, blob in pool.imap_unordered(_encode_keyed, jobs, chunksize=1):
+                blobs[key] = blob
                 try:    # (atomic: the ranks of a multi-GPU run share the directory, and a late rank must never read half a file)
-                    final = os.path.join(cache_dir, name % (w, h, channels, bits, seed))
+                    final = _stream_path(cache_dir, *key)
                     part = "%s.%d.part" % (final, os.getpid())
                     with open(part, "wb") as f:
                         f.write(blob)
                     os.replace(part, final)
                 except OSError:
                     pass
-    return [(seed0 + i, blobs[seed0 + i]) for i in range(k)]
+    return [[(seed0 + i, blobs[(kind, w, h, channels, bits, seed0 + i)]) for i in range(k)] for k, w, h, channels, bits, seed0, kind in specs]
+
+
+def _encode_keyed(job):
+    seed, w, h, channels, bits, kind = job
+    return (kind, w, h, channels, bits, seed), _encode_one(job)[1]
+
+
+def make_inputs(k, w, h, channels, bits, seed0, cache_dir, kind="squeeze"):
+    """K distinct encoded streams (+ their seeds); cached on local disk inside one box session."""
+    return make_inputs_many([(k, w, h, channels, bits, seed0, kind)], cache_dir)[0]
 
 
 def reference_encodes_start(k, w, h, channels, bits, seed0, cache_dir):
@@ -132,6 +149,108 @@ def reference_encodes_wait(jobs, timeout_s=240.0):
         with open(out, "rb") as f:
             res.append((seed, f.read()))
     return res
+
+
+# The other BASELINE.json configs at sizes that take seconds, as extra keys of the default line (the driver's record, not only
+# profiles/, shows every config with a rate, a roofline and a CPU baseline).  Full-size runs of each: --workload c3 / c4 / c5.
+EXTRA_LEGS = {
+    "c3": dict(desc="C3 shape: %d x 3840x2160 JPEG-transcode-like (YCbCr + 4:2:0 + 8x8 DCT + Quantize q90 + Squeeze of DC), sigma-3 pixels", n=128,
+               parts=[dict(kind="dct420", w=3840, h=2160, channels=3, bits=8, k=4, seed0=2000)], steps=3),
+    "c4": dict(desc="C4 shape: %d x 4096x4096 14-bit 4-channel Squeeze-only lossless (a quarter of C4's 8192x8192 per picture)", n=8,
+               parts=[dict(kind="squeeze_raw", w=4096, h=4096, channels=4, bits=14, k=2, seed0=7000)], steps=1),
+    "c5": dict(desc="C5 shape: %d x 1920x1080 mixed Squeeze / DCT pictures (alternating), one launch per kind", n=64,
+               parts=[dict(kind="squeeze", w=1920, h=1080, channels=3, bits=8, k=2, seed0=3000), dict(kind="dct420", w=1920, h=1080, channels=3, bits=8, k=2, seed0=4000)], steps=3),
+}
+
+
+def run_extra_leg(name, spec, streams, dev):
+    """one small configuration on the resident path: every part (kind) gets its own Batch, a step = decode + inverse transforms of all parts; 1 warm-up +
+    spec['steps'] timed steps; parity: lossless parts against the generator's pixels (every image), lossy parts MSE < 40 for the first replica and all
+    replicas identical; roofline of the entropy kernel from its HIP events; the reference decoder on one thread on a bounded sample of the same streams"""
+    import torch
+    import fuif_amd
+    from fuif_amd.synth import photographic
+    n_parts = len(spec["parts"])
+    parts = []
+    for pi, part in enumerate(spec["parts"]):
+        mine = [i for i in range(spec["n"]) if i % n_parts == pi]
+        blobs = [streams[pi][j % len(streams[pi])][1] for j in range(len(mine))]
+        plan = fuif_amd.Plan(blobs[0])
+        out = torch.empty(len(blobs) * plan.info.out_elems, dtype=torch.int32, device=dev)
+        batch = fuif_amd.Batch(plan, len(blobs), sum(len(b) for b in blobs), out_ptr=out.data_ptr())
+        batch.upload(blobs)
+        parts.append(dict(part=part, blobs=blobs, plan=plan, out=out, batch=batch))
+
+    def step():
+        for p in parts:
+            p["batch"].decode()
+            p["batch"].undo_transforms()
+
+    step()
+    torch.cuda.synchronize()
+    dec, tr = [], []
+    t0 = time.perf_counter()
+    for _ in range(spec["steps"]):
+        step()
+        d_sum = t_sum = 0.0
+        for p in parts:
+            p["batch"].sync()
+            d, t = p["batch"].timing()
+            d_sum += d; t_sum += t
+        dec.append(d_sum); tr.append(t_sum)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ok, px, alg, alg_tr = True, 0, 0.0, 0.0
+    for p in parts:
+        part, plan, info = p["part"], p["plan"], p["plan"].info
+        W, H, C, BITS = part["w"], part["h"], part["channels"], part["bits"]
+        st, _ = p["batch"].status()
+        ok = ok and not st.any()
+        view = p["out"].view(len(p["blobs"]), info.out_elems)
+        chans = plan.output_channels
+        K = len(streams[spec["parts"].index(part)])
+        for k in range(K):
+            src = torch.from_numpy(photographic(W, H, C, BITS, seed=streams[spec["parts"].index(part)][k][0])).to(dev)
+            first = None
+            for i in range(k, len(p["blobs"]), K):
+                for c, oc in enumerate(chans[:C]):
+                    got = view[i, oc["offset"]: oc["offset"] + oc["w"] * oc["h"]].view(oc["h"], oc["w"])
+                    if part["kind"] != "dct420":
+                        ok = ok and bool(torch.equal(got, src[c]))
+                    elif first is None:
+                        ok = ok and (got[:H, :W].to(torch.float32) - src[c].to(torch.float32)).pow(2).mean().item() < spec.get("mse_max", 40.0)
+                if part["kind"] == "dct420":
+                    if first is None:
+                        first = view[i].clone()
+                    else:
+                        ok = ok and bool(torch.equal(view[i], first))
+        px += len(p["blobs"]) * W * H
+        alg += sum(len(b) for b in p["blobs"]) + 2.0 * info.coef_elems * len(p["blobs"])
+        alg_tr += (2.0 * info.coef_elems + 4.0 * info.out_elems) * len(p["blobs"])
+    d_avg, t_avg = float(np.mean(dec)) / 1e3, float(np.mean(tr)) / 1e3
+    res = {"workload": spec["desc"] % spec["n"], "value": round(px * spec["steps"] / 1e6 / elapsed, 3), "unit": "Mpixels/s", "steps": spec["steps"], "warmup": 1,
+           "ms_per_step": round(elapsed / spec["steps"] * 1e3, 3), "entropy_kernel_ms": round(d_avg * 1e3, 3), "transforms_ms": round(t_avg * 1e3, 3),
+           "bits_per_pixel": round(8.0 * sum(sum(len(b) for b in p["blobs"]) for p in parts) / px, 3), "parity_ok": bool(ok),
+           "parity_check": "lossless pictures == source pixels (every image); lossy ones: MSE vs source < 40 and all replicas identical; status 0",
+           "roofline": {"bound": "hbm", "kernel": "k_maniac_decode", "achieved": round(alg / max(d_avg, 1e-9) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg / max(d_avg, 1e-9) / 1e9 / HBM_PEAK_GBS, 6), "kernel_ms": round(d_avg * 1e3, 3), "algorithmic_bytes_per_launch": int(alg),
+                        "transforms": {"ms": round(t_avg * 1e3, 3), "achieved": round(alg_tr / max(t_avg, 1e-9) / 1e9, 1), "unit": "GB/s",
+                                       "frac": round(alg_tr / max(t_avg, 1e-9) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": int(alg_tr)}}}
+    for p in parts:
+        p["batch"].close()
+    del parts
+    # the reference decoder, one thread, on the same streams (bounded: at least one of each part)
+    t_cpu, px_cpu, kind = 0.0, 0, None
+    for pi, part in enumerate(spec["parts"]):
+        cb = cpu_baseline([b for _, b in streams[pi]], part["w"], part["h"], budget_s=1.5)
+        n_dec = int(cb["sample"].split()[0])
+        t_cpu += n_dec * part["w"] * part["h"] / 1e6 / cb["value"]
+        px_cpu += n_dec * part["w"] * part["h"]
+        kind = cb["kind"]
+    res["cpu_baseline"] = {"value": round(px_cpu / 1e6 / t_cpu, 4), "unit": "Mpixels/s", "cores": 1, "kind": kind,
+                           "sample": "%.1f s of full decodes (entropy + inverse transforms) of this leg's streams, at least one per kind, 1 thread" % t_cpu}
+    res["speedup_vs_cpu_1thread"] = round(res["value"] / res["cpu_baseline"]["value"], 2)
+    return res, ok
 
 
 def cpu_baseline(blobs, w, h, budget_s=25.0, source=None):
@@ -520,7 +639,7 @@ def run_streamed(args, wl, inputs, blobs, dev, dist, rank, world, W, H, C, BITS,
         raise SystemExit("PARITY FAILURE: decoded planes differ from the source pixels")
 
 
-def overlapped_steps(args, plan, blobs, dev, dist, W, H):
+def overlapped_steps(args, plan, blobs, dev, dist, W, H, index=True, warmup=None, steps=None):
     """The timed region of the default run: consecutive steps OVERLAP on the device (DESIGN.md 4.1 "overlapped launches").
 
     A launch is as long as the three long channel groups of a picture, and for its last 45 % they are all that runs: half of every
@@ -545,12 +664,13 @@ def overlapped_steps(args, plan, blobs, dev, dist, W, H):
     n_slice = args.slice if args.slice > 0 else int(max(1, min(n, (8 << 30) // (4 * max(info.out_elems, 1)))))
     streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
     outs = [torch.empty(n_slice * info.out_elems, dtype=torch.int32, device=dev) for _ in range(2)]
-    warm = max(args.warmup, 1)
-    sums = torch.zeros((warm + args.steps, n), dtype=torch.int64, device=dev)
+    warm = max(args.warmup if warmup is None else warmup, 1)
+    steps = args.steps if steps is None else steps
+    sums = torch.zeros((warm + steps, n), dtype=torch.int64, device=dev)
     cap = sum(len(b) for b in blobs) + 4096 * n
     batches = [fuif_amd.Batch(plan, n, cap, streaming=True) for _ in range(2)]
     for b, st in zip(batches, streams):
-        b.set_group_parallel(True)
+        b.set_group_parallel(index)       # (False: the streams' group index is ignored -- one wavefront per picture, what a file without the trailer gets)
         b.upload(blobs, stream=st.cuda_stream)
         b.sync(st.cuda_stream)
 
@@ -580,11 +700,11 @@ def overlapped_steps(args, plan, blobs, dev, dist, W, H):
     run(0, warm)
     fence()
     t0 = time.perf_counter()
-    run(warm, args.steps)
+    run(warm, steps)
     fence()
     elapsed = fd.max_over_ranks(time.perf_counter() - t0, dist, dev)
     ok = True
-    used = batches[: min(2, max(warm, args.steps))]
+    used = batches[: min(2, max(warm, steps))]
     for b in used:
         st_words, _ = b.status()
         ok = ok and not st_words.any()
@@ -592,7 +712,7 @@ def overlapped_steps(args, plan, blobs, dev, dist, W, H):
     for b in batches:
         b.close()
     del outs
-    return {"elapsed": elapsed, "sums": sums, "launch_ms": launch_ms, "status_ok": bool(ok), "n_slice": n_slice, "warm": warm}
+    return {"elapsed": elapsed, "sums": sums, "launch_ms": launch_ms, "status_ok": bool(ok), "n_slice": n_slice, "warm": warm, "steps": steps}
 
 
 def verify_overlapped(ov, out_ptr, out_elems, n, dev, stagger):
@@ -757,8 +877,11 @@ def main():
                          "its own launch, runs its inverse transforms and is verified through per-image checksums (overlapped_steps)")
     ap.add_argument("--overlap-stagger", type=float, default=0.0,
                     help="overlapped steps: seconds the host waits before it queues the SECOND step of a run (the first one's busy phase at 1024 x 4K; 0 = both at once)")
+    ap.add_argument("--seq-steps", type=int, default=3, help="overlapped steps of the one_wavefront_per_image leg (group index ignored; ~12 s each at 1024 x 4K)")
     ap.add_argument("--alone-steps", type=int, default=2,
                     help="overlapped steps: launches timed ALONE afterwards on the resident batch (HIP events: roofline.launch_ms_alone, the inverse transforms' time)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the small C3 / C4 / C5 legs reported as extra keys of the default line")
+    ap.add_argument("--extra-legs", default="c3,c4,c5", help="which of them to run")
     ap.add_argument("--reference-encoded", type=int, default=4,
                     help="K pictures of the workload encoded by the REFERENCE encoder (oracle/_ref/fuif, default flags) on this box, given the group index "
                          "(fuif_amd.add_group_index), replicated to the batch and decoded on the resident batch: the `reference_encoded_streams` leg (0 = skip)")
@@ -805,8 +928,21 @@ def main():
             ref_jobs = reference_encodes_start(min(args.reference_encoded, K), W, H, C, BITS, 1000, args.cache)
         except Exception:   # noqa: BLE001 -- an extra leg must not cost the bench line
             ref_jobs = None
+    # the other BASELINE configs at small sizes (extra keys of the line): their streams come out of the same pool of encoder processes
+    legs = {}
+    if args.workload == "c2" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_extra_legs and not args.chunk and not args.no_index:
+        legs = {name: spec for name, spec in EXTRA_LEGS.items() if name in args.extra_legs.split(",")}
+    specs = [(K, W, H, C, BITS, 1000 + 100 * rank, wl["kind"])]
+    for name, spec in legs.items():
+        specs += [(p["k"], p["w"], p["h"], p["channels"], p["bits"], p["seed0"], p["kind"]) for p in spec["parts"]]
     t0 = time.time()
-    inputs = make_inputs(K, W, H, C, BITS, 1000 + 100 * rank, args.cache, wl["kind"])
+    made = make_inputs_many(specs, args.cache)
+    inputs = made[0]
+    leg_streams, at = {}, 1
+    for name, spec in legs.items():
+        leg_streams[name] = made[at: at + len(spec["parts"])]
+        at += len(spec["parts"])
+    del made
     t_gen = time.time() - t0
     blobs = [inputs[i % K][1] for i in range(args.batch)]
 
@@ -849,12 +985,18 @@ def main():
     info = plan.info
     # The timed region: consecutive steps overlapped on the device (default), each verified through per-image checksums that are
     # compared below with the resident path's outputs.  --no-overlap / --no-index: the steps of the resident batch are the timed ones.
-    ov = None
+    ov = ov_seq = None
     if not args.no_overlap and not args.no_index:
         ov = overlapped_steps(args, plan, blobs, dev, dist, W, H)
         import gc
         gc.collect()
         torch.cuda.empty_cache()
+        # the same steps with the group index IGNORED (files as the reference CLI writes them: one wavefront per picture), overlapped the same way:
+        # two launches in flight = two wavefronts per SIMD, which is what the wide kernel configuration is built for since round 5
+        if world == 1 and not args.no_seq_compare:
+            ov_seq = overlapped_steps(args, plan, blobs, dev, dist, W, H, index=False, warmup=1, steps=max(2, args.seq_steps))
+            gc.collect()
+            torch.cuda.empty_cache()
     out = torch.empty(args.batch * info.out_elems, dtype=torch.int32, device=dev)
     batch = fuif_amd.Batch(plan, args.batch, int(sum(len(b) for b in blobs) * 1.03) + (1 << 20), out_ptr=out.data_ptr())   # (slack: the reference-encoded leg loads other streams)
     t0 = time.time()
@@ -901,7 +1043,7 @@ def main():
         if wl["lossless"]:
             src = torch.from_numpy(photographic(W, H, C, BITS, seed=inputs[k][0])).to(dev)
         else:
-            src = torch.from_numpy(photographic(W, H, C, BITS, seed=inputs[k][0], sigma=1.0)).to(dev)
+            src = torch.from_numpy(photographic(W, H, C, BITS, seed=inputs[k][0])).to(dev)
         for i in range(k, args.batch, K):
             for c, oc in enumerate(outs):
                 got = view[i, oc["offset"]: oc["offset"] + oc["w"] * oc["h"]].view(oc["h"], oc["w"])
@@ -918,6 +1060,14 @@ def main():
     if ov is not None:
         steps_ok, overlap_info = verify_overlapped(ov, out.data_ptr(), info.out_elems, args.batch, dev, args.overlap_stagger)
         ok = ok and steps_ok
+    seq_overlap = None
+    if ov_seq is not None:
+        seq_ok, seq_info = verify_overlapped(ov_seq, out.data_ptr(), info.out_elems, args.batch, dev, args.overlap_stagger)
+        ok = ok and seq_ok
+        seq_overlap = {"value": round(args.batch * W * H * ov_seq["steps"] / 1e6 / ov_seq["elapsed"], 3), "unit": "Mpixels/s",
+                       "ms_per_step": round(ov_seq["elapsed"] / ov_seq["steps"] * 1e3, 3), "steps": ov_seq["steps"], "warmup": ov_seq["warm"],
+                       "steps_verified": seq_info["steps_verified"], "steps_identical_to_resident_outputs": seq_info["steps_identical_to_resident_outputs"],
+                       "launch_ms_overlapped": seq_info["launch_ms_overlapped"]}
     # cross-rank exchange 1: per-image output checksums (RCCL all_gather)
     checks = fd.plane_checksums(view)
     gathered = fd.gather_checksums(checks, dist)
@@ -987,6 +1137,13 @@ def main():
                "entropy_kernel_ms": round(d, 3), "identical_output": bool(torch.equal(same, checks)) and not st2.any(),
                "note": "the rate of files as the reference CLI writes them (no FGIX trailer): one wavefront per image"}
         ok = ok and seq["identical_output"]
+        if seq_overlap is not None:
+            # the leg's figure is the overlapped one (two steps in flight, like `value`); the step alone on the device stays beside it
+            seq = dict(seq_overlap, single_launch={k: seq[k] for k in ("value", "ms_per_step", "entropy_kernel_ms", "identical_output")},
+                       identical_output=seq["identical_output"] and seq_overlap["steps_verified"] == seq_overlap["steps_identical_to_resident_outputs"],
+                       note="files as the reference CLI writes them (no FGIX trailer): one wavefront per picture; steps overlapped like the headline's (two batches in flight = two "
+                            "wavefronts per SIMD in the wide kernel configuration, 20 LDS supernodes per wavefront), every step verified through per-image checksums; "
+                            "single_launch = one step alone on the device")
 
     # The same pictures as the REFERENCE ENCODER writes them ("the same .fuif inputs"): K streams encoded on this box by the
     # unmodified reference CLI while the timed region ran, given the group index by one one-wavefront-per-picture launch (add_group_index, the
@@ -1117,22 +1274,35 @@ def main():
             h2d.update({"value_incl_h2d": serial, "note": "host parse of every stream + H2D copies from pageable memory + one step; not overlapped"})
         del separate
 
-    # roofline.traffic measured in THIS run (it used to be read from a committed profile): the batch is released first,
-    # the child processes need the device's memory for the same launch
-    live_traffic, live_src = None, None
-    if rank == 0 and world == 1 and args.workload == "c2" and not args.no_live_traffic:
-        committed = pmc_traffic(args.batch, "images" if args.no_index else "groups")[1]
+    # The big batch is released here: the small legs below and the child processes of the live traffic measurement need the device's memory.
+    want_live = rank == 0 and world == 1 and args.workload == "c2" and not args.no_live_traffic
+    if legs or want_live:
         n_tiles_keep = n_tiles
         batch.close()
         del view, out
         import gc
         gc.collect()
         torch.cuda.empty_cache()
+        n_tiles = n_tiles_keep
+    # the other BASELINE configs at small sizes, on the resident path
+    leg_results = {}
+    for name, spec in legs.items():
+        try:
+            leg_results[name], leg_ok = run_extra_leg(name, spec, leg_streams[name], dev)
+            ok = ok and leg_ok
+        except Exception as e:   # noqa: BLE001 -- reported in the line
+            leg_results[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+    # roofline.traffic measured in THIS run (it used to be read from a committed profile)
+    live_traffic, live_src = None, None
+    if want_live:
+        committed = pmc_traffic(args.batch, "images" if args.no_index else "groups")[1]
         try:
             live_traffic, live_src = live_pmc_traffic(args, committed)
         except Exception as e:   # noqa: BLE001 -- a measurement aid must not cost the bench line
             live_traffic, live_src = None, "%s: %s" % (type(e).__name__, str(e)[:200])
-        n_tiles = n_tiles_keep
 
     if rank == 0:
         S = sum(len(b) for b in blobs) / args.batch
@@ -1182,7 +1352,7 @@ def main():
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
                "config": {"workload": wl["desc"] % (args.batch, W, H),
-                          "images_per_gpu": args.batch, "distinct_images": K, "bytes_per_stream": int(S),
+                          "images_per_gpu": args.batch, "distinct_images": K, "bytes_per_stream": int(S), "bits_per_pixel": round(8.0 * S / (W * H), 3),
                           "writer": "fuif_amd/csrc/writer.cpp learned trees (default rule: 9.7 tree steps per symbol and 12.05 MB per 4K picture; "
                                     "the reference encoder's own streams of the same pictures: 9.8 and 12.03 MB)", "parity_roundtrip_ok": ok,
                           "group_index": "ignored (--no-index): one wavefront per image" if args.no_index else
@@ -1200,6 +1370,8 @@ def main():
                                     "note": "the same step alone on the device (one resident batch, steps one after the other): what --no-overlap times, and rounds 1-4's `value`"}
         if refenc is not None:
             res["reference_encoded_streams"] = refenc
+        if leg_results:
+            res["other_configs"] = leg_results
         if seq is not None:
             res["one_wavefront_per_image"] = seq
         if h2d is not None:
@@ -1214,8 +1386,7 @@ def main():
             if world > 1:
                 res["cpu_baseline"]["note"] = "speedup_vs_cpu_1thread is per GPU (value / n_gpus / cpu value)"
             if world == 1 and not args.no_cpu_all_cores:
-                name = "synth_idx2_" + wl["kind"] + "_%dx%dx%d_%dbit_seed%d.fuif"
-                paths = [os.path.join(args.cache, name % (W, H, C, BITS, seed)) for seed, _ in inputs]
+                paths = [_stream_path(args.cache, wl["kind"], W, H, C, BITS, seed) for seed, _ in inputs]
                 if all(os.path.exists(p) for p in paths):
                     allc = cpu_baseline_all_cores(paths, W, H)
                     if allc:

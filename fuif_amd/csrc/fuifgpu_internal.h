@@ -82,7 +82,10 @@ constexpr uint32_t kTileSizeClassShift = 4;   // bits 4..7: floor(log2(image sam
 constexpr int kDefaultPrioBase = 2;    // tiles holding >= 1/8 of an image: priority 3, >= 1/16: 2, >= 1/32: 1 (measured: -3 % launch time)
 
 // --- inverse-transform schedule ---------------------------------------------------------------
-enum : int { BUF_COEF = 0, BUF_OUT = 1, BUF_TMP = 2 };
+enum : int { BUF_COEF = 0, BUF_OUT = 1, BUF_TMP = 2,
+              // only in the source list of an OP_IDCT: a coded plane as the entropy kernel stored it (int16 samples in the coefficient slab, same offset as
+              // BUF_COEF) whose dequantisation is folded into the load -- sample * ChannelMeta::q of `qsrc` (planner peephole fuse_dequant_into_idct)
+              BUF_COEF16Q = 3 };
 struct PlaneRef {
     int32_t buf;
     int32_t w, h;
@@ -105,7 +108,11 @@ enum : int {
     // the last three ops of a default YCoCg + Squeeze chain in one pass (planner peephole, plan.cpp finalize()): the horizontal
     // unsqueeze of Co (src[0] avg, src[1] residual) and of Cg (src[2] avg, ext[0] residual) followed by the inverse YCoCg with
     // the finished Y plane dst[0]; R, G, B go to dst[0], dst[1], dst[2] (squeeze.h:81-132 twice + ycocg.h:49-61)
-    OP_HSQ2_YCOCG = 17
+    OP_HSQ2_YCOCG = 17,
+    // the last three ops of a JPEG-transcoded 4:2:0 chain in one pass (planner peephole fuse_upsample_ycbcr): the 2x2 "fancy" upsampling of Cb (src[1]) and
+    // Cr (src[2]) (subsample.h:90-115), the inverse YCbCr with the finished Y plane dst[0] over its p0 x p1 samples (ycbcr.h:49-60) and the final clamp of
+    // the chroma planes' samples outside that region (image.cpp:107-113); R, G, B go to dst[0], dst[1], dst[2]
+    OP_UPS2_YCBCR = 18
 };
 struct Op {
     int32_t kind;

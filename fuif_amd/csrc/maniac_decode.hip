@@ -82,13 +82,16 @@ namespace {
 
 constexpr int CH_ZERO = 0, CH_SIGN = 1, CH_EXP = 2, CH_MANT = 16, CH_N = 31;
 // Supernodes (512 B each) of the context tree kept in LDS: the kernel is built twice.
-//   kLdsWide  : 29 KB of tree per wavefront, 1 wavefront per SIMD -- best when there are no more
-//               tiles than SIMDs (streams without a group index: one tile per image)
+//   kLdsWide  : 20 supernodes = 10 KB of tree per wavefront (20 KB of LDS with the property rows): exactly TWO wavefronts per SIMD -- for launches with
+//               few tiles (streams without a group index: one tile per image).  Rounds 1-4 kept 58 supernodes (one wavefront per SIMD): a launch
+//               alone was 6 % faster (20.8 against 22.1 s for 1024 x 4K), but a lone wavefront per SIMD is latency-bound and nothing could run beside
+//               it -- with 20, two 1024-picture launches side by side take 24.5 s instead of 41.6 (693 against 408 Mpixels/s; 12 supernodes = three
+//               per SIMD: 662; profiles/r5_overlap_timeline_and_wide_variants.txt)
 //   kLdsDense : no tree in LDS (the root supernode lives in registers), 6 wavefronts per SIMD -- best when
 //               tiles abound (group index): co-resident wavefronts fill each other's stalls and every round
 //               behind the root is one memory fetch (rounds 1-3 kept two slots that served 0.9 % of the rounds)
 #ifndef FUIF_LDS_WIDE
-#define FUIF_LDS_WIDE 58
+#define FUIF_LDS_WIDE 20
 #endif
 #ifndef FUIF_LDS_DENSE
 #define FUIF_LDS_DENSE 0   // round 4: the two slots served 0.9 % of the walk rounds (profiles/r2_walk_locality.txt) and cost every round an LDS read, a compare and two branches

@@ -711,6 +711,114 @@ struct Builder {
         }
     }
 
+    // Peephole on the flat schedule (round 5): the dequantisation of a JPEG-transcoded stream (quantize.h:32-49: every coefficient plane times its q)
+    // runs over 192 planes, 189 of which -- the AC coefficient planes -- are coded planes nobody touches before and that exactly one iDCT reads
+    // afterwards.  For those the product is folded into the iDCT's load: the iDCT's source entry becomes BUF_COEF16Q (the int16 sample in the
+    // coefficient slab times ChannelMeta::q of the plane's channel) and the plane leaves the QUANT op's list -- no widened int32 copy, no in-place
+    // scaling pass, no int32 re-read (18 -> 2 bytes of traffic per AC coefficient).  The DC planes (products of the unsqueeze chain) stay in the QUANT op.
+    void fuse_dequant_into_idct() {
+        const char *e = getenv("FUIFGPU_FUSE_DEQUANT");      // read per plan: A/B measurements and tests switch it inside one process
+        if (e && atoi(e) == 0) return;
+        const char *e16 = getenv("FUIFGPU_INT16_RESIDUALS");
+        if (e16 && atoi(e16) == 0) return;
+        std::vector<Op> &ops = plan.ops;
+        auto list_of = [&](const Op &op, int *n) -> PlaneRef * {
+            *n = op.pad > 0 && (size_t)op.idct_first + (size_t)op.pad <= plan.idct_src.size() ? op.pad : 0;
+            return plan.idct_src.data() + op.idct_first;
+        };
+        auto same_plane = [](const PlaneRef &a, const PlaneRef &b) { return a.buf == b.buf && a.off == b.off; };
+        for (size_t qk = 0; qk < ops.size(); qk++) {
+            if (ops[qk].kind != OP_QUANT) continue;
+            int nq = 0;
+            list_of(ops[qk], &nq);
+            std::vector<PlaneRef> keep;
+            bool changed = false;
+            for (int li = 0; li < nq; li++) {
+                const PlaneRef pl = plan.idct_src[(size_t)ops[qk].idct_first + (size_t)li];
+                bool ok = pl.buf == BUF_COEF && (int64_t)pl.w * pl.h > 0 && pl.qsrc >= 0;
+                int uses = 0;
+                for (size_t k = 0; k < ops.size() && ok; k++) {
+                    const Op &op = ops[k];
+                    for (int d = 0; d < 3; d++) if (same_plane(op.src[d], pl) || same_plane(op.dst[d], pl)) ok = false;
+                    if (same_plane(op.ext[0], pl)) ok = false;
+                    int n = 0;
+                    const PlaneRef *l = list_of(op, &n);
+                    for (int m = 0; m < n; m++) {
+                        if (!same_plane(l[m], pl)) continue;
+                        if (k == qk) { if (m != li) ok = false; }                      // listed twice in the QUANT op
+                        else if (op.kind == OP_IDCT && k > qk) uses++;                 // the one reader we fold into
+                        else ok = false;                                               // any other op, or an iDCT BEFORE the dequantisation
+                    }
+                }
+                if (ok && uses == 1) {
+                    for (size_t k = qk + 1; k < ops.size(); k++) {
+                        if (ops[k].kind != OP_IDCT) continue;
+                        int n = 0;
+                        PlaneRef *l = list_of(ops[k], &n);
+                        for (int m = 0; m < n; m++) if (same_plane(l[m], pl)) { l[m].buf = BUF_COEF16Q; l[m].qsrc = pl.qsrc; }
+                    }
+                    changed = true;
+                } else keep.push_back(pl);
+            }
+            if (!changed) continue;
+            if (getenv("FUIFGPU_VERBOSE")) fprintf(stderr, "fuifgpu: plan %dx%d: dequantisation of %d of %d planes folded into the iDCT loads\n", plan.w, plan.h, nq - (int)keep.size(), nq);
+            ops[qk].idct_first = (int)plan.idct_src.size();
+            ops[qk].pad = (int)keep.size();
+            for (const PlaneRef &r : keep) plan.idct_src.push_back(r);
+            if (keep.empty()) { ops.erase(ops.begin() + (long)qk); qk--; }
+        }
+    }
+
+    // Peephole on the flat schedule (round 5): [UPSAMPLE 2x2 -> Cb, UPSAMPLE 2x2 -> Cr, YCBCR(Y, Cb, Cr)], the way every 4:2:0 JPEG-transcoded chain
+    // ends (subsample.h:90-115, ycbcr.h:49-60), becomes ONE op: the full-size Cb / Cr planes are never written and read back (283 -> 150 MB of plane
+    // traffic per 4K picture for these three ops).  The chroma planes may be larger than the Y plane (block padding): their samples outside the
+    // colour transform's region get the upsampled value and the final clamp, as the separate ops + image.cpp:107-113 leave them.
+    void fuse_upsample_ycbcr() {
+        const char *e = getenv("FUIFGPU_FUSE_YCBCR");
+        if (e && atoi(e) == 0) return;
+        std::vector<Op> &ops = plan.ops;
+        for (size_t k = 2; k < ops.size(); k++) {
+            const Op &c = ops[k], &u1 = ops[k - 2], &u2 = ops[k - 1];
+            if (c.kind != OP_YCBCR || u1.kind != OP_UPSAMPLE || u2.kind != OP_UPSAMPLE) continue;
+            if (u1.p0 != 2 || u1.p1 != 2 || u2.p0 != 2 || u2.p1 != 2 || u1.clamp_out || u2.clamp_out) continue;
+            auto same = [](const PlaneRef &a, const PlaneRef &b) { return a.buf == b.buf && a.off == b.off && a.w == b.w && a.h == b.h; };
+            if (!same(u1.dst[0], c.src[1]) || !same(u2.dst[0], c.src[2])) continue;
+            if (u1.src[0].w != u2.src[0].w || u1.src[0].h != u2.src[0].h || u1.src[0].w < 1 || u1.src[0].h < 1) continue;
+            if (u1.dst[0].w != 2 * u1.src[0].w || u1.dst[0].h != 2 * u1.src[0].h) continue;
+            if (c.src[0].w != c.p0 || c.src[0].h != c.p1 || c.p0 > u1.dst[0].w || c.p1 > u1.dst[0].h || c.p0 < 1 || c.p1 < 1) continue;
+            // the chroma planes must be FINAL planes whose last writer is this colour transform (no later op clamps or reads them differently)
+            // (an in-place final clamp of a chroma plane that is larger than the transform's region is folded in as well: the kernel clamps what the
+            // colour transform does not write)
+            bool later = false;
+            std::vector<size_t> clamps;
+            for (size_t m = k + 1; m < ops.size(); m++) {
+                const bool chroma_clamp = ops[m].kind == OP_CLAMP && same(ops[m].src[0], ops[m].dst[0]) && (same(ops[m].src[0], c.src[1]) || same(ops[m].src[0], c.src[2]));
+                if (chroma_clamp) { clamps.push_back(m); continue; }
+                for (int d = 0; d < 3; d++) for (int q = 0; q < 3; q++) later = later || same(ops[m].src[d], c.src[q]) || same(ops[m].dst[d], c.src[q]);
+            }
+            if (later) continue;
+            auto overlaps = [](const PlaneRef &a, const PlaneRef &b) {
+                return a.buf == b.buf && a.off < b.off + (int64_t)b.w * b.h && b.off < a.off + (int64_t)a.w * a.h;
+            };
+            const PlaneRef ins[2] = {u1.src[0], u2.src[0]}, outs[3] = {c.src[0], c.src[1], c.src[2]};
+            bool alias = false;
+            for (const PlaneRef &i : ins) for (const PlaneRef &o : outs) alias = alias || overlaps(i, o);
+            for (int a = 0; a < 3; a++) for (int b2 = a + 1; b2 < 3; b2++) alias = alias || overlaps(outs[a], outs[b2]);
+            if (alias) continue;
+            Op f{};
+            f.kind = OP_UPS2_YCBCR;
+            f.lo = c.lo; f.hi = c.hi; f.p0 = c.p0; f.p1 = c.p1;
+            f.src[0] = c.src[0]; f.src[1] = u1.src[0]; f.src[2] = u2.src[0];
+            f.dst[0] = c.src[0]; f.dst[1] = c.src[1]; f.dst[2] = c.src[2];
+            f.idct_first = c.idct_first; f.pad = 0;
+            for (size_t q = clamps.size(); q-- > 0;) ops.erase(ops.begin() + (long)clamps[q]);
+            ops[k - 2] = f;
+            ops.erase(ops.begin() + (long)(k - 1), ops.begin() + (long)(k + 1));
+            if (getenv("FUIFGPU_VERBOSE")) fprintf(stderr, "fuifgpu: plan %dx%d: chroma upsampling + YCbCr fused into one op (%zu ops)\n", plan.w, plan.h, ops.size());
+            return;   // one YCbCr per chain
+        }
+    }
+
     // The coefficient slab holds int16 samples; the inverse kernels work on int32 planes.  Most coded samples are Squeeze residuals, each
     // read exactly once by the unsqueeze that consumes it: those kernels take them as int16 straight from the slab (Op::r16).  Every other
     // coded plane an op touches -- the lowest-resolution averages, DCT coefficients, palette / match / permutation planes, anything an
@@ -825,6 +933,10 @@ struct Builder {
             int pl = ch.plane;
             int lw = last_writer[pl], lk = last_kind[pl];
             bool range_ok = (lk == OP_YCBCR) || (lk == OP_YCOCG && plan.minval == 0);
+            // (the colour transforms clamp what they write -- the p0 x p1 samples of the first channel's geometry.  A chroma plane that is larger
+            // than that, block padding of a subsampled JPEG whose size is no multiple of 16, keeps samples they never touch: those need the final
+            // clamp of image.cpp:107-113 like any other -- round 5; rounds 1-4 skipped it: no stream at hand leaves those samples out of range, so no fixture noticed)
+            if (range_ok && lw >= 0 && ((int64_t)planes[pl].w != (int64_t)ops[lw].p0 || (int64_t)planes[pl].h != (int64_t)ops[lw].p1)) range_ok = false;
             if (range_ok) continue;
             if (lw >= 0 && planes[pl].birth == lw &&
                 (lk == OP_HSQUEEZE || lk == OP_VSQUEEZE || lk == OP_IDCT || lk == OP_UPSAMPLE || lk == OP_COPY_CLAMP || lk == OP_PALETTE || lk == OP_PERMUTE)) {
@@ -868,6 +980,8 @@ struct Builder {
             plan.ops.push_back(op);
         }
         fuse_chroma_hsqueeze_ycocg();
+        fuse_upsample_ycbcr();
+        fuse_dequant_into_idct();
         mark_int16_residuals();
         plan.outputs.clear();
         for (auto &ch : live) {

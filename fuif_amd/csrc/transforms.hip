@@ -731,7 +731,10 @@ DEV void idct_1d(const double (&in)[8], double (&out)[8]) {
         out[o] = acc;
     }
 }
-__global__ __launch_bounds__(64) void k_idct8x8(Bases b, const PlaneRef *list, PlaneRef po, int bw, int bh, int maxval, int clamp, int lo, int hi) {
+// A source plane of kind BUF_COEF16Q (planner peephole fuse_dequant_into_idct) is a coded plane as the entropy kernel stored it: the int16 sample is
+// read from the coefficient slab and multiplied by the channel's quantisation constant on the way in (quantize.h:32-49 folded into the load).
+__global__ __launch_bounds__(64) void k_idct8x8(Bases b, const PlaneRef *list, PlaneRef po, int bw, int bh, int maxval, int clamp, int lo, int hi,
+                                                const ChannelMeta *meta, int n_channels, int img_first) {
     const int bx = blockIdx.x * blockDim.x + threadIdx.x;
     const int by = blockIdx.y;
     if (bx >= bw || by >= bh) return;
@@ -743,7 +746,11 @@ __global__ __launch_bounds__(64) void k_idct8x8(Bases b, const PlaneRef *list, P
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const PlaneRef p = list[u * 8 + x];
-            const int v = plane_ptr(b, p, blockIdx.z)[(int64_t)by * p.w + bx];
+            int v;
+            if (p.buf == BUF_COEF16Q)
+                v = (int)(b.c16 + (int64_t)blockIdx.z * b.stride[BUF_COEF] + p.off)[(int64_t)by * p.w + bx] * meta[(int64_t)(img_first + blockIdx.z) * n_channels + p.qsrc].q;
+            else
+                v = plane_ptr(b, p, blockIdx.z)[(int64_t)by * p.w + bx];
             col[u] = (u == 0 && x == 0) ? (double)__fadd_rn((float)v, dcoff) : (double)v;
         }
         idct_1d(col, res);
@@ -840,6 +847,74 @@ __global__ __launch_bounds__(256) void k_upsample_2x2(Bases b, PlaneRef pi, Plan
     } else {
         o[0] = v00;
         if (two_rows) o[po.w] = v10;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// OP_UPS2_YCBCR: 4:2:0 chroma upsampling (k_upsample_2x2's arithmetic, subsample.h:90-115) + inverse YCbCr (k_inv_ycbcr's arithmetic, ycbcr.h:49-60) in
+// one pass.  One lane per chroma INPUT sample owning its 2x2 outputs: 9 + 9 L1-shared chroma loads and two 8-byte loads of Y for 4 pixels, six 8-byte
+// stores; the full-size Cb / Cr planes are never written and read back.  Output samples of the chroma planes outside the colour transform's w x h
+// region (block padding) get the upsampled value, clamped to [lo, hi] like the final clamp of image.cpp:107-113 leaves them.
+__global__ __launch_bounds__(256) void k_ups2_ycbcr(Bases b, PlaneRef py, PlaneRef pcb, PlaneRef pcr, PlaneRef o0, PlaneRef o1, PlaneRef o2, int w, int h, int lo, int hi) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int cw = pcb.w, ch = pcb.h;
+    if (x >= cw) return;
+    const int32_t *cb_in = plane_ptr(b, pcb, blockIdx.z), *cr_in = plane_ptr(b, pcr, blockIdx.z);
+    const int xm = x ? x - 1 : 0, xp = x + 1 < cw ? x + 1 : x;
+    const int ym = y ? y - 1 : 0, yp = y + 1 < ch ? y + 1 : y;
+    int cbv[4], crv[4];     // [row][column] of the 2x2 outputs
+    auto up = [&](const int32_t *in, int (&v)[4]) {
+        auto hrow = [&](int yy, int &he, int &ho) {
+            const int32_t *r = in + (int64_t)yy * cw;
+            const int c = r[x];
+            he = (3 * c + r[xm] + 1) >> 2;
+            ho = (3 * c + r[xp] + 2) >> 2;
+        };
+        int me, mo, ce, co, pe, po2;
+        hrow(ym, me, mo); hrow(y, ce, co); hrow(yp, pe, po2);
+        v[0] = (3 * ce + me + 1) >> 2; v[1] = (3 * co + mo + 1) >> 2;      // row 2y: with the row above
+        v[2] = (3 * ce + pe + 2) >> 2; v[3] = (3 * co + po2 + 2) >> 2;     // row 2y + 1: with the row below
+    };
+    up(cb_in, cbv); up(cr_in, crv);
+    const float half = (float)((hi + 1) / 2);
+    const double mn = (double)lo, mx = (double)hi;
+    int32_t *Yp = plane_ptr(b, py, blockIdx.z), *O0 = plane_ptr(b, o0, blockIdx.z), *O1 = plane_ptr(b, o1, blockIdx.z), *O2 = plane_ptr(b, o2, blockIdx.z);
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int Y = 2 * y + r;
+        int out0[2], out1[2], out2[2];
+        bool in_region[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int X = 2 * x + c;
+            in_region[c] = X < w && Y < h;
+            const int cb_i = cbv[2 * r + c], cr_i = crv[2 * r + c];
+            if (in_region[c]) {
+                const float yy = (float)Yp[(int64_t)Y * py.w + X];
+                const float cb = __fsub_rn((float)cb_i, half);
+                const float cr = __fsub_rn((float)cr_i, half);
+                const double dy = (double)yy, dcb = (double)cb, dcr = (double)cr;
+                double rr = __dadd_rn(__dadd_rn(dy, __dmul_rn(1.402, dcr)), 0.5);
+                double g = __dadd_rn(__dsub_rn(__dsub_rn(dy, __dmul_rn(0.344136, dcb)), __dmul_rn(0.714136, dcr)), 0.5);
+                double bl = __dadd_rn(__dadd_rn(dy, __dmul_rn(1.772, dcb)), 0.5);
+                rr = rr < mn ? mn : (rr > mx ? mx : rr);
+                g = g < mn ? mn : (g > mx ? mx : g);
+                bl = bl < mn ? mn : (bl > mx ? mx : bl);
+                out0[c] = (int)rr; out1[c] = (int)g; out2[c] = (int)bl;
+            } else {
+                out0[c] = 0; out1[c] = clampi(cb_i, lo, hi); out2[c] = clampi(cr_i, lo, hi);
+            }
+        }
+        // (the chroma planes are 2cw x 2ch, so both columns and both rows exist there; the Y plane only has the region)
+        int32_t *d1 = O1 + (int64_t)Y * o1.w + 2 * x, *d2 = O2 + (int64_t)Y * o2.w + 2 * x;
+        Int2U a1; a1.v[0] = out1[0]; a1.v[1] = out1[1];
+        Int2U a2; a2.v[0] = out2[0]; a2.v[1] = out2[1];
+        *reinterpret_cast<Int2U *>(d1) = a1;
+        *reinterpret_cast<Int2U *>(d2) = a2;
+        int32_t *d0 = O0 + (int64_t)Y * o0.w + 2 * x;
+        if (in_region[0] && in_region[1]) { Int2U a0; a0.v[0] = out0[0]; a0.v[1] = out0[1]; *reinterpret_cast<Int2U *>(d0) = a0; }
+        else if (in_region[0]) d0[0] = out0[0];
     }
 }
 
@@ -1035,7 +1110,12 @@ void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMe
         }
         case OP_IDCT:
             hipLaunchKernelGGL(k_idct8x8, dim3((op.p0 + 63) / 64, op.p1, n_images), dim3(64), 0, stream, b, dev_list + op.idct_first, op.dst[0],
-                               op.p0, op.p1, op.hi, op.clamp_out, op.lo, op.hi);
+                               op.p0, op.p1, op.hi, op.clamp_out, op.lo, op.hi, meta, n_channels, img_first);
+            break;
+        case OP_UPS2_YCBCR:
+            if (op.src[1].w <= 0 || op.src[1].h <= 0) break;
+            hipLaunchKernelGGL(k_ups2_ycbcr, dim3((op.src[1].w + 255) / 256, op.src[1].h, n_images), dim3(256), 0, stream, b, op.src[0], op.src[1], op.src[2],
+                               op.dst[0], op.dst[1], op.dst[2], op.p0, op.p1, op.lo, op.hi);
             break;
         case OP_UPSAMPLE:
             if (op.p0 == 2 && op.p1 == 2)

@@ -64,3 +64,38 @@ def test_overlapped_steps_decode_and_verify_every_step(tmp_path, damage):
         assert line["ok"] is False and line["info"]["steps_identical_to_resident_outputs"] == 0
     else:
         assert line["ok"] is True and line["info"]["steps_identical_to_resident_outputs"] == 4
+
+
+LEG_DRIVER = r'''
+import json, sys
+sys.path.insert(0, %(root)r)
+import torch
+import bench
+
+torch.cuda.synchronize = lambda *a, **k: None
+torch.cuda.empty_cache = lambda *a, **k: None
+spec = dict(desc="test leg: %%d mixed pictures", n=6, steps=2, mse_max=150.0,     # (tiny pictures: the generator's sinusoids are steep there)
+            parts=[dict(kind="squeeze", w=97, h=61, channels=3, bits=8, k=2, seed0=3000), dict(kind="dct420", w=112, h=64, channels=3, bits=8, k=2, seed0=4000)])
+streams = bench.make_inputs_many([(p["k"], p["w"], p["h"], p["channels"], p["bits"], p["seed0"], p["kind"]) for p in spec["parts"]], %(cache)r)
+if %(damage)d:
+    streams[0][1] = (streams[0][1][0] + 5, streams[0][1][1])      # the wrong source picture for one lossless stream: the leg must notice
+res, ok = bench.run_extra_leg("t", spec, streams, torch.device("cpu"))
+print(json.dumps({"ok": ok, "res": res}))
+'''
+
+
+@pytest.mark.parametrize("damage", [0, 1])
+def test_extra_leg_of_the_default_line(tmp_path, damage):
+    """run_extra_leg (the small C3 / C4 / C5 legs of the default bench line) on the emulator: two kinds in one leg, a rate, roofline,
+    parity against the generator's pixels and a CPU baseline from the reference / the oracle on the same streams"""
+    if sys.platform != "linux" or os.uname().machine != "x86_64":
+        pytest.skip("the emulator's context switch is x86-64 SysV assembly")
+    from test_emulated_kernels import build_emulated_library
+    env = dict(os.environ, FUIF_AMD_LIB=build_emulated_library(), EMU_ALARM="600")
+    r = subprocess.run([sys.executable, "-c", LEG_DRIVER % dict(root=ROOT, cache=str(tmp_path / "cache"), damage=damage)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-1500:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["ok"] is (not damage) and line["res"]["parity_ok"] is (not damage)
+    res = line["res"]
+    assert res["steps"] == 2 and res["value"] > 0 and res["roofline"]["bound"] == "hbm" and res["roofline"]["algorithmic_bytes_per_launch"] > 0
+    assert res["cpu_baseline"]["cores"] == 1 and res["cpu_baseline"]["value"] > 0 and res["cpu_baseline"]["kind"] in ("reference", "port")

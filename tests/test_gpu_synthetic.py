@@ -321,3 +321,26 @@ def test_streaming_batch_undoes_transforms_range_by_range(gpulib, port):
                     batch.out_planes(0)
         finally:
             batch.close()
+
+
+@pytest.mark.parametrize("w,h,quality,sigma", [(97, 61, 90, 3.0), (130, 70, 40, 40.0), (256, 192, 90, 3.0)])
+def test_jpeg_like_chain_fused_and_unfused_match_oracle(gpulib, port, w, h, quality, sigma, monkeypatch):
+    """the JPEG-transcode chain (Squeeze of DC, Quantize, DCT, 4:2:0 ChromaSubsampling, YCbCr) with and without the round-5 planner
+    peepholes -- dequantisation folded into the iDCT's int16 loads (fuse_dequant_into_idct), chroma upsampling + YCbCr + the final
+    clamp of the padded chroma samples in one kernel (fuse_upsample_ycbcr) -- against the oracle, plane by plane.  Sizes that are
+    no multiples of 16 leave chroma planes LARGER than the Y plane: their samples outside the colour transform's region keep the
+    upsampled value and get the final clamp of image.cpp:107-113 (rounds 1-4 left that clamp out for planes the colour transform
+    wrote last; no stream at hand drives those samples out of range, the planner now clamps them whatever they hold)."""
+    from fuif_amd.jpeglike import encode_jpeg_like
+    img = photographic(w, h, 3, 8, seed=900 + w, sigma=sigma)
+    blob = encode_jpeg_like(img, quality, True, index=True)
+    d_pre, d_post = port.decode_both(blob)
+    for fuse_q, fuse_c in ((1, 1), (0, 0), (1, 0), (0, 1)):
+        monkeypatch.setenv("FUIFGPU_FUSE_DEQUANT", str(fuse_q))
+        monkeypatch.setenv("FUIFGPU_FUSE_YCBCR", str(fuse_c))
+        pre, post, st, used = gpu_decode(gpulib, [blob, blob])
+        assert not st.any()
+        for planes in post:
+            assert len(planes) == len(d_post.channels)
+            for i, (g, e) in enumerate(zip(planes, d_post.channels)):
+                assert np.array_equal(g, e["data"]), (fuse_q, fuse_c, i)

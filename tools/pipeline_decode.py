@@ -106,9 +106,49 @@ def run(pipelined):
     return dt
 
 
+tile_log = "--tile-log" in argv      # (a -DFUIF_TILELOG build: tools/build_variant.sh tilelog -DFUIF_TILELOG)
+if tile_log:
+    for b in batches:
+        b.tile_log()                 # arms logging
 for mode in ((True,) if "--only-pipelined" in argv else (False, True)) * rounds:
     dt = run(mode)
     print("%s: %d launches of %d x %dx%d in %.2f s -> %.2f s per launch, %.1f Mpixels/s (%s)" % (
         "pipelined (two streams, stagger %.1f s)" % stagger if mode else "sequential", K, n, w, h, dt, dt / K, K * px / dt / 1e6,
         "entropy + inverse transforms; last output slices %s" % "/".join(last_slice_hash()) if with_tr else "entropy only"), flush=True)
 print("last launches by their own events: %.0f / %.0f ms" % (batches[0].timing()[0], batches[1].timing()[0]))
+
+if tile_log:
+    # the LAST launch of each batch object on one time axis (the log's ticks are the device's 100 MHz real-time counter): per launch and per
+    # channel group class when its tiles start / end and how long they ran; wavefront slots in use by each launch over time
+    import numpy as np
+    logs = [b.tile_log() for b in batches]
+    base = min(int(l[:, 1].min()) for l in logs)
+    nch = plan.info.nb_coded_channels
+    sizes = np.array([c["w"] * c["h"] for c in plan.coded_channels], np.float64)
+    long_ch = [c for c in range(nch) if sizes[c] >= sizes.max() * 0.99]
+    print("long channel groups:", long_ch)
+    rows = []
+    for k, l in enumerate(logs):
+        ch = (l[:, 0] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        t0 = (l[:, 1].astype(np.int64) - base) / 1e5
+        t1 = (l[:, 2].astype(np.int64) - base) / 1e5
+        run = (l[:, 3] & np.uint64(0xFFFFFFFFFFFF)).astype(np.float64) / 1e5
+        is_long = np.isin(ch, long_ch)
+        rows.append((t0, t1, run, is_long, ch))
+        print("launch on batch %d: tiles %d, first start %.0f ms, last end %.0f ms" % (k, len(l), t0.min(), t1.max()))
+        for name, m in (("long", is_long), ("short", ~is_long)):
+            print("   %-5s tiles: start mean %.0f (min %.0f max %.0f)  end mean %.0f (max %.0f)  running %.0f ms mean of %.0f ms lifetime; sum of running time %.0f wavefront-s" % (
+                name, t0[m].mean(), t0[m].min(), t0[m].max(), t1[m].mean(), t1[m].max(), run[m].mean(), (t1[m] - t0[m]).mean(), run[m].sum() / 1e3))
+        for c in long_ch + [c for c in range(nch) if sizes[c] >= sizes.max() * 0.2 and c not in long_ch]:
+            m = ch == c
+            print("   c%-3d start %.0f end %.0f (max %.0f) running %.0f of %.0f ms" % (c, t0[m].mean(), t1[m].mean(), t1[m].max(), run[m].mean(), (t1[m] - t0[m]).mean()))
+    T = max(r[1].max() for r in rows)
+    print("tiles alive (started, not ended) over time: launch 0 long/short | launch 1 long/short")
+    for q in np.linspace(0, T, 41)[:-1]:
+        parts = []
+        for t0, t1, run, is_long, ch in rows:
+            alive = (t0 <= q) & (t1 > q)
+            parts.append("%5d /%6d" % (int((alive & is_long).sum()), int((alive & ~is_long).sum())))
+        print("  t=%7.0f ms   %s" % (q, "  |  ".join(parts)))
+    if os.environ.get("TILE_LOG_NPY"):
+        np.save(os.environ["TILE_LOG_NPY"], np.stack([np.pad(l, ((0, max(len(x) for x in logs) - len(l)), (0, 0))) for l in logs]))
