@@ -664,7 +664,7 @@ def overlapped_steps(args, plan, blobs, dev, dist, W, H, index=True, warmup=None
     n_slice = args.slice if args.slice > 0 else int(max(1, min(n, (8 << 30) // (4 * max(info.out_elems, 1)))))
     streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
     outs = [torch.empty(n_slice * info.out_elems, dtype=torch.int32, device=dev) for _ in range(2)]
-    warm = max(args.warmup if warmup is None else warmup, 1)
+    warm = max(args.warmup, 1) if warmup is None else max(warmup, 0)
     steps = args.steps if steps is None else steps
     sums = torch.zeros((warm + steps, n), dtype=torch.int64, device=dev)
     cap = sum(len(b) for b in blobs) + 4096 * n
@@ -697,7 +697,8 @@ def overlapped_steps(args, plan, blobs, dev, dist, W, H, index=True, warmup=None
             b.sync(st.cuda_stream)
 
     torch.cuda.synchronize()
-    run(0, warm)
+    if warm:
+        run(0, warm)
     fence()
     t0 = time.perf_counter()
     run(warm, steps)
@@ -877,7 +878,7 @@ def main():
                          "its own launch, runs its inverse transforms and is verified through per-image checksums (overlapped_steps)")
     ap.add_argument("--overlap-stagger", type=float, default=0.0,
                     help="overlapped steps: seconds the host waits before it queues the SECOND step of a run (the first one's busy phase at 1024 x 4K; 0 = both at once)")
-    ap.add_argument("--seq-steps", type=int, default=3, help="overlapped steps of the one_wavefront_per_image leg (group index ignored; ~12 s each at 1024 x 4K)")
+    ap.add_argument("--seq-steps", type=int, default=4, help="overlapped steps of the one_wavefront_per_image leg (group index ignored; ~12 s each at 1024 x 4K)")
     ap.add_argument("--alone-steps", type=int, default=2,
                     help="overlapped steps: launches timed ALONE afterwards on the resident batch (HIP events: roofline.launch_ms_alone, the inverse transforms' time)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the small C3 / C4 / C5 legs reported as extra keys of the default line")
@@ -994,7 +995,8 @@ def main():
         # the same steps with the group index IGNORED (files as the reference CLI writes them: one wavefront per picture), overlapped the same way:
         # two launches in flight = two wavefronts per SIMD, which is what the wide kernel configuration is built for since round 5
         if world == 1 and not args.no_seq_compare:
-            ov_seq = overlapped_steps(args, plan, blobs, dev, dist, W, H, index=False, warmup=1, steps=max(2, args.seq_steps))
+            # (no warm-up step: the kernels have just run; an EVEN number of steps, so that every step has a partner beside it -- a step alone is 22 s)
+            ov_seq = overlapped_steps(args, plan, blobs, dev, dist, W, H, index=False, warmup=0, steps=max(2, args.seq_steps + (args.seq_steps & 1)))
             gc.collect()
             torch.cuda.empty_cache()
     out = torch.empty(args.batch * info.out_elems, dtype=torch.int32, device=dev)

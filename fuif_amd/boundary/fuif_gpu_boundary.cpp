@@ -249,9 +249,20 @@ bool fuif_encode_file(const char *filename, const Image &image, fuif_options &op
         if (rc == FUIFGPU_OK) rc = fuifgpu_index_append(bytes.data(), bytes.size(), first.data(), start.data(), ng, &indexed, &indexed_size);
     }
     if (rc == FUIFGPU_OK) {
-        FILE *f = fopen(filename, "wb");
-        if (f) { fwrite(indexed, 1, indexed_size, f); fclose(f); }
-        if (env_flag("FUIFGPU_VERBOSE")) fprintf(stderr, "fuifgpu: %s: group index of %d groups appended (%zu + %zu bytes)\n", filename, ng, bytes.size(), indexed_size - bytes.size());
+        // the indexed stream = the file's own bytes + the trailer: only the trailer is APPENDED, so a short write (disk full) can never damage
+        // the valid file the reference encoder has just written -- at worst it ends in an incomplete trailer, which the reader ignores
+        bool appended = indexed_size >= bytes.size() && !memcmp(indexed, bytes.data(), bytes.size());
+        if (appended) {
+            FILE *f = fopen(filename, "ab");
+            appended = f != nullptr;
+            if (f) {
+                const size_t extra = indexed_size - bytes.size();
+                appended = fwrite(indexed + bytes.size(), 1, extra, f) == extra;
+                appended = (fclose(f) == 0) && appended;
+            }
+        }
+        if (!appended) fprintf(stderr, "fuifgpu: %s: the group index could not be appended (write failed); the file is as the encoder wrote it\n", filename);
+        else if (env_flag("FUIFGPU_VERBOSE")) fprintf(stderr, "fuifgpu: %s: group index of %d groups appended (%zu + %zu bytes)\n", filename, ng, bytes.size(), indexed_size - bytes.size());
     } else {
         fprintf(stderr, "fuifgpu: %s written without group index (%s)\n", filename, status ? "the decode was flagged" : fuifgpu_last_error());
     }

@@ -47,6 +47,14 @@ int main(int argc, char **argv) {
     const std::string outdir = argv[1];
     const int n = argc - 2;
     char **names = argv + 2;
+    // two inputs of one basename (from different directories) would land on one output file and the second would silently replace the
+    // first: refused before anything is written
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < i; k++)
+            if (out_name(outdir, names[i]) == out_name(outdir, names[k])) {
+                fprintf(stderr, "%s and %s would both be written to %s: give files of one name separate runs / output directories\n", names[k], names[i], out_name(outdir, names[i]).c_str());
+                return 2;
+            }
     std::vector<std::vector<uint8_t>> bytes((size_t)n);
     std::vector<fuifgpu_plan *> plans((size_t)n, nullptr);
     std::map<uint64_t, std::vector<int>> groups;   // plan signature -> files

@@ -644,11 +644,13 @@ int fuifgpu_batch_undo_transforms_to(fuifgpu_batch *b, int first_image, int n_im
     if ((int)b->undone.size() != b->n_loaded) b->undone.assign((size_t)b->n_loaded, 0);
     for (int i = first_image; i < first_image + n_images; i++)
         if (b->undone[i]) { g_last_error = "fuifgpu_batch_undo_transforms_to: an image of the range has been through the inverse transforms already (once per decode)"; return FUIFGPU_E_ARG; }
-    for (int i = first_image; i < first_image + n_images; i++) b->undone[i] = 1;
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipEventRecord(b->ev[2], st));
     const int rc = undo_range(b, first_image, n_images, out_device, st);
+    // (marked only once the range has been queued: a call that failed -- a HIP error, after which the decode's metadata is not to be trusted anyway -- does not
+    // make the range unreachable for the caller's retry after the next decode)
     if (rc != FUIFGPU_OK) return rc;
+    for (int i = first_image; i < first_image + n_images; i++) b->undone[i] = 1;
     HIPCHK(hipEventRecord(b->ev[3], st));
     b->transform_timed = true;
     return FUIFGPU_OK;

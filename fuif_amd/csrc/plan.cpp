@@ -762,6 +762,7 @@ struct Builder {
             }
             if (!changed) continue;
             if (getenv("FUIFGPU_VERBOSE")) fprintf(stderr, "fuifgpu: plan %dx%d: dequantisation of %d of %d planes folded into the iDCT loads\n", plan.w, plan.h, nq - (int)keep.size(), nq);
+            for (int li = 0; li < nq; li++) plan.idct_src[(size_t)ops[qk].idct_first + (size_t)li].buf = -1;   // the old list is dead: nobody may widen its planes on its account
             ops[qk].idct_first = (int)plan.idct_src.size();
             ops[qk].pad = (int)keep.size();
             for (const PlaneRef &r : keep) plan.idct_src.push_back(r);
@@ -865,10 +866,18 @@ struct Builder {
             if (!op.r16) continue;
             auto listed = [&](const PlaneRef &r) { for (const PlaneRef &l : plan.idct_src) if (l.buf == BUF_COEF && l.off == r.off) return true; return false; };
             if (op.kind == OP_QUANT) continue;
-            if (listed(op.src[1]) || (op.kind == OP_HSQ2_YCOCG && listed(op.ext[0]))) { op.r16 = 0; want_unless_made(op.src[1]); want_unless_made(op.ext[0]); }
+            // (want(), not want_unless_made(): a plane "made" by a dequantisation that runs LATER in the schedule than this squeeze would be neither widened
+            // nor written yet when the squeeze reads it.  No transform chain produces that order today; a wasted copy is the price of not relying on it -- ADVICE r4)
+            if (listed(op.src[1]) || (op.kind == OP_HSQ2_YCOCG && listed(op.ext[0]))) { op.r16 = 0; want(op.src[1]); want(op.ext[0]); }
         }
         plan.widen.clear();
         for (auto &n : need) { plan.widen.push_back(n.first); plan.widen.push_back(n.second); }
+        if (getenv("FUIFGPU_VERBOSE")) {
+            int64_t samples = 0;
+            for (auto &n : need) samples += n.second;
+            fprintf(stderr, "fuifgpu: plan %dx%d: %zu coded planes (%lld of %lld coded samples) are widened to int32 before the inverse schedule\n", plan.w, plan.h, need.size(),
+                    (long long)samples, (long long)plan.coef_elems);
+        }
     }
 
     bool finalize() {

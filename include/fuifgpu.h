@@ -93,7 +93,8 @@ int fuifgpu_batch_create_streaming(const fuifgpu_plan *plan, int n_images, size_
 /* Image::undo_transforms(0) for images [first_image, first_image + n_images) of the current decode; their output planes go to
  * out_device (n_images * out_elems int32, device memory; plan output-channel offsets apply inside each image's slice).  Any
  * batch takes it; every image once per decode (a range that repeats an image, or a mix with fuifgpu_batch_undo_transforms, is
- * FUIFGPU_E_ARG). */
+ * FUIFGPU_E_ARG).  A range counts as done once the call has queued it; after a failed call (a HIP error) decode again before
+ * retrying.  fuifgpu_batch_last_timing's transform_ms is the time of the LAST call's range, not of all ranges of a decode. */
 int fuifgpu_batch_undo_transforms_to(fuifgpu_batch *batch, int first_image, int n_images, int32_t *out_device, void *stream);
 
 /* A second set of stream buffers for the SAME slabs, so that the upload of the next batch (host parse + H2D copies, on a copy

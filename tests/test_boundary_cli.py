@@ -319,6 +319,11 @@ def check_index_tool(run_index, run_gpu_cli, run_ref, tmp_path):
     assert r.returncode == 0 and "0 file(s) indexed, %d copied unchanged" % len(names) in r.stderr, r.stderr[-400:]
     for n in names:
         assert open(str(again / (n + ".fuif")), "rb").read() == open(str(outdir / (n + ".fuif")), "rb").read()
+    # two inputs of one basename would land on one output file: refused before anything is written
+    clash = tmp_path / "clash"
+    clash.mkdir()
+    r = run_index([str(clash), os.path.join(GOLDEN, names[0] + ".fuif"), str(outdir / (names[0] + ".fuif"))])
+    assert r.returncode == 2 and "would both be written" in r.stderr and not os.listdir(str(clash)), r.stderr[-400:]
 
 
 def check_encoder_writes_index(run_gpu_cli_env, run_ref, tmp_path):
