@@ -663,7 +663,9 @@ def overlapped_steps(args, plan, blobs, dev, dist, W, H, index=True, warmup=None
     info = plan.info
     n_slice = args.slice if args.slice > 0 else int(max(1, min(n, (8 << 30) // (4 * max(info.out_elems, 1)))))
     streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-    outs = [torch.empty(n_slice * info.out_elems, dtype=torch.int32, device=dev) for _ in range(2)]
+    # (zeros, not empty: planes are 256-byte aligned inside an image's slice and no kernel writes the gaps between them -- the per-image checksum covers
+    # the whole slice, so the gaps must hold the same thing here and in the resident path's slab; a 3840x2160 plane happens to leave none)
+    outs = [torch.zeros(n_slice * info.out_elems, dtype=torch.int32, device=dev) for _ in range(2)]
     warm = max(args.warmup, 1) if warmup is None else max(warmup, 0)
     steps = args.steps if steps is None else steps
     sums = torch.zeros((warm + steps, n), dtype=torch.int64, device=dev)
@@ -999,7 +1001,7 @@ def main():
             ov_seq = overlapped_steps(args, plan, blobs, dev, dist, W, H, index=False, warmup=0, steps=max(2, args.seq_steps + (args.seq_steps & 1)))
             gc.collect()
             torch.cuda.empty_cache()
-    out = torch.empty(args.batch * info.out_elems, dtype=torch.int32, device=dev)
+    out = torch.zeros(args.batch * info.out_elems, dtype=torch.int32, device=dev)     # (zeros: see overlapped_steps -- the checksums cover the alignment gaps between planes)
     batch = fuif_amd.Batch(plan, args.batch, int(sum(len(b) for b in blobs) * 1.03) + (1 << 20), out_ptr=out.data_ptr())   # (slack: the reference-encoded leg loads other streams)
     t0 = time.time()
     batch.set_group_parallel(not args.no_index)

@@ -108,6 +108,7 @@ ABI_SYMBOLS = [
     "fuifgpu_index_parse", "fuifgpu_index_append", "fuifgpu_batch_group_index", "fuifgpu_batch_set_group_parallel",
     "fuifgpu_plan_packed_bytes", "fuifgpu_batch_pack_out", "fuifgpu_batch_download_packed",
     "fuifgpu_dev_alloc", "fuifgpu_dev_free", "fuifgpu_dev_upload", "fuifgpu_dev_download",
+    "fuifgpu_plane_checksums", "fuifgpu_device_count", "fuifgpu_set_device", "fuifgpu_get_device", "fuifgpu_batch_device", "fuifgpu_peer_copy",
 ]
 
 

@@ -737,6 +737,15 @@ __global__ __launch_bounds__(64) void k_idct8x8(Bases b, const PlaneRef *list, P
                                                 const ChannelMeta *meta, int n_channels, int img_first) {
     const int bx = blockIdx.x * blockDim.x + threadIdx.x;
     const int by = blockIdx.y;
+    // The quantisation constants of the 64 source planes, one per lane, parked in LDS: the column loop below reads them with constant offsets.
+    // (Fetched with scalar loads inside the loop -- plane descriptor, then q, two dependent round trips per plane behind the per-column
+    // scheduling barrier -- the folded dequantisation doubled the kernel's time: 23 -> 45 ms per C3 step, profiles/r5_c3_kernel_stats.csv.)
+    __shared__ int qs[64];
+    {
+        const PlaneRef pl = list[threadIdx.x];
+        qs[threadIdx.x] = (pl.buf == BUF_COEF16Q && meta) ? meta[(int64_t)(img_first + blockIdx.z) * n_channels + pl.qsrc].q : 1;
+    }
+    __syncthreads();
     if (bx >= bw || by >= bh) return;
     const float dcoff = (float)(((double)maxval + 1.0) * 4.0);
     double tmp[64];   // [output row o][column x] after the column pass
@@ -748,7 +757,7 @@ __global__ __launch_bounds__(64) void k_idct8x8(Bases b, const PlaneRef *list, P
             const PlaneRef p = list[u * 8 + x];
             int v;
             if (p.buf == BUF_COEF16Q)
-                v = (int)(b.c16 + (int64_t)blockIdx.z * b.stride[BUF_COEF] + p.off)[(int64_t)by * p.w + bx] * meta[(int64_t)(img_first + blockIdx.z) * n_channels + p.qsrc].q;
+                v = (int)(b.c16 + (int64_t)blockIdx.z * b.stride[BUF_COEF] + p.off)[(int64_t)by * p.w + bx] * qs[u * 8 + x];
             else
                 v = plane_ptr(b, p, blockIdx.z)[(int64_t)by * p.w + bx];
             col[u] = (u == 0 && x == 0) ? (double)__fadd_rn((float)v, dcoff) : (double)v;

@@ -63,7 +63,7 @@ def test_overlapped_steps_decode_and_verify_every_step(tmp_path, damage):
     if damage:
         assert line["ok"] is False and line["info"]["steps_identical_to_resident_outputs"] == 0
     else:
-        assert line["ok"] is True and line["info"]["steps_identical_to_resident_outputs"] == 4
+        assert line["ok"] is True and line["info"]["steps_identical_to_resident_outputs"] == 4, line
 
 
 LEG_DRIVER = r'''
