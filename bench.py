@@ -369,7 +369,7 @@ def cpu_baseline_all_cores(paths, w, h, seconds=6.0):
 
 def pmc_traffic(batch, mode):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r*_pmc_traffic.json, collected with tools/collect_profiles.sh); None if no profile
+    (profiles/r*_pmc_traffic.json, collected with tools/experiments/collect_profiles.sh); None if no profile
     of this batch size exists."""
     import glob
     best = None
@@ -1362,7 +1362,8 @@ def main():
                           "group_index": "ignored (--no-index): one wavefront per image" if args.no_index else
                                          "FGIX trailer behind each stream (csrc/index.cpp): one wavefront per channel group; the unmodified reference decodes the same files",
                           "parity_check": "decoded == source pixels for all images" if wl["lossless"] else "MSE vs source < 40 and all replicas identical (bit-exactness: tests -m gpu)",
-                          "gather": "final gather of the packed pictures to rank 0 (chunked RCCL gather) + all_gather of per-image checksums", "input_gen_s": round(t_gen, 1), "upload_s": round(t_upload, 3)},
+                          "gather": "final gather of the packed pictures to rank 0 (chunked RCCL gather) + all_gather of per-image checksums", "input_gen_s": round(t_gen, 1), "upload_s": round(t_upload, 3),
+                          "value_basis": "compressed streams resident in HBM when the timed region starts, at every N; the PCIe-inclusive rate is value_incl_h2d (N = 1 only), never value"},
                "roofline": roofline}
         if overlap_info is not None:
             res["config"]["overlapped_steps"] = ("two streaming batch objects on two HIP streams take the steps in turn; a step = one entropy launch over all %d streams + "

@@ -126,7 +126,7 @@ struct Op {
     PlaneRef ext[1];           // OP_HSQ2_YCOCG: a fourth source
     int32_t r16;               // squeeze family: the residual plane(s) are coded planes nobody has rewritten -- the kernel reads them as int16 samples
                                // straight from the coefficient slab (no widened copy of them is made)
-    int32_t pad2;
+    int32_t pad2;              // OP_IDCT: 1 = the AC source planes (entries 1..63 of the list) are all BUF_COEF16Q -- the kernel instantiation with int16 AC loads
 };
 
 struct TransformDesc {

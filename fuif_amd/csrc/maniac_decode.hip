@@ -564,20 +564,8 @@ DEV int fast_symbol(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
     "s_and_b32 %[t0], %[t0], 0xff\n\ts_lshl_b32 %[L], %[L], 8\n\ts_or_b32 %[L], %[L], %[t0]\n\ts_add_u32 %[widx], %[widx], 1\n\ts_lshl_b32 %[R], %[R], 8\n\t" \
     "s_branch " back "\n\t"
 #define FS_RN_CHECK(lbl, back) "s_cmp_le_u32 %[R], 0x10000\n\ts_cbranch_scc1 " lbl "\n" back ":\n\t"
-// Sensitivity probes (diagnostic builds only, tools/experiments/r4_2_probes.sh): N extra instructions of one kind per decoded symbol,
-// on scratch registers of the block -- what one more scalar / vector instruction / taken branch costs the LAUNCH, measured
-// instead of guessed (round 3: instruction trims made the launch slower, so the derivative is worth knowing before trimming).
-#define FS_STR2(x) #x
-#define FS_STR(x) FS_STR2(x)
-#if defined(FUIF_PROBE_S)
-#define FS_PROBE ".rept " FS_STR(FUIF_PROBE_S) "\n\ts_add_u32 %[t0], %[t0], 1\n\t.endr\n\t"
-#elif defined(FUIF_PROBE_V)
-#define FS_PROBE ".rept " FS_STR(FUIF_PROBE_V) "\n\tv_add_u32 " FS_VB ", " FS_VB ", " FS_VB "\n\t.endr\n\t"
-#elif defined(FUIF_PROBE_B)
-#define FS_PROBE ".rept " FS_STR(FUIF_PROBE_B) "\n\ts_branch 1f\n\ts_nop 0\n1:\n\t.endr\n\t"
-#else
-#define FS_PROBE
-#endif
+// (Round 4 measured what one more scalar / vector instruction / taken branch per symbol costs the launch with probe builds of this block: +0.37 % / +0.19 % /
+// +0.44 %, profiles/r4_instruction_probes.txt; the probe macros left the source in round 5 -- `git log -S FUIF_PROBE_S` has them.)
 DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
     // Round 4 (profiles/r4_instruction_probes.txt: a scalar instruction or a taken branch costs the launch twice a vector one):
     //   * a decision is `s_sub t, low, thr`: SCC = borrow = (low < thr) = NOT the bit, and three s_cselect / s_addc take it from there
@@ -591,7 +579,6 @@ DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
     uint32_t res, touched, bits, t0, t1, thr, idx, ilast, sm, hv, e, midx, amax, have, skipped;
     asm volatile(
         "v_mov_b32 " FS_VK0 ", 0x800\n\tv_mov_b32 " FS_VK1 ", 0\n\t"
-        FS_PROBE
         // ---- zero?  (chance 0)
         FS_THR_PREP "s_nop 0\n\tv_readlane_b32 %[thr], " FS_VA ", 0\n\t"
         "s_cmp_ge_u32 %[L], %[thr]\n\ts_cbranch_scc1 70f\n\t"

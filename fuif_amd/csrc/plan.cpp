@@ -731,8 +731,8 @@ struct Builder {
             if (ops[qk].kind != OP_QUANT) continue;
             int nq = 0;
             list_of(ops[qk], &nq);
-            std::vector<PlaneRef> keep;
-            bool changed = false;
+            // which planes of the QUANT list qualify: coded planes nothing else reads or writes, consumed by exactly one iDCT behind the dequantisation
+            std::vector<char> cand((size_t)nq, 0);
             for (int li = 0; li < nq; li++) {
                 const PlaneRef pl = plan.idct_src[(size_t)ops[qk].idct_first + (size_t)li];
                 bool ok = pl.buf == BUF_COEF && (int64_t)pl.w * pl.h > 0 && pl.qsrc >= 0;
@@ -750,17 +750,35 @@ struct Builder {
                         else ok = false;                                               // any other op, or an iDCT BEFORE the dequantisation
                     }
                 }
-                if (ok && uses == 1) {
-                    for (size_t k = qk + 1; k < ops.size(); k++) {
-                        if (ops[k].kind != OP_IDCT) continue;
-                        int n = 0;
-                        PlaneRef *l = list_of(ops[k], &n);
-                        for (int m = 0; m < n; m++) if (same_plane(l[m], pl)) { l[m].buf = BUF_COEF16Q; l[m].qsrc = pl.qsrc; }
-                    }
-                    changed = true;
-                } else keep.push_back(pl);
+                cand[(size_t)li] = ok && uses == 1;
+            }
+            auto cand_index = [&](const PlaneRef &r) { for (int li = 0; li < nq; li++) if (cand[(size_t)li] && same_plane(plan.idct_src[(size_t)ops[qk].idct_first + (size_t)li], r)) return li; return -1; };
+            // An iDCT takes the fold only when ALL of its 63 AC planes qualify: its kernel is then the instantiation whose AC loads are int16 loads at
+            // compile time (a per-plane test inside the load loop keeps the loads from being issued together: measured, the iDCT doubled).  The DC plane
+            // (entry 0) is its own case -- a product of the unsqueeze chain in a default stream, a coded plane when the DC was not squeezed -- and is tested at run time.
+            std::vector<char> folded((size_t)nq, 0);
+            bool changed = false;
+            for (size_t k = qk + 1; k < ops.size(); k++) {
+                if (ops[k].kind != OP_IDCT) continue;
+                int n = 0;
+                PlaneRef *l = list_of(ops[k], &n);
+                if (n != 64) continue;
+                bool all_ac = true;
+                for (int m = 1; m < 64; m++) all_ac = all_ac && cand_index(l[m]) >= 0;
+                if (!all_ac) continue;
+                for (int m = 0; m < 64; m++) {
+                    const int li = cand_index(l[m]);
+                    if (li < 0) continue;
+                    const int qsrc = plan.idct_src[(size_t)ops[qk].idct_first + (size_t)li].qsrc;
+                    l[m].buf = BUF_COEF16Q; l[m].qsrc = qsrc;
+                    folded[(size_t)li] = 1;
+                }
+                ops[k].pad2 = 1;      // OP_IDCT: the AC planes (entries 1..63) are BUF_COEF16Q
+                changed = true;
             }
             if (!changed) continue;
+            std::vector<PlaneRef> keep;
+            for (int li = 0; li < nq; li++) if (!folded[(size_t)li]) keep.push_back(plan.idct_src[(size_t)ops[qk].idct_first + (size_t)li]);
             if (getenv("FUIFGPU_VERBOSE")) fprintf(stderr, "fuifgpu: plan %dx%d: dequantisation of %d of %d planes folded into the iDCT loads\n", plan.w, plan.h, nq - (int)keep.size(), nq);
             for (int li = 0; li < nq; li++) plan.idct_src[(size_t)ops[qk].idct_first + (size_t)li].buf = -1;   // the old list is dead: nobody may widen its planes on its account
             ops[qk].idct_first = (int)plan.idct_src.size();

@@ -733,13 +733,16 @@ DEV void idct_1d(const double (&in)[8], double (&out)[8]) {
 }
 // A source plane of kind BUF_COEF16Q (planner peephole fuse_dequant_into_idct) is a coded plane as the entropy kernel stored it: the int16 sample is
 // read from the coefficient slab and multiplied by the channel's quantisation constant on the way in (quantize.h:32-49 folded into the load).
-__global__ __launch_bounds__(64) void k_idct8x8(Bases b, const PlaneRef *list, PlaneRef po, int bw, int bh, int maxval, int clamp, int lo, int hi,
+// kAc16 (Op::pad2): ALL 63 AC planes are of that kind -- known at compile time, so the 8 loads of a column are issued together as before; only the DC plane
+// (entry 0: a product of the unsqueeze chain in a default stream) is tested at run time.  With a per-plane test inside the loop every load waited for
+// its own round trip and the kernel's time doubled (23 -> 45 ms per C3 step, profiles/r5_c3_kernel_stats_scalar_q_loads.csv).
+template <bool kAc16>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_idct8x8(Bases b, const PlaneRef *list, PlaneRef po, int bw, int bh, int maxval, int clamp, int lo, int hi,
                                                 const ChannelMeta *meta, int n_channels, int img_first) {
     const int bx = blockIdx.x * blockDim.x + threadIdx.x;
     const int by = blockIdx.y;
-    // The quantisation constants of the 64 source planes, one per lane, parked in LDS: the column loop below reads them with constant offsets.
-    // (Fetched with scalar loads inside the loop -- plane descriptor, then q, two dependent round trips per plane behind the per-column
-    // scheduling barrier -- the folded dequantisation doubled the kernel's time: 23 -> 45 ms per C3 step, profiles/r5_c3_kernel_stats.csv.)
+    // The quantisation constants of the 64 source planes, one per lane, parked in LDS: the column loop below reads them with constant offsets
+    // (no dependent scalar loads -- plane descriptor, then q -- inside the loop).
     __shared__ int qs[64];
     {
         const PlaneRef pl = list[threadIdx.x];
@@ -756,7 +759,7 @@ __global__ __launch_bounds__(64) void k_idct8x8(Bases b, const PlaneRef *list, P
         for (int u = 0; u < 8; u++) {
             const PlaneRef p = list[u * 8 + x];
             int v;
-            if (p.buf == BUF_COEF16Q)
+            if ((u != 0 || x != 0) ? kAc16 : p.buf == BUF_COEF16Q)
                 v = (int)(b.c16 + (int64_t)blockIdx.z * b.stride[BUF_COEF] + p.off)[(int64_t)by * p.w + bx] * qs[u * 8 + x];
             else
                 v = plane_ptr(b, p, blockIdx.z)[(int64_t)by * p.w + bx];
@@ -1118,8 +1121,10 @@ void launch_op(const Op &op, const Bases &b, const PlaneRef *dev_list, ChannelMe
             break;
         }
         case OP_IDCT:
-            hipLaunchKernelGGL(k_idct8x8, dim3((op.p0 + 63) / 64, op.p1, n_images), dim3(64), 0, stream, b, dev_list + op.idct_first, op.dst[0],
-                               op.p0, op.p1, op.hi, op.clamp_out, op.lo, op.hi, meta, n_channels, img_first);
+            if (op.pad2 && meta) hipLaunchKernelGGL(k_idct8x8<true>, dim3((op.p0 + 63) / 64, op.p1, n_images), dim3(64), 0, stream, b, dev_list + op.idct_first, op.dst[0],
+                                                    op.p0, op.p1, op.hi, op.clamp_out, op.lo, op.hi, meta, n_channels, img_first);
+            else hipLaunchKernelGGL(k_idct8x8<false>, dim3((op.p0 + 63) / 64, op.p1, n_images), dim3(64), 0, stream, b, dev_list + op.idct_first, op.dst[0],
+                                    op.p0, op.p1, op.hi, op.clamp_out, op.lo, op.hi, meta, n_channels, img_first);
             break;
         case OP_UPS2_YCBCR:
             if (op.src[1].w <= 0 || op.src[1].h <= 0) break;

@@ -155,11 +155,13 @@ def test_fp64_kernels_are_not_contracted(tmp_path):
     subprocess.run(["hipcc"] + fuif_amd.HIPCC_FLAGS + ["-S", "--cuda-device-only", os.path.join(ROOT, "fuif_amd", "csrc", "transforms.hip"), "-o", out],
                    check=True, stderr=subprocess.DEVNULL)
     text = open(out).read()
-    for name in ("k_idct8x8", "k_inv_ycbcr"):
-        m = re.search(r"^_ZN7fuifgpu\d+%s\w*:[^\n]*\n(.*?)s_endpgm" % name, text, re.S | re.M)
-        assert m, name
-        body = m.group(1)
-        assert not re.search(r"\bv_fmac?_f(64|32)", body), name + " holds fused multiply-adds"
-        if name == "k_idct8x8":
-            assert len(re.findall(r"\bv_mul_f64", body)) == 353
-            assert 896 <= len(re.findall(r"\bv_add_f64", body)) <= 896 + 3 * 64 + 1
+    for name, instances in (("k_idct8x8", 2), ("k_inv_ycbcr", 1), ("k_ups2_ycbcr", 1)):      # (the iDCT is built twice: int32 / int16 AC loads)
+        bodies = [m.group(1) for m in re.finditer(r"^_ZN7fuifgpu\d+%s\w*:[^\n]*\n(.*?)s_endpgm" % name, text, re.S | re.M)]
+        assert len(bodies) == instances, (name, len(bodies))
+        for body in bodies:
+            assert not re.search(r"\bv_fmac?_f(64|32)", body), name + " holds fused multiply-adds"
+            if name == "k_idct8x8":
+                assert len(re.findall(r"\bv_mul_f64", body)) == 353
+                assert 896 <= len(re.findall(r"\bv_add_f64", body)) <= 896 + 3 * 64 + 1
+            if name == "k_ups2_ycbcr":
+                assert len(re.findall(r"\bv_mul_f64", body)) == 16      # 4 products per pixel (ycbcr.h:56-58), 4 pixels per lane

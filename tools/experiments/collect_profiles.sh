@@ -14,5 +14,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH --s
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH --steps 1 --warmup 0 > $OUT/bench_fetch.json 2> $OUT/bench_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH --steps 1 --warmup 0 > $OUT/bench_write.json 2> $OUT/bench_write.err
 find $OUT -name "*.csv" | head -40
-python $ROOT/tools/summarize_profiles.py $OUT > $OUT/summary.txt 2>&1
+python $ROOT/tools/experiments/summarize_profiles.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

@@ -3,7 +3,7 @@
 #   1. kernel-trace + stats of `bench.py --steps 2 --warmup 1` (average duration of k_maniac_decode must agree with bench.py's HIP events)
 #   2. FETCH_SIZE and WRITE_SIZE of the same launch, one --pmc pass each (they do not fit one pass; no trace domains next to --pmc)
 #   3. the same two counters on a known byte count in the kernel's own access pattern (tools/ubench_gather.hip): calibration factors
-# Outputs: gpurun_out/prof_<tag>/ ; tools/summarize_profiles_r2.py condenses them into the files copied to profiles/.
+# Outputs: gpurun_out/prof_<tag>/ ; tools/experiments/summarize_profiles_r2.py condenses them into the files copied to profiles/.
 set -u
 TAG=${1:-r2}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -17,5 +17,5 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH --ste
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/cal_read_fetch -- $ROOT/tools/ubench_gather_bin read 20000 > $OUT/cal_read.json 2> $OUT/cal_read.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write_write -- $ROOT/tools/ubench_gather_bin write 20000 > $OUT/cal_write.json 2> $OUT/cal_write.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/cal_write_fetch -- $ROOT/tools/ubench_gather_bin write 20000 > /dev/null 2> $OUT/cal_write_fetch.err
-python $ROOT/tools/summarize_profiles_r2.py $OUT > $OUT/summary.txt 2>&1
+python $ROOT/tools/experiments/summarize_profiles_r2.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
