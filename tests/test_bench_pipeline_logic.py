@@ -50,7 +50,7 @@ print(json.dumps({"ok": ok, "info": info}))
 '''
 
 
-@pytest.mark.parametrize("damage", [0, 1])
+@pytest.mark.parametrize("damage", [1])      # (the undamaged case is part of the end-to-end runs of tests/test_bench_launcher.py)
 def test_overlapped_steps_decode_and_verify_every_step(tmp_path, damage):
     if sys.platform != "linux" or os.uname().machine != "x86_64":
         pytest.skip("the emulator's context switch is x86-64 SysV assembly")
