@@ -106,6 +106,39 @@ def run(pipelined):
     return dt
 
 
+if "--per-launch" in argv:
+    # one host thread per stream: queue a launch, wait for it, note the time -- the spacing of the completions in the middle of the run is the steady-state
+    # time per launch (the totals above include the ramp: the first launch has the device to itself, the last one too)
+    import threading
+    done = []
+    t_start = time.perf_counter()
+
+    def worker(k):
+        b, s = batches[k], streams[k]
+        if k == 1 and stagger > 0:
+            time.sleep(stagger)
+        for i in range(k, K, 2):
+            b.decode(s)
+            if with_tr:
+                transforms(b, s, outs[k])
+            b.sync(s)
+            done.append((time.perf_counter() - t_start, i))
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    done.sort()
+    ends = [t for t, _ in done]
+    gaps = [b - a for a, b in zip(ends, ends[1:])]
+    mid = gaps[len(gaps) // 4: len(gaps) - len(gaps) // 4] or gaps
+    print("per-launch completions (s): " + " ".join("%.2f" % t for t in ends))
+    print("steady state: %.2f s per launch in the middle half of the run (%d gaps) -> %.1f Mpixels/s; whole run %.2f s for %d launches -> %.1f Mpixels/s (%s)" % (
+        sum(mid) / len(mid), len(mid), px / (sum(mid) / len(mid)) / 1e6, ends[-1], K, K * px / ends[-1] / 1e6, "entropy + inverse transforms" if with_tr else "entropy only"), flush=True)
+    for b in batches:
+        st, _ = b.status()
+        assert not st.any(), st[st != 0][:8]
+    sys.exit(0)
 tile_log = "--tile-log" in argv      # (a -DFUIF_TILELOG build: tools/build_variant.sh tilelog -DFUIF_TILELOG)
 if tile_log:
     for b in batches:
