@@ -409,16 +409,6 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
     for (auto &g : groups) deepest = std::max(deepest, g.size());
     b->dense = (int64_t)total_tiles > b->max_waves[0] ? 1 : 0;
     b->n_waves = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)total_tiles, b->max_waves[b->dense]));
-    // FUIFGPU_WAVES_PER_SIMD=k (experiment, dense launches): a launch brings only k wavefronts per SIMD of the 6 the kernel is built for, so that the
-    // wavefronts of ANOTHER launch (a second batch on a second stream) have slots of their own from its first millisecond to its last
-    int layout_waves_per_simd = b->waves_per_simd;
-    if (const char *e = getenv("FUIFGPU_WAVES_PER_SIMD")) {
-        const int k = atoi(e);
-        if (b->dense && k >= 1 && k < b->waves_per_simd) {
-            layout_waves_per_simd = k;
-            b->n_waves = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)b->n_waves, (int64_t)b->max_waves[1] / b->waves_per_simd * k));
-        }
-    }
     // an image whose every tile holds exactly one non-empty channel (one single-channel group per tile) may have its tiles suspended
     std::vector<char> suspendable(groups.size(), 0);
     for (size_t gi = 0; gi < groups.size(); gi++) {
@@ -467,7 +457,7 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
         for (size_t k = 0; k < deepest; k++)
             for (int i = 0; i < n_images; i++) push_tile(i, k);
     } else {
-        const int waves_per_cu = 4 * std::max(1, layout_waves_per_simd);
+        const int waves_per_cu = 4 * std::max(1, b->waves_per_simd);
         b->n_queues = std::max(1, std::min(n_images, b->n_waves / waves_per_cu));
         const int Q = b->n_queues;
         layout.resize((size_t)Q + 1 + n_images + n_images + 1);
