@@ -112,14 +112,20 @@ def gather_packed(local, dist, root=0, chunk_bytes=256 << 20, keep=True):
             out = [0] * world
             out[root] = byte_sum(local)
     longest = max(sizes)
+    # equal-sized slots per step (gather needs them): a rank past its end sends an empty tail padded in the slot.  The send buffer and the
+    # root's receive slots are allocated ONCE for the largest step and reused (round 4 allocated `world` fresh 256 MB slots per chunk)
+    first = min(chunk_bytes, longest)
+    mine_buf = torch.zeros(first, dtype=torch.uint8, device=local.device) if longest else None
+    slot_bufs = [torch.empty(first, dtype=torch.uint8, device=local.device) for _ in range(world)] if (rank == root and longest) else None
     for off in range(0, longest, chunk_bytes):
-        # equal-sized slots per step (gather needs them): a rank past its end sends an empty tail padded in the slot
         step = min(chunk_bytes, longest - off)
-        mine = torch.zeros(step, dtype=torch.uint8, device=local.device)
+        mine = mine_buf[:step]
         n_mine = max(0, min(step, local.numel() - off))
         if n_mine:
             mine[:n_mine] = local[off:off + n_mine]
-        slots = [torch.empty(step, dtype=torch.uint8, device=local.device) for _ in range(world)] if rank == root else None
+        if n_mine < step:
+            mine[n_mine:] = 0
+        slots = [b[:step] for b in slot_bufs] if rank == root else None
         dist.gather(mine, gather_list=slots, dst=root)
         if rank == root:
             for r in range(world):
