@@ -309,8 +309,9 @@ bool cpu_decode_whole(const std::vector<uint8_t> &bytes, Image &img, const fuif_
 
 namespace {
 // the files `idx` (one geometry + transform chain: one plan) on the calling thread's current device: one batch object, chunk by chunk
+// `sharers` = host threads of this call that work on the same device (a device list may name one twice): each sizes its chunks for its share of the memory
 void decode_group_here(fuifgpu_plan *plan, const std::vector<int> &idx, const std::vector<std::vector<uint8_t>> &bytes, const char *const *filenames,
-                       Image *images, const fuif_options &options, std::vector<char> &ok, std::vector<char> &cpu_route, bool verbose) {
+                       Image *images, const fuif_options &options, std::vector<char> &ok, std::vector<char> &cpu_route, bool verbose, int sharers) {
     fuifgpu_image_info info;
     fuifgpu_plan_info(plan, &info);
     int device = 0;
@@ -327,7 +328,7 @@ void decode_group_here(fuifgpu_plan *plan, const std::vector<int> &idx, const st
         if (fuifgpu_dev_mem_info(&free_b, &total_b) == FUIFGPU_OK && free_b) {
             const size_t reserve = std::min<size_t>(free_b / 4, (size_t)40 << 30);
             const size_t per_image = 2 * (size_t)info.coef_elems + 4 * (size_t)info.out_elems + max_stream + ((size_t)16 << 20);   // int16 coefficients, int32 outputs
-            chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, (free_b - reserve) / std::max<size_t>(per_image, 1)));
+            chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, (free_b - reserve) / (size_t)std::max(1, sharers) / std::max<size_t>(per_image, 1)));
         }
         if (const char *e = getenv("FUIFGPU_BOUNDARY_CHUNK")) chunk = std::max(1, std::min(n, atoi(e)));
     }
@@ -436,7 +437,9 @@ int fuif_decode_files_on(const char *const *filenames, int n_files, Image *image
     }
     auto run = [&](int wkr) {
         if (n_devices > 0 && fuifgpu_set_device(devices[wkr]) != FUIFGPU_OK) { e_printf("fuifgpu: GPU %d: %s\n", devices[wkr], fuifgpu_last_error()); return; }
-        for (const Share &sh : work[wkr]) decode_group_here(sh.plan, sh.idx, bytes, filenames, images, options, ok, cpu_route, verbose);
+        int sharers = 1;
+        if (n_devices > 0) { sharers = 0; for (int k = 0; k < n_devices; k++) sharers += devices[k] == devices[wkr] ? 1 : 0; }
+        for (const Share &sh : work[wkr]) decode_group_here(sh.plan, sh.idx, bytes, filenames, images, options, ok, cpu_route, verbose, sharers);
     };
     if (n_workers == 1) run(0);
     else {
