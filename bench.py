@@ -1244,7 +1244,7 @@ def main():
                     except Exception as e:                                       # noqa: BLE001 -- reported in the JSON line
                         failed.append(repr(e))
 
-                n_pipe = max(2, args.steps)
+                n_pipe = min(max(2, args.steps), 4)        # (a few steps show the steady state; 20 of them were 150 s of the driver's run)
                 # `batch` holds step 0's streams already (the serial upload above); the first overlapped upload also allocates
                 th = threading.Thread(target=uploader, args=(other,))
                 th.start()
