@@ -34,8 +34,8 @@
 // item above trades scalar instructions for vector ones.  Measured on the 1024 x 4K launch (round 4,
 // profiles/r4_instruction_probes.txt): one more scalar instruction per symbol costs 0.37 % of the launch,
 // a vector one 0.19 %, a taken branch 0.44 % -- ~165 instructions per symbol since round 4 (was 202).
-// Two LDS configurations are built: "wide" = 38.9 KB per wave (29 KB of supernodes, 8.4 KB of chunk
-// properties, small state; one wave per SIMD) and "dense" = 5.7 KB (no supernode slots, 32-pixel chunks;
+// Two LDS configurations are built: "wide" = 19.7 KB per wave (20 supernodes = 10 KB, 8.4 KB of chunk
+// properties, small state; exactly two waves per SIMD since round 5) and "dense" = 5.7 KB (no supernode slots, 32-pixel chunks;
 // 80 VGPRs: 24 waves per CU, six per SIMD, which fill each other's stalls when tiles outnumber SIMDs).
 // The 16 KB chance transition table is read through L1/L2 instead: its lookups are off the dependency
 // chain thanks to the batched update.
