@@ -99,6 +99,13 @@ JPEG_SPECS = [
     # expected planes from the real reference decoding it -- the inverse is the replication branch of subsample.h:116-126
     ("jpeg411_176x72_q85", dict(w=176, h=72, channels=3, bits=8, seed=24), dict(quality=85, writer_factors=(4, 1))),
 ]
+# raw YUV 4:2:0 input (fuif -y WxH: import/read_yuv... builds Y + two half-size chroma planes and records [YCbCr, ChromaSubsampling], no DCT): with odd sizes
+# the upsampled chroma planes (98x62) are LARGER than the Y plane (97x61) -- their samples outside the colour transform's region keep the upsampled value
+# and only get the final clamp (image.cpp:107-113); -Q drives values out of range.  Round 5: the fused upsampling + YCbCr kernel's edge cases.
+YUV_SPECS = [
+    ("yuv420p_97x61", dict(w=97, h=61, channels=3, bits=8, seed=321, sigma=6.0), dict(yuv420p=True)),
+    ("yuv420p_75x49_Q60", dict(w=75, h=49, channels=3, bits=8, seed=322, sigma=25.0), dict(yuv420p=True, quality=60)),
+]
 # animation (FUAF): frames are stacked vertically; -M 0 keeps the 2D-match transform (out of scope) off
 ANIM_SPECS = [
     ("anim3_48x32", dict(w=48, h=32, channels=3, bits=8, seed=700), dict(frames=3)),
@@ -126,10 +133,10 @@ SOFTMATCH_SPECS = [
     ("softmatch_rgb_graphic_nosqueeze_72x60", dict(w=72, h=60, channels=3, bits=8, seed=53, colors=300), dict(softmatch=1, match_distance=200, squeeze=0)),
     ("softmatch_anim4_40x28_q2", dict(w=40, h=28, channels=3, bits=8, seed=710, static=True), dict(softmatch=1, match_distance=-2, frames=4, quant=2)),
 ]
-PREVIEWS = {"softmatch_rgb_graphic_96x80_q3": [2], "c1_rgb8_512x512": [0, 1, 2, 3, 4], "rgb8_97x61": [0, 2, 4], "jpeg420_256x192_q90": [0, 1, 2, 3, 4],
+PREVIEWS = {"yuv420p_97x61": [1, 3], "softmatch_rgb_graphic_96x80_q3": [2], "c1_rgb8_512x512": [0, 1, 2, 3, 4], "rgb8_97x61": [0, 2, 4], "jpeg420_256x192_q90": [0, 1, 2, 3, 4],
             "pal_rgb_graphic_120x90": [1, 3], "approx_rgb8_96x80_A3": [2], "approx_quant_rgb8_40x30": [3], "match_rgb_graphic_96x80": [3]}
 TRUNCATE_EXTRA = {"softmatch_rgb_graphic_nosqueeze_72x60": [0.7], "softmatch_anim4_40x28_q2": [0.6], "approx_on_palette_gray12_24x50": [0.8], "match_rgb_graphic_96x80": [0.6]}
-TRUNCATE = {"rgb8_512x384_I16_bigtrees": [0.8], "permute_channel_rgb8_48x40": [0.5], "permute_explicit_rgb8_48x40": [0.6], "rgb8_97x61": [0.2, 0.55, 0.93], "rgb8_128x128_I0": [0.5], "rgb8_112x96_E18": [0.7], "rgb8_120x88_E50": [0.6], "jpeg420_256x192_q90": [0.4], "rgb8_64x64_U": [0.6],
+TRUNCATE = {"yuv420p_75x49_Q60": [0.6], "rgb8_512x384_I16_bigtrees": [0.8], "permute_channel_rgb8_48x40": [0.5], "permute_explicit_rgb8_48x40": [0.6], "rgb8_97x61": [0.2, 0.55, 0.93], "rgb8_128x128_I0": [0.5], "rgb8_112x96_E18": [0.7], "rgb8_120x88_E50": [0.6], "jpeg420_256x192_q90": [0.4], "rgb8_64x64_U": [0.6],
             "pal_rgba_graphic_72x64": [0.5], "pal_rgb_sparse_128x96": [0.7],
             "gray8_nosqueeze_60x40": [0.6], "rgb8_96x96_nosqueeze": [0.45]}
 
@@ -145,7 +152,7 @@ def main():
             manifest = json.load(f)
         manifest["fixtures"] = [e for e in manifest["fixtures"] if e["name"] not in only]
     tmp = tempfile.mkdtemp()
-    for name, gen, flags in SPECS + GRAPHIC_SPECS + [(n, g, j) for n, g, j in JPEG_SPECS] + ANIM_SPECS + PERMUTE_SPECS + SOFTMATCH_SPECS:
+    for name, gen, flags in SPECS + GRAPHIC_SPECS + [(n, g, j) for n, g, j in JPEG_SPECS] + YUV_SPECS + ANIM_SPECS + PERMUTE_SPECS + SOFTMATCH_SPECS:
         if only and name not in only:
             continue
         gen = dict(gen)
@@ -173,6 +180,15 @@ def main():
             with open(out, "wb") as f:
                 f.write(blob)
             src, cli_flags = None, []
+        elif isinstance(flags, dict) and flags.get("yuv420p"):
+            w, h = gen["w"], gen["h"]
+            cw, ch2 = (w + 1) // 2, (h + 1) // 2
+            src = os.path.join(tmp, name + ".yuv")
+            with open(src, "wb") as f:      # planar Y, then the two chroma planes at half size (what a 4:2:0 raw video frame holds)
+                f.write(img[0].astype(np.uint8).tobytes())
+                f.write(np.ascontiguousarray(img[1][::2, ::2][:ch2, :cw]).astype(np.uint8).tobytes())
+                f.write(np.ascontiguousarray(img[2][::2, ::2][:ch2, :cw]).astype(np.uint8).tobytes())
+            cli_flags = ["-y", "%dx%d" % (w, h)] + (["-Q", str(flags["quality"])] if "quality" in flags else [])
         elif isinstance(flags, dict) and "frames" in flags:
             base = photographic(**gen)
             for i in range(flags["frames"]):
@@ -207,7 +223,7 @@ def main():
                 raise SystemExit("reference CLI failed for %s: %s %s" % (name, r.stdout[-400:], r.stderr[-400:]))
         blob = open(out, "rb").read()
         entry = {"name": name, "file": name + ".fuif", "bytes": len(blob), "file_sha256": hashlib.sha256(blob).hexdigest(),
-                 "source": gen, "cli_flags": cli_flags if not isinstance(flags, dict) else (["<library: oracle/ref_driver.cpp fuifref_encode>", json.dumps(flags)] if ("permute" in flags or "softmatch" in flags) else ["<stream written by fuif_amd/jpeglike.py; expected planes = the reference decoding it>", json.dumps(flags)] if "writer_factors" in flags else ["<jpeg/anim>", json.dumps(flags)] + cli_flags), "cases": []}
+                 "source": gen, "cli_flags": cli_flags if not isinstance(flags, dict) else (["<library: oracle/ref_driver.cpp fuifref_encode>", json.dumps(flags)] if ("permute" in flags or "softmatch" in flags) else ["<stream written by fuif_amd/jpeglike.py; expected planes = the reference decoding it>", json.dumps(flags)] if "writer_factors" in flags else ["<jpeg/anim/yuv>", json.dumps(flags)] + cli_flags), "cases": []}
         cases = [("full", -1, len(blob))]
         cases += [("preview%d" % k, k, len(blob)) for k in PREVIEWS.get(name, [])]
         cases += [("trunc%02d" % int(f * 100), -1, int(len(blob) * f)) for f in TRUNCATE.get(name, []) + TRUNCATE_EXTRA.get(name, [])]

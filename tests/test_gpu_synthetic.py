@@ -344,3 +344,20 @@ def test_jpeg_like_chain_fused_and_unfused_match_oracle(gpulib, port, w, h, qual
             assert len(planes) == len(d_post.channels)
             for i, (g, e) in enumerate(zip(planes, d_post.channels)):
                 assert np.array_equal(g, e["data"]), (fuse_q, fuse_c, i)
+
+
+@pytest.mark.parametrize("name", ["yuv420p_97x61", "yuv420p_75x49_Q60"])
+def test_yuv420p_fixtures_with_and_without_the_fused_colour_kernel(gpulib, manifest, name, monkeypatch):
+    """raw 4:2:0 input through the reference CLI (`fuif -y WxH`: [YCbCr, ChromaSubsampling, Squeeze], no DCT) with ODD sizes: the upsampled chroma planes
+    (98x62 / 76x50) are larger than the Y plane, whose last column / row has no partner -- the fused upsampling + YCbCr kernel's edge lanes (one column /
+    one row inside the colour transform's region, the other only clamped) -- against the real reference's plane hashes, fused and unfused"""
+    from conftest import golden_blob, plane_hash
+    e = next(x for x in manifest["fixtures"] if x["name"] == name)
+    c = e["cases"][0]
+    blob = golden_blob(e, c)
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("FUIFGPU_FUSE_YCBCR", fuse)
+        pre, post, st, used = gpu_decode(gpulib, [blob, blob, blob])
+        assert not st.any()
+        for planes in post:
+            assert [plane_hash(p) for p in planes] == [x["sha256"] for x in c["post"]], (name, fuse)
