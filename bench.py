@@ -672,6 +672,7 @@ def overlapped_steps(args, plan, blobs, dev, dist, W, H, index=True, warmup=None
     cap = sum(len(b) for b in blobs) + 4096 * n
     batches = [fuif_amd.Batch(plan, n, cap, streaming=True) for _ in range(2)]
     for b, st in zip(batches, streams):
+        b.set_in_flight(2)                # (two batches in flight: launches with few tiles leave room for each other's wavefronts)
         b.set_group_parallel(index)       # (False: the streams' group index is ignored -- one wavefront per picture, what a file without the trailer gets)
         b.upload(blobs, stream=st.cuda_stream)
         b.sync(st.cuda_stream)

@@ -108,7 +108,7 @@ ABI_SYMBOLS = [
     "fuifgpu_index_parse", "fuifgpu_index_append", "fuifgpu_batch_group_index", "fuifgpu_batch_set_group_parallel",
     "fuifgpu_plan_packed_bytes", "fuifgpu_batch_pack_out", "fuifgpu_batch_download_packed",
     "fuifgpu_dev_alloc", "fuifgpu_dev_free", "fuifgpu_dev_upload", "fuifgpu_dev_download",
-    "fuifgpu_plane_checksums", "fuifgpu_device_count", "fuifgpu_set_device", "fuifgpu_get_device", "fuifgpu_batch_device", "fuifgpu_peer_copy",
+    "fuifgpu_plane_checksums", "fuifgpu_device_count", "fuifgpu_set_device", "fuifgpu_get_device", "fuifgpu_batch_device", "fuifgpu_peer_copy", "fuifgpu_batch_set_in_flight",
 ]
 
 
@@ -208,6 +208,7 @@ def lib():
     L.fuifgpu_index_append.argtypes = [C.c_char_p, C.c_size_t, vp, vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.fuifgpu_batch_group_index.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int)]
     L.fuifgpu_batch_set_group_parallel.argtypes = [vp, C.c_int]
+    L.fuifgpu_batch_set_in_flight.argtypes = [vp, C.c_int]
     L.fuifgpu_plan_packed_bytes.argtypes = [vp, C.c_int]; L.fuifgpu_plan_packed_bytes.restype = C.c_size_t
     L.fuifgpu_batch_pack_out.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
     L.fuifgpu_batch_download_packed.argtypes = [vp, C.c_int, C.c_int, vp, vp]
@@ -335,6 +336,10 @@ class Batch:
     def set_group_parallel(self, enable):
         """False: ignore group indices (one wavefront per image, as for streams that carry none); applies to the next upload"""
         _check(lib().fuifgpu_batch_set_group_parallel(self._h, int(bool(enable))))
+
+    def set_in_flight(self, n_batches):
+        """how many batches the host keeps in flight on this device (fuifgpu_batch_set_in_flight); applies to the next upload"""
+        _check(lib().fuifgpu_batch_set_in_flight(self._h, int(n_batches)))
 
     def group_index(self, image):
         """[(first_channel, byte_offset)] of every channel group the last decode of `image` went through"""

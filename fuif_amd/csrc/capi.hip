@@ -40,8 +40,9 @@ struct fuifgpu_batch {
     uint8_t *d_scratch = nullptr;
     size_t scratch_stride = 0, bfs_off = 0, leaves_off = 0, stack_off = 0, queue_off = 0, subtree_off = 0;
     int scratch_waves = 0;            // wavefronts d_scratch is sized for
-    int max_waves[2] = {0, 0};        // resident wavefronts the device holds in the wide / dense kernel configuration
-    int n_waves = 0, dense = 0;       // persistent wavefronts and configuration of the next decode launch
+    int max_waves[3] = {0, 0, 0};     // resident wavefronts the device holds in the kernel configurations: wide for two batches in flight / dense / wide for a launch alone
+    int in_flight = 1;                // batches the host keeps in flight on this device (fuifgpu_batch_set_in_flight): picks the wide configuration
+    int n_waves = 0, dense = 0, cfg = 1;   // persistent wavefronts and configuration (index into max_waves) of the next decode launch
     bool group_parallel = true;       // use group indices (index.cpp) when streams carry them
     Tile *d_tiles = nullptr;
     int tiles_cap = 0, n_tiles = 0;
@@ -269,7 +270,9 @@ static int batch_create_impl(const Plan &plan_in, int n_images, size_t blob_capa
     b->scratch_stride = maniac_scratch_bytes(b->max_nodes, &b->bfs_off, &b->leaves_off, &b->stack_off, &b->queue_off, &b->subtree_off);
     b->max_waves[0] = maniac_max_waves(0);
     b->max_waves[1] = maniac_max_waves(1, &b->waves_per_simd);
-    if (b->max_waves[0] < 1 || b->max_waves[1] < 1) { g_last_error = "cannot query the device occupancy of the entropy kernel"; fuifgpu_batch_destroy(b); return FUIFGPU_E_HIP; }
+    b->max_waves[2] = maniac_max_waves(2);
+    if (const char *e = getenv("FUIFGPU_IN_FLIGHT")) b->in_flight = std::max(1, atoi(e));     // (tests and tools: what fuifgpu_batch_set_in_flight sets)
+    if (b->max_waves[0] < 1 || b->max_waves[1] < 1 || b->max_waves[2] < 1) { g_last_error = "cannot query the device occupancy of the entropy kernel"; fuifgpu_batch_destroy(b); return FUIFGPU_E_HIP; }
     CHK(hipMalloc((void **)&b->d_progress, sizeof(uint32_t) * (size_t)n_images * std::max(nch, 1)));
     CHK(hipMalloc((void **)&b->d_group_start, sizeof(uint32_t) * (size_t)n_images * std::max(nch, 1)));
     if (coef_ext) b->d_coef = coef_ext;
@@ -320,7 +323,7 @@ static size_t ctx_bytes_per_image() {
     return per_image;
 }
 static int freeze_launch_resources(fuifgpu_batch *b) {
-    const int64_t cap = std::max(b->max_waves[0], b->max_waves[1]);
+    const int64_t cap = std::max(std::max(b->max_waves[0], b->max_waves[1]), b->max_waves[2]);
     const int waves = (int)std::max<int64_t>(1, std::min<int64_t>(cap, (int64_t)b->n * std::max<int64_t>((int64_t)b->plan.coded.size(), 1)));
     if (waves > b->scratch_waves) {
         HIPCHK(hipDeviceSynchronize());
@@ -407,8 +410,10 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
     size_t total_tiles = 0, deepest = 0;
     for (int i = 0; i < n_images; i++) total_tiles += groups[group_of[i]].size();
     for (auto &g : groups) deepest = std::max(deepest, g.size());
-    b->dense = (int64_t)total_tiles > b->max_waves[0] ? 1 : 0;
-    b->n_waves = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)total_tiles, b->max_waves[b->dense]));
+    const int wide_cfg = b->in_flight > 1 ? 0 : 2;      // a host with two batches in flight leaves room for the other launch's wavefronts (20 LDS supernodes: two per SIMD)
+    b->dense = (int64_t)total_tiles > b->max_waves[wide_cfg] ? 1 : 0;
+    b->cfg = b->dense ? 1 : wide_cfg;
+    b->n_waves = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)total_tiles, b->max_waves[b->cfg]));
     // an image whose every tile holds exactly one non-empty channel (one single-channel group per tile) may have its tiles suspended
     std::vector<char> suspendable(groups.size(), 0);
     for (size_t gi = 0; gi < groups.size(); gi++) {
@@ -550,7 +555,7 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
     b->n_loaded = n_images;
     if (getenv("FUIFGPU_VERBOSE"))
         fprintf(stderr, "fuifgpu: %d images, %d tiles, %s configuration, %d persistent wavefronts (%d per SIMD), %d queues, context scheduler %s\n", n_images, b->n_tiles,
-                b->dense ? "dense" : "wide", b->n_waves, b->waves_per_simd, b->n_queues, b->sched ? "on" : "off");
+                b->cfg == 1 ? "dense" : b->cfg == 2 ? "wide" : "wide (two batches in flight)", b->n_waves, b->waves_per_simd, b->n_queues, b->sched ? "on" : "off");
     return FUIFGPU_OK;
 }
 
@@ -603,7 +608,7 @@ int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
         P.ctx_units_per_queue = b->share ? (uint32_t)std::min<size_t>(r->ctx_bytes / (size_t)std::max(b->n_queues, 1) / 256, (size_t)0xFFFFFF00u / (size_t)std::max(b->n_queues, 1)) : b->ctx_units_per_queue;
     } P.progress = b->d_progress; P.group_start = b->d_group_start;
     HIPCHK(hipEventRecord(b->ev[0], st));
-    launch_maniac_decode(P, b->n_waves, b->dense, b->n_tiles > b->n_loaded ? 1 : 0, st);
+    launch_maniac_decode(P, b->n_waves, b->cfg, b->n_tiles > b->n_loaded ? 1 : 0, st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->ev[1], st));
     b->decode_timed = true;
@@ -687,6 +692,12 @@ int fuifgpu_batch_status(fuifgpu_batch *b, int32_t *status, uint32_t *bytes_cons
     HIPCHK(hipDeviceSynchronize());
     if (status) HIPCHK(hipMemcpy(status, b->d_status, sizeof(int32_t) * b->n_loaded, hipMemcpyDeviceToHost));
     if (bytes_consumed) HIPCHK(hipMemcpy(bytes_consumed, b->d_consumed, sizeof(uint32_t) * b->n_loaded, hipMemcpyDeviceToHost));
+    return FUIFGPU_OK;
+}
+
+int fuifgpu_batch_set_in_flight(fuifgpu_batch *b, int n_batches) {
+    if (!b || n_batches < 1) return FUIFGPU_E_ARG;
+    b->in_flight = n_batches;
     return FUIFGPU_OK;
 }
 

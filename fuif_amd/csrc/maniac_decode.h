@@ -94,7 +94,7 @@ int maniac_max_supernodes(int max_nodes);
 size_t maniac_scratch_bytes(int max_nodes, size_t *bfs_off, size_t *leaves_off, size_t *stack_off, size_t *queue_off, size_t *subtree_off);
 // The kernel exists in two LDS configurations: wide (1 wavefront per SIMD, most of the context tree in
 // LDS) and dense (4 per SIMD).  maniac_max_waves = wavefronts the device holds at once in that configuration.
-int maniac_max_waves(int dense, int *per_simd = nullptr);
-void launch_maniac_decode(const DecodeParams &P, int n_waves, int dense, int hand_off, hipStream_t stream);
+int maniac_max_waves(int config, int *per_simd = nullptr);   // config: 0 wide (two batches in flight), 1 dense, 2 wide (a launch alone)
+void launch_maniac_decode(const DecodeParams &P, int n_waves, int config, int hand_off, hipStream_t stream);
 
 }  // namespace fuifgpu

@@ -34,8 +34,9 @@
 // item above trades scalar instructions for vector ones.  Measured on the 1024 x 4K launch (round 4,
 // profiles/r4_instruction_probes.txt): one more scalar instruction per symbol costs 0.37 % of the launch,
 // a vector one 0.19 %, a taken branch 0.44 % -- ~165 instructions per symbol since round 4 (was 202).
-// Two LDS configurations are built: "wide" = 19.7 KB per wave (20 supernodes = 10 KB, 8.4 KB of chunk
-// properties, small state; exactly two waves per SIMD since round 5) and "dense" = 5.7 KB (no supernode slots, 32-pixel chunks;
+// Three LDS configurations are built: "wide" for a launch alone = 38.9 KB per wave (58 supernodes = 29 KB, 8.4 KB of chunk properties,
+// small state; one wave per SIMD), "wide" for hosts with two batches in flight = 19.7 KB (20 supernodes; exactly two waves per SIMD:
+// fuifgpu_batch_set_in_flight, round 5) and "dense" = 5.7 KB (no supernode slots, 32-pixel chunks;
 // 80 VGPRs: 24 waves per CU, six per SIMD, which fill each other's stalls when tiles outnumber SIMDs).
 // The 16 KB chance transition table is read through L1/L2 instead: its lookups are off the dependency
 // chain thanks to the batched update.
@@ -96,7 +97,13 @@ constexpr int CH_ZERO = 0, CH_SIGN = 1, CH_EXP = 2, CH_MANT = 16, CH_N = 31;
 #ifndef FUIF_LDS_DENSE
 #define FUIF_LDS_DENSE 0   // round 4: the two slots served 0.9 % of the walk rounds (profiles/r2_walk_locality.txt) and cost every round an LDS read, a compare and two branches
 #endif
-constexpr int kLdsWide = FUIF_LDS_WIDE, kLdsDense = FUIF_LDS_DENSE;
+// A host that decodes ONE batch at a time (fuifgpu_batch_set_in_flight: 1, the default) gets the wide configuration of rounds 1-4 for its launches with few tiles: 58
+// supernodes in LDS, one wavefront per SIMD -- a launch alone is 6 % faster that way (20.8 against 22.1 s for 1024 x 4K without index); a host that keeps two batches
+// in flight gets the 20-supernode instantiation, whose wavefronts leave room for the other launch's.
+#ifndef FUIF_LDS_WIDE_ALONE
+#define FUIF_LDS_WIDE_ALONE 58
+#endif
+constexpr int kLdsWide = FUIF_LDS_WIDE, kLdsDense = FUIF_LDS_DENSE, kLdsWideAlone = FUIF_LDS_WIDE_ALONE;
 #ifndef FUIF_SIZE_ORDERED
 #define FUIF_SIZE_ORDERED 64   // supernodes (breadth first) whose children are numbered by subtree size; 0 = exit order everywhere
 #endif
@@ -1815,20 +1822,24 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
 #endif
 }
 
-int maniac_max_waves(int dense, int *per_simd) {
+// config: 0 = wide for hosts with two batches in flight (kLdsWide supernodes in LDS), 1 = dense, 2 = wide for a launch alone (kLdsWideAlone)
+int maniac_max_waves(int config, int *per_simd) {
     int dev = 0, per_cu = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    hipError_t e = dense ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_maniac_decode<kLdsDense, true>, 64, 0)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_maniac_decode<kLdsWide, true>, 64, 0);
+    hipError_t e = config == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_maniac_decode<kLdsDense, true>, 64, 0)
+                 : config == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_maniac_decode<kLdsWideAlone, true>, 64, 0)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_maniac_decode<kLdsWide, true>, 64, 0);
     if (e != hipSuccess || per_cu < 1) per_cu = 1;
     if (per_simd) *per_simd = per_cu / 4 > 0 ? per_cu / 4 : 1;   // a CU has 4 SIMDs
     return per_cu * prop.multiProcessorCount;
 }
 
 // hand_off = 0 promises that no tile reads what another tile of the launch writes (one tile per image)
-void launch_maniac_decode(const DecodeParams &P, int n_waves, int dense, int hand_off, hipStream_t stream) {
-    if (dense) hipLaunchKernelGGL((k_maniac_decode<kLdsDense, true>), dim3(n_waves), dim3(64), 0, stream, P);
+void launch_maniac_decode(const DecodeParams &P, int n_waves, int config, int hand_off, hipStream_t stream) {
+    if (config == 1) hipLaunchKernelGGL((k_maniac_decode<kLdsDense, true>), dim3(n_waves), dim3(64), 0, stream, P);
+    else if (config == 2 && hand_off) hipLaunchKernelGGL((k_maniac_decode<kLdsWideAlone, true>), dim3(n_waves), dim3(64), 0, stream, P);
+    else if (config == 2) hipLaunchKernelGGL((k_maniac_decode<kLdsWideAlone, false>), dim3(n_waves), dim3(64), 0, stream, P);
     else if (hand_off) hipLaunchKernelGGL((k_maniac_decode<kLdsWide, true>), dim3(n_waves), dim3(64), 0, stream, P);
     else hipLaunchKernelGGL((k_maniac_decode<kLdsWide, false>), dim3(n_waves), dim3(64), 0, stream, P);
 }

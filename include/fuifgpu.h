@@ -197,6 +197,12 @@ int fuifgpu_index_append(const uint8_t *blob, size_t size, const int32_t *first_
 int fuifgpu_batch_group_index(fuifgpu_batch *batch, int image, int32_t *first_channel, uint32_t *start, int cap, int *n_groups);
 /* enable = 0: ignore trailers from the next upload on (A/B measurements; default 1) */
 int fuifgpu_batch_set_group_parallel(fuifgpu_batch *batch, int enable);
+/* How many batches the host keeps in flight on this device (default 1); applies from the next upload on.  It only matters for launches with few tiles
+ * (streams without group index: one wavefront per picture).  1: such a launch runs with 58 supernodes of every context tree in LDS, one wavefront per
+ * SIMD -- the fastest a launch ALONE can be (20.8 s for 1024 x 4K).  2 or more: 20 supernodes, two wavefronts per SIMD -- 6 % slower alone, but the
+ * launch of a second batch on a second stream runs beside it: 24.5 s for two such launches instead of 41.6 s (profiles/r5_overlap_timeline_and_wide_variants.txt).
+ * The reference decodes one file at a time (fuif.cpp:213-233); no counterpart. */
+int fuifgpu_batch_set_in_flight(fuifgpu_batch *batch, int n_batches);
 
 /* ---- several GPUs of one node (round 5) ---------------------------------------------------------------------
  * The reference decodes file after file on one core (fuif.cpp:213-233: fuif_decode_file + undo_transforms per file); a batch of

@@ -63,6 +63,7 @@ SELECTED = [
     ("tests/test_gpu_parity.py::test_invalid_permutation_flags_the_image_and_zero_fills", 5),
     ("tests/test_gpu_synthetic.py::test_sibling_outliving_its_primary_is_refused_not_dangling", 3),
     ("tests/test_gpu_synthetic.py::test_yuv420p_fixtures_with_and_without_the_fused_colour_kernel", 6),
+    ("tests/test_gpu_parity.py::test_wide_configuration_for_two_batches_in_flight", 25),
     ("tests/test_gpu_synthetic.py::test_jpeg_like_chain_fused_and_unfused_match_oracle", 20),
     ("tests/test_gpu_group_parallel.py::test_add_group_index_copies_refused_streams_through", 2),
 ]

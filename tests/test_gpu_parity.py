@@ -180,3 +180,31 @@ def test_invalid_permutation_flags_the_image_and_zero_fills(gpulib, manifest):
                     assert not g.any()
     finally:
         batch.close()
+
+
+def test_wide_configuration_for_two_batches_in_flight(gpulib, manifest):
+    """fuifgpu_batch_set_in_flight(2): launches with few tiles (streams without index) run the wide kernel instantiation with 20 instead of 58
+    supernodes in LDS (two wavefronts per SIMD, room for a second batch's launch) -- same planes, same bytes consumed; two such batches decode
+    side by side on two streams (where the runtime has streams: one GPU box; the emulator runs them one after the other)"""
+    picks = [e for e in manifest["fixtures"] if e["name"] in ("c1_rgb8_512x512", "rgb8_97x61", "jpeg420_256x192_q90", "rgb8_512x384_I16_bigtrees", "rgba14_80x72")]
+    assert picks
+    for e in picks:
+        c = e["cases"][0]
+        blob = golden_blob(e, c)
+        plan = gpulib.Plan(blob)
+        a, b = gpulib.Batch(plan, 3, 3 * len(blob)), gpulib.Batch(plan, 1, len(blob))     # (one picture: the wide configuration also on the one-wavefront emulator)
+        try:
+            for bt, n in ((a, 3), (b, 1)):
+                bt.set_in_flight(2)
+                bt.set_group_parallel(False)
+                bt.upload([blob] * n)
+            a.decode(); b.decode()
+            a.undo_transforms(); b.undo_transforms()
+            a.sync(); b.sync()
+            for bt, n in ((a, 3), (b, 1)):
+                st, used = bt.status()
+                assert not (st & 2).any() and (used == used[0]).all(), e["name"]
+                for i in range(n):
+                    assert [plane_hash(p) for p in bt.out_planes(i)] == [x["sha256"] for x in c["post"]], e["name"]
+        finally:
+            a.close(); b.close()

@@ -55,6 +55,7 @@ if "--no-streams" not in argv:
 cap = sum(len(b) for b in blobs) + 4096 * n
 batches = [fuif_amd.Batch(plan, n, cap, streaming=True) for _ in range(2)]
 for b, s in zip(batches, streams):
+    b.set_in_flight(1 if "--in-flight-1" in argv else 2)     # (1: the 58-supernode wide configuration of a launch alone)
     if "--no-index" in argv:
         b.set_group_parallel(False)        # files as the reference CLI writes them: one wavefront per picture (the wide configuration, one per SIMD)
     b.upload(blobs, stream=s)
@@ -143,7 +144,7 @@ tile_log = "--tile-log" in argv      # (a -DFUIF_TILELOG build: tools/build_vari
 if tile_log:
     for b in batches:
         b.tile_log()                 # arms logging
-for mode in ((True,) if "--only-pipelined" in argv else (False, True)) * rounds:
+for mode in ((True,) if "--only-pipelined" in argv else (False,) if "--only-sequential" in argv else (False, True)) * rounds:
     dt = run(mode)
     print("%s: %d launches of %d x %dx%d in %.2f s -> %.2f s per launch, %.1f Mpixels/s (%s)" % (
         "pipelined (two streams, stagger %.1f s)" % stagger if mode else "sequential", K, n, w, h, dt, dt / K, K * px / dt / 1e6,
