@@ -665,17 +665,39 @@ def overlapped_steps(args, plan, blobs, dev, dist, W, H, index=True, warmup=None
     streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
     # (zeros, not empty: planes are 256-byte aligned inside an image's slice and no kernel writes the gaps between them -- the per-image checksum covers
     # the whole slice, so the gaps must hold the same thing here and in the resident path's slab; a 3840x2160 plane happens to leave none)
-    outs = [torch.zeros(n_slice * info.out_elems, dtype=torch.int32, device=dev) for _ in range(2)]
     warm = max(args.warmup, 1) if warmup is None else max(warmup, 0)
     steps = args.steps if steps is None else steps
-    sums = torch.zeros((warm + steps, n), dtype=torch.int64, device=dev)
     cap = sum(len(b) for b in blobs) + 4096 * n
-    batches = [fuif_amd.Batch(plan, n, cap, streaming=True) for _ in range(2)]
-    for b, st in zip(batches, streams):
-        b.set_in_flight(2)                # (two batches in flight: launches with few tiles leave room for each other's wavefronts)
-        b.set_group_parallel(index)       # (False: the streams' group index is ignored -- one wavefront per picture, what a file without the trailer gets)
-        b.upload(blobs, stream=st.cuda_stream)
-        b.sync(st.cuda_stream)
+    batches, outs, sums = [], None, None
+    try:
+        # allocation and upload first, then ONE agreement over the ranks before the region's first barrier: a rank that cannot hold two batches must not leave
+        # the others waiting in a collective it never reaches (the caller falls back to the resident steps on every rank alike)
+        try:
+            outs = [torch.zeros(n_slice * info.out_elems, dtype=torch.int32, device=dev) for _ in range(2)]
+            sums = torch.zeros((warm + steps, n), dtype=torch.int64, device=dev)
+            for _ in range(2):
+                batches.append(fuif_amd.Batch(plan, n, cap, streaming=True))
+            for b, st in zip(batches, streams):
+                b.set_in_flight(2)                # (two batches in flight: launches with few tiles leave room for each other's wavefronts)
+                b.set_group_parallel(index)       # (False: the streams' group index is ignored -- one wavefront per picture, what a file without the trailer gets)
+                b.upload(blobs, stream=st.cuda_stream)
+                b.sync(st.cuda_stream)
+        except Exception:
+            fd.all_ok(False, dist, dev)
+            raise
+        if not fd.all_ok(True, dist, dev):
+            raise RuntimeError("the overlapped region could not be set up on another rank")
+        return _overlapped_steps_on(args, plan, blobs, dev, dist, batches, streams, outs, sums, n, n_slice, warm, steps, index)
+    finally:
+        for b in batches:      # (also when an allocation or a launch failed: the caller falls back to the resident steps and needs the memory)
+            b.close()
+
+
+def _overlapped_steps_on(args, plan, blobs, dev, dist, batches, streams, outs, sums, n, n_slice, warm, steps, index):
+    import torch
+    import fuif_amd
+    from fuif_amd import dist as fd
+    info = plan.info
 
     def fence():
         torch.cuda.synchronize()
@@ -713,9 +735,6 @@ def overlapped_steps(args, plan, blobs, dev, dist, W, H, index=True, warmup=None
         st_words, _ = b.status()
         ok = ok and not st_words.any()
     launch_ms = [float(b.timing()[0]) for b in used]
-    for b in batches:
-        b.close()
-    del outs
     return {"elapsed": elapsed, "sums": sums, "launch_ms": launch_ms, "status_ok": bool(ok), "n_slice": n_slice, "warm": warm, "steps": steps}
 
 
@@ -989,17 +1008,26 @@ def main():
     info = plan.info
     # The timed region: consecutive steps overlapped on the device (default), each verified through per-image checksums that are
     # compared below with the resident path's outputs.  --no-overlap / --no-index: the steps of the resident batch are the timed ones.
-    ov = ov_seq = None
+    ov = ov_seq = overlap_error = None
     if not args.no_overlap and not args.no_index:
-        ov = overlapped_steps(args, plan, blobs, dev, dist, W, H)
+        # (a failure of the overlapped region -- it holds two batches' worth of device memory -- must not cost the line: the steps of the resident batch are then
+        # the timed ones, as with --no-overlap, and the line says why.  The ranks agree on the outcome inside overlapped_steps, before its first barrier.)
+        overlap_error = None
+        try:
+            ov = overlapped_steps(args, plan, blobs, dev, dist, W, H)
+        except (fuif_amd.FuifGpuError, RuntimeError, MemoryError) as e:
+            ov, overlap_error = None, "%s: %s" % (type(e).__name__, str(e)[:300])
         import gc
         gc.collect()
         torch.cuda.empty_cache()
         # the same steps with the group index IGNORED (files as the reference CLI writes them: one wavefront per picture), overlapped the same way:
         # two launches in flight = two wavefronts per SIMD, which is what the wide kernel configuration is built for since round 5
-        if world == 1 and not args.no_seq_compare:
+        if ov is not None and world == 1 and not args.no_seq_compare:
             # (no warm-up step: the kernels have just run; an EVEN number of steps, so that every step has a partner beside it -- a step alone is 22 s)
-            ov_seq = overlapped_steps(args, plan, blobs, dev, dist, W, H, index=False, warmup=0, steps=max(2, args.seq_steps + (args.seq_steps & 1)))
+            try:
+                ov_seq = overlapped_steps(args, plan, blobs, dev, dist, W, H, index=False, warmup=0, steps=max(2, args.seq_steps + (args.seq_steps & 1)))
+            except (fuif_amd.FuifGpuError, RuntimeError, MemoryError):
+                ov_seq = None      # (the leg then shows the step alone only)
             gc.collect()
             torch.cuda.empty_cache()
     out = torch.zeros(args.batch * info.out_elems, dtype=torch.int32, device=dev)     # (zeros: see overlapped_steps -- the checksums cover the alignment gaps between planes)
@@ -1366,6 +1394,8 @@ def main():
                           "gather": "final gather of the packed pictures to rank 0 (chunked RCCL gather) + all_gather of per-image checksums", "input_gen_s": round(t_gen, 1), "upload_s": round(t_upload, 3),
                           "value_basis": "compressed streams resident in HBM when the timed region starts, at every N; the PCIe-inclusive rate is value_incl_h2d (N = 1 only), never value"},
                "roofline": roofline}
+        if overlap_error is not None:
+            res["config"]["overlapped_steps"] = "FAILED (%s): the timed steps are the resident batch's, one after the other, as with --no-overlap" % overlap_error
         if overlap_info is not None:
             res["config"]["overlapped_steps"] = ("two streaming batch objects on two HIP streams take the steps in turn; a step = one entropy launch over all %d streams + "
                                                  "its inverse transforms in slices of %d images + per-image checksums; consecutive steps overlap on the device (the second "

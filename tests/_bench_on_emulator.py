@@ -27,4 +27,14 @@ torch.cuda.Stream = _FakeStream
 torch.device = lambda *a, **k: _real_device("cpu")      # bench.py's torch.device("cuda", local_rank)
 import bench  # noqa: E402
 
+if os.environ.get("FUIF_TEST_BREAK_OVERLAP"):
+    # the overlapped region cannot be set up (as when two batches do not fit the device): the line must still come, from the resident steps
+    import fuif_amd
+    _real_batch = fuif_amd.Batch
+
+    def _refusing(plan, n_images, cap, *a, **k):
+        if k.get("streaming"):
+            raise fuif_amd.FuifGpuError(7, "test: no memory for a streaming batch")
+        return _real_batch(plan, n_images, cap, *a, **k)
+    fuif_amd.Batch = _refusing
 bench.main()

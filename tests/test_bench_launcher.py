@@ -96,3 +96,28 @@ def test_bench_main_default_path_on_one_emulated_rank(tmp_path):
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "fuif")):
         ref = d["reference_encoded_streams"]
         assert "error" not in ref and ref["decoded_equals_source_pixels"] is True and ref["distinct_streams"] == 2
+
+
+def test_bench_line_survives_an_overlapped_region_that_cannot_be_set_up(tmp_path):
+    """two streaming batches do not fit (here: refused by a test hook in tests/_bench_on_emulator.py): both gloo ranks agree on it before the region's first
+    barrier, the timed steps are the resident batch's, the line says so and still carries value / roofline / cpu_baseline"""
+    import socket
+    if sys.platform != "linux" or os.uname().machine != "x86_64":
+        import pytest
+        pytest.skip("the emulator's context switch is x86-64 SysV assembly")
+    from test_emulated_kernels import build_emulated_library
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, FUIF_AMD_LIB=build_emulated_library(), EMU_ALARM="900", FUIF_BENCH_CACHE=str(tmp_path / "cache"), FUIF_TEST_BREAK_OVERLAP="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "_bench_on_emulator.py"), "--gpus", "2", "--batch", "3", "--width", "97", "--height", "61", "--distinct", "2", "--steps", "2", "--warmup", "1",
+           "--no-live-traffic", "--no-cpu-all-cores"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["parity_roundtrip_ok"] is True and d["value"] > 0
+    assert d["config"]["overlapped_steps"].startswith("FAILED") and "no memory for a streaming batch" in d["config"]["overlapped_steps"]
+    assert "overlap" not in d and "kernel_ms" in d["roofline"] and d["cpu_baseline"]["value"] > 0
