@@ -9,17 +9,19 @@
 //     template <IO> bool fuif_decode(IO&, Image&, fuif_options)     encoding/encoding.cpp:599-720
 //     void Image::undo_transforms(int keep)                         image/image.cpp:94-115
 //
-// The reference's own definitions of these three are kept in the link under the names
+// The reference's own definitions of these three stay in the link under the names
 // fuif_decode_file_cpu / fuif_decode_cpu / Image::undo_transforms_cpu (the Makefile compiles
-// encoding.cpp and image.cpp with -Dname=name_cpu) and are used for what is outside the GPU
-// scope: -i/--identify (header only), the loop of undo_transforms(keep != 0) (its Transform::apply calls come back here), and the streams the library
+// encoding.cpp and image.cpp with -Dname=name_cpu: encoder and decoder are one translation unit), but THIS FILE DOES NOT CALL THE
+// REFERENCE'S DECODER (round 6): -i/--identify is answered from the header bytes here (identify_header below), and a stream the library
 // reports as FUIFGPU_E_UNSUPPORTED / FUIFGPU_ST_UNSUPPORTED (a data-driven Permute over channels of different geometry; a 2D
-// match with a forward reference).  Stills and
+// match with a forward reference; more than 50 reference properties) is a loud error -- a planner regression or a failed launch in
+// a deployment can never silently produce the output of the code this path replaces.  Only the ten-line LOOP of
+// undo_transforms(keep != 0) (image.cpp:94-115) is the reference's: its Transform::apply calls come back here.
+// A maintainer who wants the reference's decoder as a route for out-of-scope streams builds this one file with
+// -DFUIFGPU_WITH_CPU_FALLBACK (`make WITH_CPU_FALLBACK=1`: binaries under _build_with_cpu_fallback/, never the shipped _build/);
+// that build honours FUIFGPU_ALLOW_CPU_FALLBACK=1 and FUIFGPU_CPU_TRANSFORMS=1 at run time.  Stills and
 // animations (FUAF), Squeeze / YCoCg / YCbCr / DCT / Quantize / Subsample / Palette / Approximate / 2D-match / Permute
-// chains all decode on the GPU.  By DEFAULT nothing is ever routed to the reference's CPU decoder: an
-// unsupported stream is a loud error (so a planner regression cannot hide behind a fallback);
-// FUIFGPU_ALLOW_CPU_FALLBACK=1 opts in to the reference's code for such input; FUIFGPU_VERBOSE=1 reports
-// on stderr which path decoded.  Everything else (fuif.cpp, import/export code, the encoder) is
+// chains all decode on the GPU; FUIFGPU_VERBOSE=1 reports on stderr which path decoded.  Everything else (fuif.cpp, import/export code, the encoder) is
 // compiled and linked UNCHANGED; fuif_encode_file is bound as well, only to append the group index to the file the
 // reference's encoder wrote when FUIFGPU_WRITE_INDEX=1 asks for it (off by default).
 //
@@ -55,9 +57,14 @@ namespace refdct {
 #include "transform/subsample.h"
 }
 
-// the reference's CPU implementations, renamed at compile time (see Makefile)
+#ifdef FUIFGPU_WITH_CPU_FALLBACK
+// the reference's CPU implementations, renamed at compile time (see Makefile): declared -- and callable -- in the opt-in build only
 bool fuif_decode_file_cpu(const char *filename, Image &image, fuif_options options);
 template <typename IO> bool fuif_decode_cpu(IO &io, Image &image, fuif_options options);
+#define FUIFGPU_OUTSIDE_HINT "set FUIFGPU_ALLOW_CPU_FALLBACK=1 to decode it with the reference's CPU code"
+#else
+#define FUIFGPU_OUTSIDE_HINT "this binding was built without the reference's CPU decoder (-DFUIFGPU_WITH_CPU_FALLBACK)"
+#endif
 
 namespace {
 
@@ -80,10 +87,13 @@ std::map<const Image *, std::unique_ptr<Resident>> &registry() {
     return *r;
 }
 bool env_flag(const char *name) { const char *e = getenv(name); return e && *e && strcmp(e, "0") != 0; }
-// The reference's own CPU code is kept in the link (as *_cpu) but is OPT-IN: by default a stream or transform the GPU path
-// does not take is a loud error, so a planner regression in a deployment can never silently run the code this path replaces.
-// FUIFGPU_ALLOW_CPU_FALLBACK=1 lets such input go to the reference's decoder instead.
+// A stream or transform the GPU path does not take is a loud error.  Only a binding compiled with -DFUIFGPU_WITH_CPU_FALLBACK holds call
+// sites of the reference's decoder at all, and even there they are opt-in at run time (FUIFGPU_ALLOW_CPU_FALLBACK=1).
+#ifdef FUIFGPU_WITH_CPU_FALLBACK
 bool cpu_fallback_allowed() { return env_flag("FUIFGPU_ALLOW_CPU_FALLBACK"); }
+#else
+constexpr bool cpu_fallback_allowed() { return false; }
+#endif
 // den / num / loops of an animation header (encoding.cpp:611-622): the four varints after the magic, then these
 struct Cursor {
     const std::vector<uint8_t> &b; size_t pos;
@@ -183,22 +193,83 @@ bool gpu_decode_bytes(const std::vector<uint8_t> &bytes, Image &image, const fui
     return true;
 }
 
+
+// -i / --identify: the header lines the reference prints (encoding.cpp:601-702 with options.identify), from the header bytes alone --
+// magic, the basic-info varints, the responsive offsets, the transform list; no Image is touched, no channel data is read and nothing
+// of the reference's decoder runs.  Same text at every verbosity level (v_printf is the reference's, io.cpp:58-65).
+template <typename IO> bool identify_header(IO &io) {
+    char buff[5];
+    if (!io.gets(buff, 5)) { e_printf("Could not read header from file: %s\n", io.getName()); return false; }
+    const bool multi_frame = !strcmp(buff, "FUAF");
+    if (!multi_frame && strcmp(buff, "FUIF")) { e_printf("%s is not a FUIF file\n", io.getName()); return false; }
+    auto varint = [&io]() { int r = 0; for (int k = 0; k < 10; k++) { const int c = io.get_c(); if (c < 0) break; if (c < 128) return r + c; r = (r + c - 128) << 7; } return -1; };   // encoding.cpp:45-59
+    const int nb_channels = varint() - '0', bit_depth = varint() - '&';
+    const int w = varint() + 1, h = varint() + 1;
+    int nb_frames = 1;
+    if (multi_frame) {
+        nb_frames = varint() + 2;
+        varint();                                                     // den
+        if (varint()) for (int i = 1; i < nb_frames; i++) varint();   // num
+        varint();                                                     // loops
+    }
+    const int colormodel = varint();
+    v_printf(1, "%s: %i-channel, %i-bit, ", io.getName(), nb_channels, bit_depth);
+    if (multi_frame) v_printf(1, "%ix%i %s%s animation (%i frames)\n", w, h / nb_frames, colormodel_name(colormodel, nb_channels), colorprofile_name(colormodel), nb_frames);
+    else v_printf(1, "%ix%i %s%s image\n", w, h, colormodel_name(colormodel, nb_channels), colorprofile_name(colormodel));
+    const int max_properties = varint();
+    v_printf(4, "Global option: up to %i back-referencing MANIAC properties.\n", max_properties);
+    v_printf(7, "First part of header decoded (basic info). Read %i bytes so far.\n", io.ftell());
+    if (nb_channels < 1) return true;
+    static const int sizes[5] = {0, 16, 8, 4, 2};   // responsive_sizes, encoding/encoding.h (LQIP, 1/16 .. 1/2)
+    int offsets[5], relative = 0;
+    for (int s = 0; s < 5; s++) { offsets[s] = varint() * TRUNCATION_OFFSET_RESOLUTION + relative; relative = offsets[s]; }
+    relative = io.ftell();
+    for (int s = 0; s < 5; s++) {
+        offsets[s] += relative;
+        if (s) v_printf(3, "Responsive truncation point for size 1/%i at position %i\n", sizes[s], offsets[s]);
+        else v_printf(3, "Responsive truncation point for LQIP at position %i\n", offsets[s]);
+    }
+    v_printf(7, "Second part of header decoded (responsive offsets and global parameters; before transforms). Read %i bytes so far.\n", io.ftell());
+    const int nb_transforms = varint();
+    v_printf(2, "Image data underwent %i transformations: ", nb_transforms);
+    for (int i = 0; i < nb_transforms; i++) {
+        const int id_and_nb_params = varint();
+        if (id_and_nb_params < 0) break;
+        Transform t(id_and_nb_params & 0xf);
+        if (t.has_parameters()) for (int j = 0, n = id_and_nb_params >> 4; j < n; j++) t.parameters.push_back(varint());
+        if (i) v_printf(2, ", ");
+        v_printf(2, "%s", t.name());
+        if (t.ID == TRANSFORM_PALETTE && t.parameters.size() >= 3) {
+            if (t.parameters[0] == t.parameters[1]) v_printf(3, "[Compact channel %i to ", t.parameters[0]);
+            else v_printf(3, "[channels %i-%i with ", t.parameters[0], t.parameters[1]);
+            v_printf(3, "%i colors]", t.parameters[2]);
+        }
+    }
+    v_printf(2, "\n");
+    v_printf(6, "Header decoded. Read %i bytes so far.\n", io.ftell());
+    return true;
+}
+
 }  // namespace
 
 template <typename IO> bool fuif_decode(IO &io, Image &image, fuif_options options) {
     registry().erase(&image);   // whatever was decoded into an Image at this address before is gone now
-    if (options.identify) return fuif_decode_cpu(io, image, options);
+    if (options.identify) return identify_header(io);
     std::vector<uint8_t> bytes = slurp(io);
     bool unsupported = false;
     if (gpu_decode_bytes(bytes, image, options, &unsupported)) return true;
     if (!unsupported) return false;
     if (!cpu_fallback_allowed()) {
-        e_printf("fuifgpu: this stream needs a feature outside the GPU path (%s); set FUIFGPU_ALLOW_CPU_FALLBACK=1 to decode it with the reference's CPU code\n", fuifgpu_last_error());
+        e_printf("fuifgpu: this stream needs a feature outside the GPU path (%s); " FUIFGPU_OUTSIDE_HINT "\n", fuifgpu_last_error());
         return false;
     }
+#ifdef FUIFGPU_WITH_CPU_FALLBACK
     if (env_flag("FUIFGPU_VERBOSE")) fprintf(stderr, "fuifgpu: outside the GPU path, decoding with the reference's CPU code\n");
     BlobReader again(bytes.data(), bytes.size());  // outside the GPU scope: the reference's own decoder
     return fuif_decode_cpu(again, image, options);
+#else
+    return false;
+#endif
 }
 template bool fuif_decode(FileIO &io, Image &image, fuif_options options);
 template bool fuif_decode(BlobReader &io, Image &image, fuif_options options);
@@ -299,12 +370,14 @@ void image_from_outputs(Image &img, fuifgpu_plan *plan, fuifgpu_batch *batch, in
     img.transform.clear();
     img.error = false;
 }
+#ifdef FUIFGPU_WITH_CPU_FALLBACK
 bool cpu_decode_whole(const std::vector<uint8_t> &bytes, Image &img, const fuif_options &options) {
     BlobReader io(bytes.data(), bytes.size());
     if (!fuif_decode_cpu(io, img, options)) return false;
     img.undo_transforms(0);   // (macro-renamed: the reference's CPU implementation)
     return !img.error;
 }
+#endif
 }  // namespace
 
 namespace {
@@ -373,27 +446,33 @@ void decode_group_here(fuifgpu_plan *plan, const std::vector<int> &idx, const st
     fuifgpu_batch_destroy(batch);
 }
 
-// FUIFGPU_DEVICES = "all" | "0,2,3": the GPUs fuif_decode_files() spreads a list of files over (unset: the calling thread's current device)
-std::vector<int> devices_from_env() {
-    std::vector<int> out;
+// FUIFGPU_DEVICES = "all" | "0,2,3": the GPUs fuif_decode_files() spreads a list of files over (unset: the calling thread's current device).
+// A list that does not parse, or a device count that cannot be read, is an ERROR (false): a typo must not quietly leave a GPU out.
+bool devices_from_env(std::vector<int> &out) {
+    out.clear();
     const char *e = getenv("FUIFGPU_DEVICES");
-    if (!e || !*e) return out;
+    if (!e || !*e) return true;
     int n = 0;
-    if (fuifgpu_device_count(&n) != FUIFGPU_OK) return out;
-    if (!strcmp(e, "all")) { for (int d = 0; d < n; d++) out.push_back(d); return out; }
+    if (fuifgpu_device_count(&n) != FUIFGPU_OK) { e_printf("fuifgpu: FUIFGPU_DEVICES is set but the device count cannot be read (%s)\n", fuifgpu_last_error()); return false; }
+    if (!strcmp(e, "all")) { for (int d = 0; d < n; d++) out.push_back(d); return true; }
     for (const char *p = e; *p;) {
         char *end = nullptr;
         const long d = strtol(p, &end, 10);
-        if (end == p) break;
+        if (end == p || (*end != ',' && *end != 0) || (*end == ',' && end[1] == 0)) {
+            e_printf("fuifgpu: FUIFGPU_DEVICES=\"%s\" is not \"all\" or a comma-separated list of GPU numbers\n", e);
+            out.clear();
+            return false;
+        }
         out.push_back((int)d);
         p = *end == ',' ? end + 1 : end;
     }
-    return out;
+    return true;
 }
 }  // namespace
 
 int fuif_decode_files(const char *const *filenames, int n_files, Image *images, fuif_options options, bool *ok_out) {
-    const std::vector<int> dev = devices_from_env();
+    std::vector<int> dev;
+    if (!devices_from_env(dev)) { if (ok_out) for (int i = 0; i < n_files; i++) ok_out[i] = false; return 0; }
     return fuif_decode_files_on(filenames, n_files, images, options, dev.empty() ? nullptr : dev.data(), (int)dev.size(), ok_out);
 }
 
@@ -452,9 +531,11 @@ int fuif_decode_files_on(const char *const *filenames, int n_files, Image *image
             BlobReader io(bytes[i].data(), bytes[i].size());
             if (fuif_decode(io, images[i], options)) { fuifgpu_boundary_undo_transforms(&images[i], 0); ok[i] = !images[i].error; }
         } else if (cpu_route[i] == 1) {
-            if (no_cpu) { e_printf("fuifgpu: %s needs a feature outside the GPU path; set FUIFGPU_ALLOW_CPU_FALLBACK=1 to decode it with the reference's CPU code\n", filenames[i]); continue; }
+            if (no_cpu) { e_printf("fuifgpu: %s needs a feature outside the GPU path; " FUIFGPU_OUTSIDE_HINT "\n", filenames[i]); continue; }
+#ifdef FUIFGPU_WITH_CPU_FALLBACK
             if (verbose) fprintf(stderr, "fuifgpu: %s is outside the GPU path, decoding with the reference's CPU code\n", filenames[i]);
             ok[i] = cpu_decode_whole(bytes[i], images[i], options) ? 1 : 0;
+#endif
         }
         if (plans[i]) fuifgpu_plan_destroy(plans[i]);
     }
@@ -498,9 +579,10 @@ void fuifgpu_boundary_undo_transforms(Image *self, int keep) {
     fuifgpu_batch_status(res.batch, &status, nullptr);
     if (status & FUIFGPU_ST_UNSUPPORTED) {
         if (!cpu_fallback_allowed()) {
-            e_printf("fuifgpu: the transform chain needs a feature outside the GPU path; set FUIFGPU_ALLOW_CPU_FALLBACK=1 to run it with the reference's CPU code\n");
+            e_printf("fuifgpu: the transform chain needs a feature outside the GPU path; " FUIFGPU_OUTSIDE_HINT "\n");
             self->error = true;
         } else {
+#ifdef FUIFGPU_WITH_CPU_FALLBACK
             // the planes on the host are still the coded ones: decode again with the reference's code and undo there
             BlobReader again(res.bytes.data(), res.bytes.size());
             Image redo;
@@ -511,6 +593,7 @@ void fuifgpu_boundary_undo_transforms(Image *self, int keep) {
                 self->channel.swap(redo.channel); self->transform.clear();
                 self->nb_channels = redo.nb_channels; self->nb_meta_channels = redo.nb_meta_channels; self->error = redo.error;
             } else self->error = true;
+#endif
         }
         registry().erase(self);
         return;
@@ -832,7 +915,12 @@ bool gpu_inv_match(Image &img, std::vector<int> par) {
 
 bool fuifgpu_boundary_transform_apply(Transform *self, Image &input, bool inverse) __asm__("_ZN9Transform5applyER5Imageb");
 bool fuifgpu_boundary_transform_apply(Transform *self, Image &input, bool inverse) {
-    if (inverse && !env_flag("FUIFGPU_CPU_TRANSFORMS")) {
+#ifdef FUIFGPU_WITH_CPU_FALLBACK
+    const bool cpu_transforms = env_flag("FUIFGPU_CPU_TRANSFORMS");   // opt-in build only: every inverse through the reference's code
+#else
+    constexpr bool cpu_transforms = false;
+#endif
+    if (inverse && !cpu_transforms) {
         bool done = false, claimed = true;
         switch (self->ID) {
             case TRANSFORM_YCoCg: done = gpu_inv_color(input, false); break;
@@ -853,7 +941,7 @@ bool fuifgpu_boundary_transform_apply(Transform *self, Image &input, bool invers
         // a transform this layer binds, on an image its kernels do not take (or a device error): the image is untouched (every
         // gpu_inv_* works on a copy), so the reference's own loop can run -- unless the caller asked for the GPU path or nothing
         if (claimed && !cpu_fallback_allowed()) {
-            e_printf("fuifgpu: inverse %s could not run on the GPU (%s); set FUIFGPU_ALLOW_CPU_FALLBACK=1 to run it with the reference's CPU code\n", self->name(), fuifgpu_last_error());
+            e_printf("fuifgpu: inverse %s could not run on the GPU (%s); " FUIFGPU_OUTSIDE_HINT "\n", self->name(), fuifgpu_last_error());
             return false;
         }
         if (claimed && env_flag("FUIFGPU_VERBOSE")) fprintf(stderr, "fuifgpu: inverse %s with the reference's CPU code (Transform::apply)\n", self->name());

@@ -726,7 +726,8 @@ struct Builder {
             *n = op.pad > 0 && (size_t)op.idct_first + (size_t)op.pad <= plan.idct_src.size() ? op.pad : 0;
             return plan.idct_src.data() + op.idct_first;
         };
-        auto same_plane = [](const PlaneRef &a, const PlaneRef &b) { return a.buf == b.buf && a.off == b.off; };
+        // (an Op's unused PlaneRef slots are value-initialised -- buf 0 = BUF_COEF, off 0, w = h = 0 -- and must not pass for the coded plane at offset 0: ADVICE r5)
+        auto same_plane = [](const PlaneRef &a, const PlaneRef &b) { return a.buf == b.buf && a.off == b.off && (int64_t)a.w * a.h > 0 && (int64_t)b.w * b.h > 0; };
         for (size_t qk = 0; qk < ops.size(); qk++) {
             if (ops[qk].kind != OP_QUANT) continue;
             int nq = 0;

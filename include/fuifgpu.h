@@ -17,7 +17,10 @@
 extern "C" {
 #endif
 
-#define FUIFGPU_ABI_VERSION 2   /* 2 (round 4): fuifgpu_encode_options starts with struct_size; sibling batches freeze the launch resources */
+#define FUIFGPU_ABI_VERSION 3   /* 2 (round 4): fuifgpu_encode_options starts with struct_size; sibling batches freeze the launch resources.
+                                 * 3 (rounds 5-6): every fuifgpu_batch_* call runs on the batch's own device (the caller's is restored on return);
+                                 *   the device / peer-copy / checksum / in-flight entry points exist; fuifgpu_batch_create reads FUIFGPU_IN_FLIGHT.
+                                 *   A host checks fuifgpu_abi_version() >= the version whose entry points it binds before looking them up. */
 
 /* error codes (0 = success).  The reference reports these conditions as `return false` +
  * e_printf (encoding/encoding.cpp:601-605, 276-279, 697-700). */
@@ -210,7 +213,9 @@ int fuifgpu_batch_set_in_flight(fuifgpu_batch *batch, int n_batches);
  * the calling thread's current device, as in HIP: fuifgpu_set_device() selects it, a batch lives on the device that was current when
  * it was created, and every fuifgpu_batch_* call runs on the batch's own device whatever the calling thread's current device is (it
  * is restored on return) -- so a host runs one thread per device (fuif_decode_files in fuif_amd/boundary does) or one thread over
- * the batches of several devices.  fuifgpu_dev_* and the single-transform entry points use the calling thread's current device.
+ * the batches of several devices.  A `stream` handed to a fuifgpu_batch_* call must be a stream OF THE BATCH'S DEVICE (NULL = that
+ * device's null stream); the library does not check it, and HIP reports a foreign stream as an invalid handle at the first launch.
+ * fuifgpu_dev_* and the single-transform entry points use the calling thread's current device.
  * Several PROCESSES (one per GPU, torch.distributed / RCCL: bench.py, fuif_amd/dist.py) each simply see their own device. */
 int fuifgpu_device_count(int *n_devices);
 int fuifgpu_set_device(int device);                                   /* FUIFGPU_E_ARG: no such device */

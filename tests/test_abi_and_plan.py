@@ -17,7 +17,7 @@ def test_header_symbols_exported(gpulib):
     L = ctypes.CDLL(os.path.join(ROOT, "fuif_amd", "libfuifgpu.so"))
     for s in declared:
         assert hasattr(L, s), s
-    assert gpulib.lib().fuifgpu_abi_version() == 2
+    assert gpulib.lib().fuifgpu_abi_version() == 3
 
 
 def test_plan_matches_reference_geometry(gpulib, manifest):
