@@ -511,7 +511,7 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
     {
         // scheduler state, zeroed before every launch: q_head | done_total | statistics | started_total | heartbeat | cu claim table |
         // cu_alive | cu_live | cu_foreign | img_next | img_done | ctx_used | tile records
-        const size_t words = 20 + (2 * 4096 + 1) + 3 * 4096 + 4 * 4096 + 2 * (size_t)n_images + 2 * (size_t)b->n_queues + (b->sched ? (size_t)b->n_tiles * (sizeof(TileRec) / 4) : 0);
+        const size_t words = 24 + (2 * 4096 + 1) + 3 * 4096 + 4 * 4096 + 2 * (size_t)n_images + 2 * (size_t)b->n_queues + (b->sched ? (size_t)b->n_tiles * (sizeof(TileRec) / 4) : 0);
         if (words > b->sched_words) {
             hipFree(b->d_sched); b->d_sched = nullptr; b->sched_words = 0;
             HIPCHK(hipMalloc((void **)&b->d_sched, words * 4));
@@ -603,7 +603,9 @@ int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
     P.tiles = b->d_tiles; P.n_tiles = b->n_tiles; P.sched = b->sched; P.n_queues = b->n_queues;
     {
         uint32_t *w = b->d_sched;
-        P.q_head = w; P.done_total = w + 1; P.sched_stats = reinterpret_cast<unsigned long long *>(w + 2); P.started_total = w + 18; P.heartbeat = w + 19; w += 20;
+        P.q_head = w; P.done_total = w + 1; P.sched_stats = reinterpret_cast<unsigned long long *>(w + 2); P.started_total = w + 18; P.heartbeat = w + 19;
+        P.ctx_used = reinterpret_cast<unsigned long long *>(w + 20);   // (byte offset 80: 8-byte aligned)
+        w += 24;
         P.yield_slack = 4;   // (round 4, profiles/r4_scheduler_knobs.txt: 4 -> 7.30 s, 8 -> 7.37 s, 16 -> 7.60 s, 32 -> 7.83 s on the trimmed kernel)
         if (const char *e = getenv("FUIFGPU_YIELD_SLACK")) P.yield_slack = (uint32_t)std::max(0, atoi(e));
         P.prio_base = kDefaultPrioBase;   // size classes <= base run at wavefront priority 3, base+1 at 2, base+2 at 1; negative: all 0
@@ -615,7 +617,7 @@ int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
         if (const char *e = getenv("FUIFGPU_LONG_PER_SIMD")) P.long_per_simd = std::max(0, atoi(e));
         P.img_next = w; w += b->n_loaded;
         P.img_done = w; w += b->n_loaded;
-        P.ctx_used = w; w += b->n_queues;
+        w += b->n_queues;   // (rounds 2-5: one bump counter per queue)
         P.q_turn = w; w += b->n_queues;
         P.tile_rec = reinterpret_cast<TileRec *>(w);
         P.q_img_begin = b->d_layout; P.q_images = b->d_layout + b->n_queues + 1; P.img_tile_begin = b->d_layout + b->n_queues + 1 + b->n_loaded;

@@ -74,9 +74,10 @@ struct DecodeParams {
                                  // while (0: no such rule).  Long tiles are the launch's critical path; by chance a SIMD got 1 to 7 of them and each extra
                                  // one costs the others ~1 % (profiles/r3_stragglers.txt)
     TileRec *tile_rec;           // sched 1: [n_tiles]; zeroed before the launch
-    uint8_t *ctx_scratch;        // sched 1: one arena per queue for the context areas (supernodes | leaf chances) of its images' tiles
-    uint32_t ctx_units_per_queue; //         arena size in 256-byte units
-    uint32_t *ctx_used;          // sched 1: [n_queues] units handed out (bump allocation: a launch never frees); zeroed before the launch
+    uint8_t *ctx_scratch;        // sched 1: the arena of the context areas (supernodes | leaf chances) of suspendable tiles: ctx_units_per_queue * n_queues units
+    uint32_t ctx_units_per_queue; //         arena size in 256-byte units per queue (the arena is sized per queue and used as ONE since round 6)
+    unsigned long long *ctx_used; // sched 1: units handed out from the bottom (low word: long tiles) and from the top (high word: the others) of the arena -- bump
+                                 //          allocation, a launch never frees; zeroed before the launch
     unsigned long long *sched_stats; // -DFUIF_STATS builds, sched 1: {ticks wavefronts spent without work before the last tile finished, tiles picked up, suspensions, ...}; zeroed before the launch
     uint32_t *simd_claim;        // [2 * 4096 + 1] {arrivals, 1 + dense index} per physical CU key, then the CU counter; zeroed before the launch
     uint32_t *progress;          // [n_images][n_channels] 0 = nothing yet, 1 + rows finished once the header is known; zeroed before the launch

@@ -104,12 +104,37 @@ constexpr int CH_ZERO = 0, CH_SIGN = 1, CH_EXP = 2, CH_MANT = 16, CH_N = 31;
 #define FUIF_LDS_WIDE_ALONE 58
 #endif
 constexpr int kLdsWide = FUIF_LDS_WIDE, kLdsDense = FUIF_LDS_DENSE, kLdsWideAlone = FUIF_LDS_WIDE_ALONE;
+// Round 6: the dense configuration keeps the first kLdsDenseNarrow NARROW supernodes behind the root (256 bytes each) in LDS after all.  Since round 3 the
+// children of the top supernodes are numbered by subtree size, and subtree size predicts the traffic almost perfectly: on the long 4K groups the 11 largest
+// second-level supernodes serve 63-70 % of the rounds behind the root (tools/supernode_packing.py on the oracle's visit counts; round 2's "two slots serve
+// 0.9 %" was measured on breadth-first numbering).  The room comes from the property rows, which a narrow group stores as int16 (its properties lie inside
+// 13 bits): 2112 bytes of the 4224, plus 704 bytes more -- 6440 bytes per wavefront, still 24 wavefronts per CU (13 x 512-byte LDS granules each).
+#ifndef FUIF_LDS_DENSE_NARROW
+#define FUIF_LDS_DENSE_NARROW 11
+#endif
+constexpr int kLdsDenseNarrow = FUIF_LDS_DENSE_NARROW;
 #ifndef FUIF_SIZE_ORDERED
 #define FUIF_SIZE_ORDERED 64   // supernodes (breadth first) whose children are numbered by subtree size; 0 = exit order everywhere
 #endif
 constexpr int kSizeOrdered = FUIF_SIZE_ORDERED;
 constexpr uint32_t kLeafFlag = 0x800000u;
 constexpr uint32_t kSlowFlag = 0x400000u;   // exit leads to a plain tree node (index in the low 16 bits), not to a supernode
+// NARROW supernodes (round 6): 4 bytes per lane instead of 8 -- a supernode is 256 bytes, two cache lines instead of four.  The per-symbol chain of a
+// long tile is two dependent memory round trips whose latency grows with everything the ~6000 resident wavefronts keep in flight; halving the supernode
+// record is worth 8-15 % of that chain (tools/ubench_context.hip, profiles/r6_ubench_context_layouts.txt).  Lane word:
+//     [1:0] exit, bits 13..12 | [6:2] property | [19:7] split value (signed, 13 bits) | [31:20] exit, bits 11..0      (a rotation by 20 makes the exit contiguous)
+// exit = kLeafFlagN | leaf id, or the number of the child supernode (14 bits).  A channel group gets narrow supernodes when every property of it stays
+// inside +-4095 (8-bit pictures up to 4096 rows / columns do), it has at most 32 properties (default options: 25) and its tree at most kNarrowMaxNodes
+// nodes -- then no supernode index, leaf id or split value can overflow its field and the node-by-node walk (kSlowFlag) cannot occur; any other
+// group keeps the 8-byte form.  The word IS the ds_bpermute address (bits 7..2: bit 7 is the split's lowest bit, so lanes 32..63 of the property
+// vector mirror lanes 0..31 for such groups).
+constexpr uint32_t kLeafFlagN = 0x2000u;
+constexpr int kNarrowMaxNodes = 13999;   // (7 * 6999 + 5) / 12 = 4083 supernodes at most: inside every area (capi.hip: FUIF_MAX_SUPER = 4096), leaf ids < 7000
+constexpr int kNarrowSplitMax = 4095, kNarrowSplitMin = -4096;
+DEV uint32_t pack_narrow(int split, uint32_t prop, uint32_t exit14) {
+    const int sv = split > kNarrowSplitMax ? kNarrowSplitMax : (split < kNarrowSplitMin ? kNarrowSplitMin : split);   // values lie in [-4095, 4095]: the clamped comparison is the same
+    return ((exit14 >> 12) & 3u) | ((prop & 31u) << 2) | (((uint32_t)sv & 0x1FFFu) << 7) | ((exit14 & 0xFFFu) << 20);
+}
 constexpr int kPropPitch = 33;    // odd pitch: conflict-free column writes / row reads; groups with more than 31 properties use 2 * 33 - 1 = 65 words and half the chunk
 constexpr int kPropPitchWide = 65;
 // Pixels whose properties are prepared at once (lane = pixel).  The property rows are the largest LDS
@@ -227,6 +252,23 @@ DEV uint2 global_load_supernode(const uint2 *base, uint32_t sn, uint32_t lane8) 
     uint2 v;
     uint32_t off;
     asm volatile("v_lshl_add_u32 %1, %3, 9, %4\n\tglobal_load_dwordx2 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(v), "=&v"(off) : "s"(base), "s"(sn), "v"(lane8) : "memory");
+    return v;
+}
+#endif
+
+// narrow supernode `sn` (256 B), lane's word
+#ifdef FUIF_EMU
+DEV uint32_t lds_load_node_n(uint32_t lds_byte_addr) { return *reinterpret_cast<const uint32_t *>(emu_lds_base + lds_byte_addr); }
+DEV uint32_t global_load_supernode_n(const uint32_t *base, uint32_t sn, uint32_t lane4) { return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(base) + sn * 256u + lane4); }
+#else
+DEV uint32_t lds_load_node_n(uint32_t lds_byte_addr) {
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_byte_addr) : "memory");
+    return v;
+}
+DEV uint32_t global_load_supernode_n(const uint32_t *base, uint32_t sn, uint32_t lane4) {
+    uint32_t v, off;
+    asm volatile("v_lshl_add_u32 %1, %3, 8, %4\n\tglobal_load_dword %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(v), "=&v"(off) : "s"(base), "s"(sn), "v"(lane4) : "memory");
     return v;
 }
 #endif
@@ -381,7 +423,14 @@ struct LeafRegs {
     int leafv;          // per lane
     uint32_t touched;   // scalar
     uint32_t bits;      // scalar
+    // COMPACT leaves (round 6): a group whose symbols have at most 8 magnitude bits (|diff| <= 255: exponent 0..7) touches only the zero, the sign, 7
+    // exponent and 7 mantissa chances of a leaf (symbol.h:167-183), so its leaves are 16 chances = 32 bytes instead of 31 padded to 64: slots 0 zero, 1 sign,
+    // 2..8 exponent, 9..15 mantissa.  Only the mantissa's first slot moves (16 -> 9); lanes 16..63 mirror lanes 0..15.  Half the leaf bytes of such
+    // a group's context (the larger half of it once the supernodes are narrow): profiles/r6_ubench_context_layouts.txt.
+    int mb;             // scalar: slot of mantissa chance 0 (CH_MANT = 16, compact leaves: 9)
+    uint32_t mirror;    // scalar: 1, compact leaves: 0x10001 -- a 16-bit slot mask times this covers the lanes 16..31 that mirror 0..15
 };
+constexpr int kMantCompact = 9;
 DEV int leaf_bit(Rac &r, Stream &s, int lane, LeafRegs &L, int idx) {
     // Every lane evaluates the decision for ITS chance with the current range (rac.h:43-52,82-95):
     // chance = (range*b12+0x800)>>12 as one 64-bit mad, threshold = range-chance, low >= threshold.
@@ -421,7 +470,7 @@ DEV int leaf_symbol(Rac &r, Stream &s, int lane, LeafRegs &L, int min, int max) 
             for (int pos = e - 1; pos >= 0; pos--) {
                 const int minabs1 = have | (1 << pos);
                 if (minabs1 <= amax) {  // else the 1-bit is impossible (symbol.h:180)
-                    const int b = leaf_bit(r, s, lane, L, CH_MANT + pos);
+                    const int b = leaf_bit(r, s, lane, L, L.mb + pos);
                     have = b ? minabs1 : have;
                 }
             }
@@ -486,7 +535,7 @@ DEV int fast_symbol(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
     if (LIKELY(e < emax)) {
         // have | 1 << pos < 2^(e+1) <= 2^emax <= amax: every mantissa bit is coded (symbol.h:173-183)
         for (int pos = e - 1; pos >= 0; pos--) {
-            thr = (uint32_t)rdlane((int)lane_thresholds(r.range, L.leafv), CH_MANT + pos);
+            thr = (uint32_t)rdlane((int)lane_thresholds(r.range, L.leafv), L.mb + pos);
             const bool b = r.low >= thr;
             r.range = b ? r.range - thr : thr;
             r.low -= b ? thr : 0u;
@@ -497,7 +546,7 @@ DEV int fast_symbol(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
         for (int pos = e - 1; pos >= 0; pos--) {
             const int minabs1 = have | (1 << pos);
             if (minabs1 > amax) { skipped |= 1u << pos; continue; }   // the 1-bit is impossible (symbol.h:180)
-            thr = (uint32_t)rdlane((int)lane_thresholds(r.range, L.leafv), CH_MANT + pos);
+            thr = (uint32_t)rdlane((int)lane_thresholds(r.range, L.leafv), L.mb + pos);
             const bool b = r.low >= thr;
             r.range = b ? r.range - thr : thr;
             r.low -= b ? thr : 0u;
@@ -506,8 +555,8 @@ DEV int fast_symbol(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
         }
     }
     const uint32_t emask = (1u << e) - 1u;
-    L.touched = 3u | (((1u << (e + (int)one)) - 1u) << CH_EXP) | ((emask & ~skipped) << CH_MANT);
-    L.bits = ((uint32_t)sign << CH_SIGN) | (one << (CH_EXP + e)) | (((uint32_t)have & emask) << CH_MANT);
+    L.touched = 3u | (((1u << (e + (int)one)) - 1u) << CH_EXP) | ((emask & ~skipped) << L.mb);
+    L.bits = ((uint32_t)sign << CH_SIGN) | (one << (CH_EXP + e)) | (((uint32_t)have & emask) << L.mb);
     return sign ? have : -have;
 }
 #ifndef FUIF_EMU
@@ -610,21 +659,21 @@ DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
         FS_RN_CHECK("94f", "84")
         // ---- mantissa, e = idx - 2 < emax: every bit is coded  (chances 16 + pos, top bit first); hv collects the INVERTED bits
         "s_cmp_eq_u32 %[idx], 2\n\ts_mov_b32 %[hv], 0\n\ts_cbranch_scc1 60f\n\t"
-        "s_add_u32 %[midx], %[idx], 14\n"
+        "s_add_u32 %[midx], %[idx], %[mb2]\n"
         "41:\n\t"
         FS_THR_PREP "s_sub_u32 %[midx], %[midx], 1\n\tv_readlane_b32 %[thr], " FS_VA ", %[midx]\n\t"
         "s_sub_u32 %[t0], %[R], %[thr]\n\ts_sub_u32 %[t1], %[L], %[thr]\n\t"
         "s_cselect_b32 %[L], %[L], %[t1]\n\ts_cselect_b32 %[R], %[thr], %[t0]\n\ts_addc_u32 %[hv], %[hv], %[hv]\n\t"
         FS_RN_CHECK("96f", "86")
-        "s_cmp_gt_u32 %[midx], 16\n\ts_cbranch_scc1 41b\n"
+        "s_cmp_gt_u32 %[midx], %[mb]\n\ts_cbranch_scc1 41b\n"
         // ---- value and the (index, bit) pairs of the decisions taken, for leaf_commit
         "60:\n\t"
-        "s_sub_u32 %[e], %[idx], 2\n\ts_bfm_b32 %[t1], %[e], 16\n\t"              // mantissa chances: ((1 << e) - 1) << 16
+        "s_sub_u32 %[e], %[idx], 2\n\ts_bfm_b32 %[t1], %[e], %[mb]\n\t"            // mantissa chances: ((1 << e) - 1) << mb (16; compact leaves: 9)
         "s_add_u32 %[t0], %[idx], 1\n\ts_bfm_b32 %[touched], %[t0], 0\n\ts_or_b32 %[touched], %[touched], %[t1]\n\t"   // chances 0 .. idx
-        "s_lshl_b32 %[t0], %[hv], 16\n\ts_andn2_b32 %[t0], %[t1], %[t0]\n\t"      // the mantissa bits as decided, at 16 ..
+        "s_lshl_b32 %[t0], %[hv], %[mb]\n\ts_andn2_b32 %[t0], %[t1], %[t0]\n\t"    // the mantissa bits as decided, at mb ..
         "s_lshl_b32 %[bits], 1, %[idx]\n\ts_or_b32 %[bits], %[bits], %[t0]\n\t"   // the exponent's closing 1
         "s_andn2_b32 %[t1], 2, %[sm]\n\ts_or_b32 %[bits], %[bits], %[t1]\n\t"     // sign decision
-        "s_lshr_b32 %[t0], %[t0], 16\n\ts_bitset1_b32 %[t0], %[e]\n\t"           // magnitude = 1 << e | mantissa
+        "s_lshr_b32 %[t0], %[t0], %[mb]\n\ts_bitset1_b32 %[t0], %[e]\n\t"         // magnitude = 1 << e | mantissa
         "s_xor_b32 %[t0], %[t0], %[sm]\n\ts_sub_u32 %[res], %[t0], %[sm]\n\t"
         "s_branch 99f\n"
         // ---- exponent exhausted: e = emax = idx - 1, no closing 1; a mantissa 1 that would exceed amax is not coded (symbol.h:180)
@@ -634,7 +683,7 @@ DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
         "42:\n\t"
         "s_sub_u32 %[t1], %[t1], 1\n\ts_cbranch_scc1 61f\n\t"
         "s_lshl_b32 %[t0], 1, %[t1]\n\ts_or_b32 %[res], %[have], %[t0]\n\ts_cmp_gt_i32 %[res], %[amax]\n\ts_cbranch_scc1 45f\n\t"
-        FS_THR_PREP "s_add_u32 %[t0], %[t1], 16\n\tv_readlane_b32 %[thr], " FS_VA ", %[t0]\n\t"
+        FS_THR_PREP "s_add_u32 %[t0], %[t1], %[mb]\n\tv_readlane_b32 %[thr], " FS_VA ", %[t0]\n\t"
         "s_sub_u32 %[t0], %[R], %[thr]\n\ts_cmp_ge_u32 %[L], %[thr]\n\t"
         "s_cselect_b32 %[R], %[t0], %[thr]\n\ts_cselect_b32 %[t0], %[thr], 0\n\ts_cselect_b32 %[have], %[res], %[have]\n\ts_sub_u32 %[L], %[L], %[t0]\n\t"
         // (the renormalisation stub uses t0 and hv as scratch here: t1 is the loop counter)
@@ -649,8 +698,8 @@ DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
         "s_or_b32 %[skipped], %[skipped], %[t0]\n\ts_branch 42b\n"
         "61:\n\t"
         "s_bfm_b32 %[t0], %[e], 0\n\ts_bfm_b32 %[t1], %[e], 2\n\t"              // (1 << e) - 1; exponent decisions: chances 2 .. 2 + e - 1
-        "s_andn2_b32 %[touched], %[t0], %[skipped]\n\ts_lshl_b32 %[touched], %[touched], 16\n\ts_or_b32 %[touched], %[touched], %[t1]\n\ts_or_b32 %[touched], %[touched], 3\n\t"
-        "s_and_b32 %[bits], %[have], %[t0]\n\ts_lshl_b32 %[bits], %[bits], 16\n\ts_andn2_b32 %[t1], 2, %[sm]\n\ts_or_b32 %[bits], %[bits], %[t1]\n\t"
+        "s_andn2_b32 %[touched], %[t0], %[skipped]\n\ts_lshl_b32 %[touched], %[touched], %[mb]\n\ts_or_b32 %[touched], %[touched], %[t1]\n\ts_or_b32 %[touched], %[touched], 3\n\t"
+        "s_and_b32 %[bits], %[have], %[t0]\n\ts_lshl_b32 %[bits], %[bits], %[mb]\n\ts_andn2_b32 %[t1], 2, %[sm]\n\ts_or_b32 %[bits], %[bits], %[t1]\n\t"
         "s_xor_b32 %[t0], %[have], %[sm]\n\ts_sub_u32 %[res], %[t0], %[sm]\n\t"
         "s_branch 99f\n"
         // ---- the symbol is zero
@@ -664,7 +713,7 @@ DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
           [t1] "=&s"(t1), [thr] "=&s"(thr), [idx] "=&s"(idx), [ilast] "=&s"(ilast), [sm] "=&s"(sm), [hv] "=&s"(hv), [e] "=&s"(e),
           [midx] "=&s"(midx), [amax] "=&s"(amax), [have] "=&s"(have), [skipped] "=&s"(skipped)
         : [leafv] "v"(L.leafv), [win] "v"(s.win), [amaxp] "s"(F.amax_pos), [amaxn] "s"(F.amax_neg), [ilastp] "s"(F.ilast_pos),
-          [ilastn] "s"(F.ilast_neg)
+          [ilastn] "s"(F.ilast_neg), [mb] "s"(L.mb), [mb2] "s"(L.mb - 2)
         : "scc", "vcc", FS_VA, FS_VB, FS_VC, FS_VK0, FS_VK1);
     r.range = R; r.low = Lo; s.pos = s.win_base + widx;
     L.touched = touched; L.bits = bits;
@@ -673,12 +722,14 @@ DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
 #endif
 DEV void leaf_commit(LeafRegs &L, int lane, const uint16_t *table) {
 #ifdef FUIF_EMU
-    if ((L.touched >> (lane & 31)) & 1u) L.leafv = table[L.leafv * 2 + ((L.bits >> (lane & 31)) & 1u)];   // (lanes 32..63 mirror 0..31)
+    const int slot = lane & (L.mirror == 1u ? 31 : 15);   // (lanes 32..63 mirror 0..31; compact leaves: 16..63 mirror 0..15)
+    if ((L.touched >> slot) & 1u) L.leafv = table[L.leafv * 2 + ((L.bits >> slot) & 1u)];
 #else
     // the scalar masks ARE lane masks: inverse_ballot hands them to the compiler as per-lane conditions (EXEC and a v_cndmask
     // operand) without a vector test per lane.  (An inline-asm load here would be invisible to the compiler's s_waitcnt
     // placement: tools/test_fast_symbol.hip caught exactly that.)
-    const unsigned long long b64 = (unsigned long long)L.bits * 0x100000001ull, t64 = (unsigned long long)L.touched * 0x100000001ull;   // both halves: lanes 32..63 mirror 0..31
+    // both halves: lanes 32..63 mirror 0..31 (compact leaves: the 16-bit slot masks are first doubled into lanes 16..31, one scalar multiply each)
+    const unsigned long long b64 = (unsigned long long)(L.bits * L.mirror) * 0x100000001ull, t64 = (unsigned long long)(L.touched * L.mirror) * 0x100000001ull;
     const uint32_t boff = __builtin_amdgcn_inverse_ballot_w64(b64) ? 2u : 0u;
     if (__builtin_amdgcn_inverse_ballot_w64(t64))
         L.leafv = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(table) + (((uint32_t)L.leafv << 2) | boff));
@@ -717,13 +768,25 @@ struct RefChan {  // one reference channel of the current group (context_predict
 
 template <int kLdsSuper>
 struct Shared {
+    static constexpr bool kDense = kLdsSuper == kLdsDense;
     uint2 snodes[kLdsSuper > 0 ? kLdsSuper * 64 : 1];   // breadth-first top of the supernode tree: lane i = {split_i, prop_i << 2 | exit_i << 8}
-    static constexpr int kChunk = kLdsSuper == kLdsDense ? kChunkDense : 64;
-    int32_t cprops[(kChunk > 4 ? kChunk : 4) * kPropPitch]; // [pixel of the chunk][property]; the supernode build borrows 256 words
+    static constexpr int kChunk = kDense ? kChunkDense : 64;
+    static constexpr int kPropWords = (kChunk > 4 ? kChunk : 4) * kPropPitch;
+    // narrow supernodes resident in LDS: the wide configurations keep them in `snodes`; the dense one behind the int16 property rows of a narrow
+    // group, i.e. in the second half of `cprops` and in `ntail` right behind it (kNarrowBase: word offset from cprops)
+    static constexpr int kLdsN = kDense ? kLdsDenseNarrow : kLdsSuper;
+    static constexpr int kNarrowBase = (kPropWords + 1) / 2;
+    static constexpr int kTailWords = kDense && kLdsDenseNarrow * 64 > kPropWords - kNarrowBase ? kLdsDenseNarrow * 64 - (kPropWords - kNarrowBase) : 1;
+    int32_t cprops[kPropWords]; // [pixel of the chunk][property]; the supernode build borrows 256 words
+    uint32_t ntail[kTailWords];
     uint16_t meta_ctx[3][32];            // three SimpleSymbolCoder contexts of the tree coder
     int32_t lo[kMaxProps], hi[kMaxProps];
     RefChan refs[kMaxRefs];
 };
+
+// the element type of a chunk's property rows (k_maniac_decode: int16 for a narrow group in the dense configuration)
+template <bool kNarrow, int kLdsSuper>
+struct PropRow { using type = std::conditional_t<kNarrow && Shared<kLdsSuper>::kDense, int16_t, int32_t>; };
 
 // kHandOff = false: every image is one tile, nothing a tile writes is read by another one before the
 // kernel ends -- plain cached stores and loads (write-through stores drop the line from L2, and the
@@ -746,7 +809,11 @@ template <int kLdsSuper, bool kHandOff>
 __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParams P) {
     __shared__ Shared<kLdsSuper> sh;
     constexpr int kChunk = Shared<kLdsSuper>::kChunk;
+    constexpr int kLdsN = Shared<kLdsSuper>::kLdsN;          // narrow supernodes resident in LDS (behind the root)
+    constexpr bool kDense = Shared<kLdsSuper>::kDense;
     const int lane = threadIdx.x;
+    // where they live: the wide configurations' `snodes`, the dense one's second half of the property rows (a narrow group's rows are int16)
+    uint32_t *const lds_narrow = kDense ? reinterpret_cast<uint32_t *>(sh.cprops) + Shared<kLdsSuper>::kNarrowBase : reinterpret_cast<uint32_t *>(sh.snodes);
 
     const uint16_t *tree_table = P.tables;          // cut 2, alpha 0xFFFFFFFF/19 (compound.h:262)
     const uint16_t *pixel_table = P.tables + 8192;  // cut 6, alpha 0x0d000000 (encoding.h:54-55)
@@ -763,8 +830,10 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
 #ifdef FUIF_EMU
     emu_lds_base = reinterpret_cast<const char *>(&sh.snodes[0]);
     const uint32_t lds_nodes_addr = 0;
+    const uint32_t lds_narrow_addr = (uint32_t)(reinterpret_cast<const char *>(lds_narrow) - reinterpret_cast<const char *>(&sh.snodes[0]));
 #else
     const uint32_t lds_nodes_addr = (uint32_t)(uintptr_t)(&sh.snodes[0]);  // LDS byte offset (low half of the flat address)
+    const uint32_t lds_narrow_addr = (uint32_t)(uintptr_t)lds_narrow;
 #endif
     // geometry of a 6-level supernode in heap order (children of slot k: 2k+1 = "> split", 2k+2 = "<= split"):
     // lane e owns exit e; exp/msk = the decisions its path needs and the slots they sit in
@@ -789,6 +858,8 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
     int home_q = 0;
     uint32_t simd_key = 0, simd_slot = 0;   // simd_slot: this wavefront's entry of P.simd_long (CU key x 4 + SIMD)
     constexpr uint32_t kLongClass = 2, kRecLong = 1u << 12;   // size class of a long tile (>= 1/8 of its picture's samples); its mark in TileRec::flags
+    constexpr uint32_t kRecNarrow = 1u << 13;                 // TileRec::flags: the suspended group's supernodes are narrow (4 bytes per lane)
+    constexpr uint32_t kRecCompact = 1u << 14;                //                 ... its leaves are compact (16 chances, 32 bytes)
     if (sched) {
         // home queue = dense index of the CU this wavefront sits on (the first arrival numbers it)
 #ifdef FUIF_EMU
@@ -1199,10 +1270,16 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         int predictability = 2048;
         Rac rac;
         int tree_size = 1, n_super = 1, cur_leaf = 0;
+        bool narrow = false;   // this group's supernodes are 4-byte lane words (kLeafFlagN): decided after the tree parse, kept in TileRec::flags across a suspension
+        bool compact = false;  // this group's leaves are 16 chances of 32 bytes (LeafRegs::mb): every symbol of it has at most 8 magnitude bits
         if (resumed) {
             rac.range = rflu(rec->range); rac.low = rflu(rec->low);
             tree_size = rfl((int)rec->tree_size); n_super = rfl((int)rec->n_super); cur_leaf = rfl((int)rec->cur_leaf);
-            for (int sn = 1; sn <= kLdsSuper && sn < n_super; sn++) sh.snodes[(sn - 1) * 64 + lane] = snodes_g[(size_t)sn * 64 + lane];
+            narrow = (rflu(rec->flags) & kRecNarrow) != 0u;
+            compact = (rflu(rec->flags) & kRecCompact) != 0u;
+            if (ctx_slot < 0) leaves = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(snodes_w) + (size_t)n_super * (narrow ? 256u : 512u));   // pinned: see the leaf placement below
+            if (narrow) for (int sn = 1; sn <= kLdsN && sn < n_super; sn++) lds_narrow[(sn - 1) * 64 + lane] = reinterpret_cast<const uint32_t *>(snodes_g)[(size_t)sn * 64 + lane];
+            else for (int sn = 1; sn <= kLdsSuper && sn < n_super; sn++) sh.snodes[(sn - 1) * 64 + lane] = snodes_g[(size_t)sn * 64 + lane];
             __syncthreads();
         }
         if (!resumed) {
@@ -1256,6 +1333,8 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
 
         // ---- MANIAC tree: compound.h:277-320 with an explicit stack -------------------------
         __syncthreads();  // sh.lo/hi, sh.refs
+        // narrow supernodes need every property (value and split) inside 13 signed bits and one property per lane of HALF a wavefront
+        const bool narrow_ok = nprops <= 32 && __ballot(lane < nprops && (sh.lo[lane] < -kNarrowSplitMax || sh.hi[lane] > kNarrowSplitMax)) == 0ull;
         for (int k = lane; k < 3 * 32; k += 64) sh.meta_ctx[k / 32][k % 32] = 0;
         __syncthreads();
         if (lane == 0) for (int k = 0; k < 3; k++) symbol_chance_init(sh.meta_ctx[k], 1024);
@@ -1323,6 +1402,20 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
             break;
         }
 
+        // compact leaves: every channel of the group codes differences of at most 8 magnitude bits (symbol.h:160-183: the exponent stops at
+        // ilog2(amax), amax <= maxv - zero or zero - minv with predictor 0, <= maxv - minv with any other)
+        {
+            bool small = true;
+            for (int i = beginc; i <= endc; i++) {
+                const int minv = rfl(ld_agent(&meta[i].minval)), maxv = rfl(ld_agent(&meta[i].maxval));
+                if (minv == maxv) continue;
+                const int zero = minv > 0 ? minv : (maxv < 0 ? maxv : 0);
+                const int bound = predictor == 0 ? (maxv - zero > zero - minv ? maxv - zero : zero - minv) : maxv - minv;
+                small = small && bound <= 255;
+            }
+            compact = small;
+        }
+        const uint32_t leaf_bytes = compact ? 32u : 64u;
         // ---- supernode layout ------------------------------------------------------------------
         // The tree is cut into complete 6-level subtrees ("supernodes", 63 node slots in heap order
         // + 64 exits).  Lane i of a supernode holds {splitval_i, property_i | exit_i << 8}; a walk
@@ -1341,13 +1434,24 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
             // (7n+5)/12 supernodes are enough for n inner nodes (capi.hip), so nothing falls to the node-by-node walk
             const uint32_t inner = (uint32_t)(tree_size - 1) / 2u;
             const uint32_t sn_cap = (7u * inner + 5u) / 12u + 1u;
-            const uint32_t units = sn_cap * 2u + ((uint32_t)nleaves * (uint32_t)kLeafStride * 2u + 255u) / 256u;   // 256-byte units
+            narrow = narrow_ok && tree_size <= kNarrowMaxNodes;
+            const uint32_t sn_units = narrow ? sn_cap : sn_cap * 2u;   // a narrow supernode is one 256-byte unit
+            const uint32_t units = sn_units + ((uint32_t)nleaves * leaf_bytes + 255u) / 256u;   // 256-byte units
             uint32_t off = 0xFFFFFFFFu;
+            const bool low_end = ((rflu(tile.flags) >> kTileSizeClassShift) & 15u) <= kLongClass + 1u;
             if (lane == 0) {
-                const uint32_t q = (uint32_t)(img % n_queues);
-                if (ld_agent(&P.ctx_used[q]) + units <= P.ctx_units_per_queue) {
-                    const uint32_t o = atomicAdd(&P.ctx_used[q], units);
-                    if (o + units <= P.ctx_units_per_queue) off = q * P.ctx_units_per_queue + o;
+                // ONE arena, two bump pointers in one 64-bit word: the tiles that hold >= 1/16 of their picture -- the long per-symbol chains that bound
+                // the launch, whose contexts are what the memory system has to keep close -- are packed from the bottom, everything else from the top.
+                // (Rounds 2-5 gave every CU queue its own 64 MiB arena: the hot contexts of a launch lay 512 pages apart instead of ~100; tight
+                // placement is worth ~6 % of a long tile's per-symbol chain, profiles/r6_ubench_context_layouts.txt.)  Both counters only grow, and an
+                // area is granted from ONE atomic snapshot of both, so areas never overlap; a failed request leaves its units unused (the arena
+                // was full: the tile is pinned to this wavefront's scratch area).
+                const uint32_t total = P.ctx_units_per_queue * (uint32_t)n_queues;
+                const unsigned long long seen = __hip_atomic_load(P.ctx_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned long long)(uint32_t)seen + (seen >> 32) + units <= total) {
+                    const unsigned long long o = atomicAdd(P.ctx_used, low_end ? (unsigned long long)units : (unsigned long long)units << 32);
+                    const unsigned long long lo = (uint32_t)o + (low_end ? units : 0u), hi = (o >> 32) + (low_end ? 0u : units);
+                    if (lo + hi <= total) off = low_end ? (uint32_t)o : total - (uint32_t)hi;
                 }
             }
             off = rflu(off);
@@ -1356,15 +1460,16 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 ctx_slot = (int)off;
                 uint8_t *cb = P.ctx_scratch + (size_t)off * 256u;
                 snodes_g = reinterpret_cast<uint2 *>(cb);
-                leaves = reinterpret_cast<uint16_t *>(cb + (size_t)sn_cap * 512u);
-                ctx_leaves_units = sn_cap * 2u;
+                leaves = reinterpret_cast<uint16_t *>(cb + (size_t)sn_units * 256u);
+                ctx_leaves_units = sn_units;
                 max_super_here = (int)sn_cap;
             } else {
                 // no area left: the context stays in this wavefront's scratch area and the tile is pinned to the wavefront
                 STATS(st_noctx++;)
                 pinned_tix = tix;
+                narrow = narrow && (int)sn_cap <= max_super_here;   // (the wavefront's scratch area holds P.max_super supernodes)
             }
-        }
+        } else narrow = narrow_ok && tree_size <= kNarrowMaxNodes && (7 * ((tree_size - 1) / 2) + 5) / 12 + 1 <= max_super_here;
         // Subtree sizes (nodes, saturating): children always have larger indices than their parent in the parse-order
         // array, so one backward sweep does it.  The learner splits contexts that see many samples, so a child
         // supernode with a big subtree is (statistically) a frequently walked one: numbering them big-first puts the
@@ -1429,37 +1534,62 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 uint2 out;
                 out.x = (uint32_t)(is_raw_slog_prop(st_prop[lane] - nrefprops) && st_split[lane] != 0x7FFFFFFF ? slog_threshold(st_split[lane]) : st_split[lane]);
                 out.y = (((uint32_t)st_prop[lane] << 2) & 0xFFu) | (tgt << 8);   // the property as a ds_bpermute byte address (lane * 4): no shift or mask per walk round
-                snodes_g[(size_t)sn * 64 + lane] = out;
-                if (sn >= 1 && sn <= kLdsSuper) sh.snodes[(sn - 1) * 64 + lane] = out;   // the root (0) lives in registers: LDS holds 1..kLdsSuper
+                if (narrow) {
+                    // (every inner exit is admitted: the area holds (7n+5)/12 + 1 supernodes, which is what made the group narrow)
+                    const uint32_t w = pack_narrow((int)out.x, (uint32_t)st_prop[lane], inner ? (tgt & 0x1FFFu) : (kLeafFlagN | (uint32_t)n.child));
+                    reinterpret_cast<uint32_t *>(snodes_g)[(size_t)sn * 64 + lane] = w;
+                    if (sn >= 1 && sn <= kLdsN) lds_narrow[(sn - 1) * 64 + lane] = w;   // (dense configuration: behind the 1020 bytes of cprops this build borrows)
+                } else {
+                    snodes_g[(size_t)sn * 64 + lane] = out;
+                    if (sn >= 1 && sn <= kLdsSuper) sh.snodes[(sn - 1) * 64 + lane] = out;   // the root (0) lives in registers: LDS holds 1..kLdsSuper
+                }
                 __syncthreads();
             }
         }
+        // A context that lives in this wavefront's scratch area (streams without group index, pinned tiles): the leaf chances start right behind the
+        // supernodes the tree really has, not at the area's fixed leaf offset 2 MB further on -- the two halves of the per-symbol chain then share a page
+        // (thousands of wavefronts x two pages each was more than the address translation caches hold; profiles/r6_ubench_context_layouts.txt, "scratch")
+        if (ctx_slot < 0) leaves = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(snodes_w) + (size_t)n_super * (narrow ? 256u : 512u));
         // FinalPropertySymbolCoder ctor: every leaf starts from SymbolChance(zero_chance) (compound.h:213-219)
         {
-            if (lane == 0) { symbol_chance_init(leaves, predictability); leaves[31] = 0; }
+            if (lane == 0) {
+                if (compact) {   // zero, sign, exponent 0..6, mantissa 0..6 (symbol_chance_init's values for these slots)
+                    uint16_t full[32];
+                    symbol_chance_init(full, predictability);
+                    for (int k = 0; k < kMantCompact; k++) leaves[k] = full[k];
+                    for (int k = 0; k < 16 - kMantCompact; k++) leaves[kMantCompact + k] = full[CH_MANT + k];
+                } else { symbol_chance_init(leaves, predictability); leaves[31] = 0; }
+            }
             __syncthreads();
             const uint32_t *l0 = reinterpret_cast<const uint32_t *>(leaves);
             uint32_t *lw = reinterpret_cast<uint32_t *>(leaves);
-            const uint32_t mine = l0[lane & 15];
-            for (int64_t i = 16 + lane; i < (int64_t)nleaves * 16; i += 64) lw[i] = mine;  // (i & 15) == (lane & 15)
+            const int words = compact ? 8 : 16;   // per leaf
+            const uint32_t mine = l0[lane & (words - 1)];
+            for (int64_t i = words + lane; i < (int64_t)nleaves * words; i += 64) lw[i] = mine;  // (i & (words - 1)) == (lane & (words - 1))
             __syncthreads();
         }
         }  // !resumed
-        const uint2 root_nd = snodes_g[lane];  // the root supernode lives in registers
+#ifdef FUIF_EMU_DEBUG
+        if (lane == 0 || lane == 20) fprintf(stderr, "group c%d: lane %d tree %d n_super %d narrow %d nprops %d ctx %d resumed %d\n", ci, lane, tree_size, n_super, (int)narrow, nprops, ctx_slot, (int)resumed);
+#endif
+        const uint2 root_nd = narrow ? uint2{0u, 0u} : snodes_g[lane];  // the root supernode lives in registers
+        const uint32_t root_w = narrow ? reinterpret_cast<const uint32_t *>(snodes_g)[lane] : 0u;
         LeafRegs L;
-        L.leafv = (int)leaves[(int64_t)cur_leaf * kLeafStride + (lane & 31)];   // lanes 32..63 mirror lanes 0..31 (switch_leaf)
+        const uint32_t leaf_shift = compact ? 5u : 6u, leaf_l2 = (uint32_t)(lane & (compact ? 15 : 31)) * 2u;   // a leaf's bytes; this lane's chance inside it
+        L.leafv = (int)*reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(leaves) + (((uint32_t)cur_leaf << leaf_shift) + leaf_l2));   // lanes 32..63 mirror lanes 0..31 (switch_leaf)
         L.touched = 0; L.bits = 0;
+        L.mb = rfl(compact ? kMantCompact : CH_MANT); L.mirror = rflu(compact ? 0x10001u : 1u);
         auto switch_leaf = [&](int id) {
             // Lanes 32..63 mirror lanes 0..31 (same addresses, same values): the write-back and the fetch need no lane mask, and the
             // compiler tracks both (32-bit offsets from the leaves' base: a tree has at most 32768 leaves of 64 bytes)
             if (LIKELY(id != cur_leaf)) {
                 char *lb = reinterpret_cast<char *>(leaves);
-                const uint32_t l2 = (uint32_t)(lane & 31) * 2u;
+                const uint32_t l2 = leaf_l2;
                 // the fetch is issued FIRST: it does not depend on the chances in leafv, the write-back does (the commit's table lookup may
                 // still be landing in them) -- where the walk is short (wide configuration: every round from LDS) that wait would
                 // otherwise sit in front of the leaf's memory round trip
-                const int fresh = (int)*reinterpret_cast<const uint16_t *>(lb + ((uint32_t)id * 64u + l2));
-                *reinterpret_cast<uint16_t *>(lb + ((uint32_t)cur_leaf * 64u + l2)) = (uint16_t)L.leafv;
+                const int fresh = (int)*reinterpret_cast<const uint16_t *>(lb + (((uint32_t)id << leaf_shift) + l2));
+                *reinterpret_cast<uint16_t *>(lb + (((uint32_t)cur_leaf << leaf_shift) + l2)) = (uint16_t)L.leafv;
                 L.leafv = fresh;
                 cur_leaf = id;
             }
@@ -1497,8 +1627,12 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 fsym.emax_pos = ilog2u((uint32_t)fsym.amax_pos); fsym.emax_neg = ilog2u((uint32_t)fsym.amax_neg);
                 fsym.ilast_pos = rfl(fsym.emax_pos + 1); fsym.ilast_neg = rfl(fsym.emax_neg + 1);
                 const bool sym_fast = minv < zero && zero < maxv;   // both signs possible: symbol.h:160-165 codes zero and sign
-                auto rows = [&](auto pred0_tag) {
+                auto rows = [&](auto pred0_tag, auto narrow_tag) {
                     constexpr bool PRED0 = decltype(pred0_tag)::value;
+                    constexpr bool NARROW = decltype(narrow_tag)::value;   // 4-byte supernode lane words (kLeafFlagN)
+                    // dense configuration, narrow group: the property rows are int16 (every property of such a group lies inside 13 bits, the partial sums the
+                    // vector phase parks inside 15), which leaves the other half of cprops to the LDS-resident supernodes (Shared::kNarrowBase)
+                    using prop_t = typename PropRow<decltype(narrow_tag)::value, kLdsSuper>::type;
                     for (; y < h; y++) {
                         if (s_limit_hit(s)) break;
                         __syncthreads();  // the previous row's stores are complete before it is re-read as `top`
@@ -1548,7 +1682,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                         //   k:  1 |left|   3 slog(left)   6 left+top-topleft   7 topleft+topright-top
                         //       8 slog(left-topleft)   9 slog(topleft-top)   12 slog(left-leftleft)
                         // In row 0 topleft IS left (context_predict.h:128), which moves the left term from 6,8 to 7,9.
-                        const int kloc = lane - nrefprops;
+                        const int kloc = (lane & prop_mask) - nrefprops;   // (up to 32 properties: lanes 32..63 mirror lanes 0..31, which narrow supernodes rely on)
                         // (3, 8, 9, 12 stay raw differences: the supernodes hold slog_threshold(split) for them)
                         const bool f_abs = (kloc == 1);
                         // per-lane masks: d = bias + (left & m_left) - (leftleft & m_ll) -- two ANDs and one add3 instead of two 24-bit multiplies
@@ -1564,35 +1698,52 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                             const int vtr = (x + 1 < w && y) ? row1[x + 1] : vtop;         // context_predict.h:129
                             const int vtt = y > 1 ? row2[x] : vtop;                        // :133
                             if (lane < chunk_px) {
-                                int32_t *cp = sh.cprops + lane * prop_pitch;
+                                prop_t *cp = reinterpret_cast<prop_t *>(sh.cprops) + lane * prop_pitch;
                                 // (more than kFastRefs references, -E > 18: the rest one by one -- rare, and its chunks are half as long)
                                 for (int k = kFastRefs; k < nrefs; k++) {
                                     const RefChan rc = sh.refs[k];
                                     int ry = (y << gvs) >> rc.vshift; if (ry >= rc.h) ry = rc.h - 1;
                                     int rx = ghs < 0 ? rc.w - 1 : (x << ghs) >> rc.hshift; if (rx >= rc.w) rx = rc.w - 1;
                                     const int v = ld_plane<kHandOff>(coef + rc.off + (int64_t)ry * rc.w + rx);
-                                    cp[2 * k] = iabs(v); cp[2 * k + 1] = slog(v);
+                                    cp[2 * k] = (prop_t)iabs(v); cp[2 * k + 1] = (prop_t)slog(v);
                                 }
-#pragma unroll
-                                for (int k = 0; k < kFastRefs; k++) {
-                                    if (k < nrefs) {
-                                        // rx = min((x<<hshift)>>ref.hshift, ref.w-1) covers the three cases of context_predict.h:241-284
-                                        const RefChan rc = sh.refs[k];
-                                        int ry = (y << gvs) >> rc.vshift; if (ry >= rc.h) ry = rc.h - 1;
-                                        // a meta-channel (hshift -1) coded AFTER ordinary channels (Approximate on a palette, approximate.h:76)
-                                        // takes the `ch.hshift < rc.hshift` branch with stepsize (1<<rc.hshift) >> -1, which the reference's
-                                        // x86 build evaluates as 0: every x then reads the LAST sample of the reference row (:253-262)
-                                        int rx = ghs < 0 ? rc.w - 1 : (x << ghs) >> rc.hshift; if (rx >= rc.w) rx = rc.w - 1;
-                                        const int v = ld_plane<kHandOff>(coef + rc.off + (int64_t)ry * rc.w + rx);
-                                        cp[2 * k] = iabs(v); cp[2 * k + 1] = slog(v);
+                                // The reference samples of this pixel: every load is a memory round trip (another tile's plane, read past the L1), so the
+                                // loads of up to 6 references -- what the default options give -- are ISSUED TOGETHER and consumed afterwards.  (Rounds 1-5
+                                // had one `if (k < nrefs)` block per reference: a uniform branch between two loads, which hipcc does not hoist a load
+                                // across -- six round trips one after the other, 7200 cycles per 32-pixel chunk on the long 4K groups,
+                                // profiles/r6_phases_by_channel_narrow.txt.)  A slot beyond nrefs reads reference 0 again and is dropped.
+                                auto ref_sample = [&](int k) -> int {
+                                    // rx = min((x<<hshift)>>ref.hshift, ref.w-1) covers the three cases of context_predict.h:241-284
+                                    const RefChan rc = sh.refs[k < nrefs ? k : 0];
+                                    int ry = (y << gvs) >> rc.vshift; if (ry >= rc.h) ry = rc.h - 1;
+                                    // a meta-channel (hshift -1) coded AFTER ordinary channels (Approximate on a palette, approximate.h:76)
+                                    // takes the `ch.hshift < rc.hshift` branch with stepsize (1<<rc.hshift) >> -1, which the reference's
+                                    // x86 build evaluates as 0: every x then reads the LAST sample of the reference row (:253-262)
+                                    int rx = ghs < 0 ? rc.w - 1 : (x << ghs) >> rc.hshift; if (rx >= rc.w) rx = rc.w - 1;
+                                    return ld_plane<kHandOff>(coef + rc.off + (int64_t)ry * rc.w + rx);
+                                };
+                                static_assert(kFastRefs == 9, "the reference loads are issued in batches of 6 + 3");
+                                if (nrefs > 0) {
+                                    const int r0 = ref_sample(0), r1 = ref_sample(1), r2 = ref_sample(2), r3 = ref_sample(3), r4 = ref_sample(4), r5 = ref_sample(5);
+                                    cp[0] = (prop_t)iabs(r0); cp[1] = (prop_t)slog(r0);
+                                    if (nrefs > 1) { cp[2] = (prop_t)iabs(r1); cp[3] = (prop_t)slog(r1); }
+                                    if (nrefs > 2) { cp[4] = (prop_t)iabs(r2); cp[5] = (prop_t)slog(r2); }
+                                    if (nrefs > 3) { cp[6] = (prop_t)iabs(r3); cp[7] = (prop_t)slog(r3); }
+                                    if (nrefs > 4) { cp[8] = (prop_t)iabs(r4); cp[9] = (prop_t)slog(r4); }
+                                    if (nrefs > 5) { cp[10] = (prop_t)iabs(r5); cp[11] = (prop_t)slog(r5); }
+                                    if (nrefs > 6) {
+                                        const int r6 = ref_sample(6), r7 = ref_sample(7), r8 = ref_sample(8);
+                                        cp[12] = (prop_t)iabs(r6); cp[13] = (prop_t)slog(r6);
+                                        if (nrefs > 7) { cp[14] = (prop_t)iabs(r7); cp[15] = (prop_t)slog(r7); }
+                                        if (nrefs > 8) { cp[16] = (prop_t)iabs(r8); cp[17] = (prop_t)slog(r8); }
                                     }
                                 }
-                                int32_t *q = cp + nrefprops;
-                                q[0] = iabs(vtop); q[2] = slog(vtop); q[4] = y; q[5] = x0 + lane;
-                                q[10] = slog(vtop - vtr); q[11] = slog(vtop - vtt);
+                                prop_t *q = cp + nrefprops;
+                                q[0] = (prop_t)iabs(vtop); q[2] = (prop_t)slog(vtop); q[4] = (prop_t)y; q[5] = (prop_t)(x0 + lane);
+                                q[10] = (prop_t)slog(vtop - vtr); q[11] = (prop_t)slog(vtop - vtt);
                                 q[1] = 0; q[3] = 0; q[12] = 0;
-                                if (y) { q[6] = vtop - vtl; q[7] = vtl + vtr - vtop; q[8] = -vtl; q[9] = vtl - vtop; }
-                                else { q[6] = zero; q[7] = 0; q[8] = 0; q[9] = -zero; }
+                                if (y) { q[6] = (prop_t)(vtop - vtl); q[7] = (prop_t)(vtl + vtr - vtop); q[8] = (prop_t)-vtl; q[9] = (prop_t)(vtl - vtop); }
+                                else { q[6] = (prop_t)zero; q[7] = 0; q[8] = 0; q[9] = (prop_t)-zero; }
                             }
                             __syncthreads();
                             PROF_LAP(0);
@@ -1605,12 +1756,12 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                             // leftleft = value at x-2, except at x == 1 where the rule is leftleft = left (context_predict.h:131): the first
                             // pixel of a row is a loop part of its own, so that the rule costs nothing per pixel
                             const int j_split = x0 == 0 ? 1 : 0;
-                            const int32_t *prow = &sh.cprops[lane & prop_mask];
+                            const prop_t *prow = reinterpret_cast<const prop_t *>(sh.cprops) + (lane & prop_mask);
                             for (int part = 0; part < 2; part++) {
                             const int j_end = part ? nx : j_split;
                             for (int j = part ? j_split : 0; j < j_end; j++) {
                                 PROF_START();
-                                int pv = *prow; prow += prop_pitch;   // sh.cprops[j * prop_pitch + (lane & prop_mask)]
+                                int pv = (int)*prow; prow += prop_pitch;   // cprops[j * prop_pitch + (lane & prop_mask)]
                                 const int l = left;
                                 {
                                     const int d = pv + (l & m_left) + (-leftleft & m_ll);
@@ -1650,7 +1801,41 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                         const int e = __builtin_ctzll(__ballot(hit));
                                         return (uint32_t)rdlane((int)nd.y, e) >> 8;
                                     };
-                                    uint32_t tgt = walk_round(root_nd);
+                                    uint32_t tgt;
+                                    if (NARROW) {
+                                        // the same round on 4-byte lane words: the word is the ds_bpermute address, the split a 13-bit field, the exit 14 bits
+                                        // that a rotation makes contiguous
+                                        auto walk_round_n = [&](const uint32_t w) -> uint32_t {
+                                            const int val = __builtin_amdgcn_ds_bpermute((int)w, pv);   // source lane = bits 7..2 = property | split bit 0 << 5: lanes 32..63 of pv mirror 0..31
+                                            const int split = ((int)(w << 12)) >> 19;                  // bits 19..7, sign extended (v_bfe_i32)
+                                            const unsigned long long m = __ballot(val > split);
+                                            const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
+                                            const bool hit = ((((mlo ^ exp_lo) & msk_lo) | ((mhi ^ exp_hi) & msk_hi)) == 0u);
+                                            const int e = __builtin_ctzll(__ballot(hit));
+                                            const uint32_t rot = (w >> 20) | (w << 12);               // exit: bits 13..0 (v_alignbit_b32)
+                                            return (uint32_t)rdlane((int)rot, e) & 0x3FFFu;
+                                        };
+                                        tgt = walk_round_n(root_w);
+                                        EMU_COUNT(0);
+                                        while (!(tgt & kLeafFlagN)) {
+                                            EMU_COUNT(tgt <= (uint32_t)kLdsN ? 1 : 2);
+#ifdef FUIF_EMU_DEBUG
+                                            if ((int)tgt >= n_super || tgt == 0) { fprintf(stderr, "narrow walk: tgt %u n_super %d tree %d lane %d\n", tgt, n_super, tree_size, lane); abort(); }
+#endif
+                                            uint32_t w;
+                                            if (kLdsN > 0) {
+                                                const uint32_t li = tgt <= (uint32_t)kLdsN ? tgt : (uint32_t)kLdsN;
+                                                w = lds_load_node_n(lds_narrow_addr + (li - 1u) * 256u + (uint32_t)lane * 4u);
+                                                if (tgt > (uint32_t)kLdsN) w = global_load_supernode_n(reinterpret_cast<const uint32_t *>(snodes_g), tgt, (uint32_t)lane * 4u);
+                                            } else w = global_load_supernode_n(reinterpret_cast<const uint32_t *>(snodes_g), tgt, (uint32_t)lane * 4u);
+                                            tgt = walk_round_n(w);
+                                        }
+                                        tgt &= kLeafFlagN - 1u;
+#ifdef FUIF_EMU_DEBUG
+                                        if ((int)tgt >= (tree_size + 1) / 2) { fprintf(stderr, "narrow walk: leaf %u of %d\n", tgt, (tree_size + 1) / 2); abort(); }
+#endif
+                                    } else {
+                                    tgt = walk_round(root_nd);
                                     EMU_COUNT(0);
                                     while (!(tgt & (kLeafFlag | kSlowFlag))) {
                                         EMU_COUNT(tgt <= (uint32_t)kLdsSuper ? 1 : 2);
@@ -1680,11 +1865,12 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                         }
                                         tgt = kLeafFlag | (uint32_t)rfl((int)n.child);
                                     }
+                                    }
                                     const int leaf = (int)(tgt & (kLeafFlag - 1u));
                                     PROF_LAP(2);
                                     switch_leaf(leaf);
 #ifdef FUIF_PROF
-                                    prof_acc[7] += (unsigned)rdlane(L.leafv, 0) & 0u;  // force the leaf load to complete inside this lap
+                                    asm volatile("; the leaf's chances are here" :: "v"(L.leafv));  // force the leaf load to complete inside this lap (an input operand: hipcc waits for it)
 #endif
                                     PROF_LAP(3);
                                     if (kChunkFast || (PRED0 && sym_fast && LIKELY(s.pos + 64u <= s.size))) {
@@ -1722,7 +1908,8 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                         publish(i, (uint32_t)y + 2u);
                     }
                 };
-                if (predictor == 0) rows(std::true_type{}); else rows(std::false_type{});
+                if (predictor == 0) { if (narrow) rows(std::true_type{}, std::true_type{}); else rows(std::true_type{}, std::false_type{}); }
+                else { if (narrow) rows(std::false_type{}, std::true_type{}); else rows(std::false_type{}, std::false_type{}); }
             }
             if (yielded) break;
             // rows the stream never reached keep what Channel::resize() (encoding.cpp:368) left there: `zero` in a plane
@@ -1734,11 +1921,11 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         }
         if (yielded) {
             // suspend: current leaf back to its slot, coder state into the tile's record, then release the record
-            if (lane < 32) leaves[(int64_t)cur_leaf * kLeafStride + lane] = (uint16_t)L.leafv;
+            if (lane < (compact ? 16 : 32)) leaves[((int64_t)cur_leaf << (leaf_shift - 1u)) + lane] = (uint16_t)L.leafv;
             if (lane == 0) {
                 rec->wait_chan = yield_chan; rec->wait_val = yield_val; rec->y = resume_y;
                 rec->range = rac.range; rec->low = rac.low; rec->pos = s.pos;
-                rec->flags = ((uint32_t)status & 0xFFu) | ((uint32_t)(s.eof_flag & 1) << 8) | ((uint32_t)predictor << 9) | (long_tile ? kRecLong : 0u);
+                rec->flags = ((uint32_t)status & 0xFFu) | ((uint32_t)(s.eof_flag & 1) << 8) | ((uint32_t)predictor << 9) | (long_tile ? kRecLong : 0u) | (narrow ? kRecNarrow : 0u) | (compact ? kRecCompact : 0u);
                 if (long_tile) atomicAdd(&P.simd_long[simd_slot], 0xFFFFFFFFu);
                 rec->ctx = (uint32_t)ctx_slot; rec->ctx_leaves = ctx_leaves_units; rec->tree_size = (uint32_t)tree_size; rec->n_super = (uint32_t)n_super; rec->cur_leaf = (uint32_t)cur_leaf;
                 rec->pin = ctx_slot >= 0 ? 0u : my_pin;

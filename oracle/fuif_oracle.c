@@ -948,11 +948,15 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
     meta.rac = &rac; meta.table = g_table_tree; meta.nprops = nprops; meta.maxdepth = 0;
     for (int k = 0; k < 3; k++) fo_symbol_chance_init(meta.ctx[k], 1024); /* ZERO_CHANCE symbol.h:67 */
     for (int k = 0; k < nprops; k++) { meta.lo[k] = pr[k].lo; meta.hi[k] = pr[k].hi; }
+    /* FO_DUMP_TREES=path (analysis tooling, tools/supernode_packing.py): every group's context tree with the number of walks through each node */
+    const char *dump_path = getenv("FO_DUMP_TREES");
+    uint32_t *visits = NULL;
     if (!read_subtree(&meta, &tree, 0, 0)) {
         free(tree.n);
         img->stat_rac_decisions += rac.decisions;
         return corrupt_or_truncated(io, &img->ch[beginc], btl);
     }
+    if (dump_path) visits = (uint32_t *)calloc((size_t)tree.size, sizeof(uint32_t));
 
     if (tree.size > img->stat_max_tree_nodes) img->stat_max_tree_nodes = tree.size;
     /* FinalPropertySymbolCoder ctor: compound.h:213-225 */
@@ -1098,6 +1102,7 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
                             if (g_stats > 0 && depth && depth % 6 == 0) g_st.rounds_behind++;
                             if (g_stats > 0 && depth == 12) { g_st.r3_rounds++; if (pos == st_t3[0][0]) g_st.r3_hit[0]++; if (pos == st_t3[1][0] || pos == st_t3[1][1]) g_st.r3_hit[1]++; }
                             img->stat_tree_steps++;
+                            if (visits) visits[pos]++;
                             if (g_stats > 0 && pre < 0) {
                                 const int kl = tree.n[pos].property - nref;  /* local properties that read `left` */
                                 if (kl == 1 || kl == 3 || kl == 12 || (y ? (kl == 6 || kl == 8) : (kl == 7 || kl == 9))) pre = depth;
@@ -1133,6 +1138,7 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
                         if (g_leafsim) { leafsim_access(ls_ids[tree.n[pos].childID], &ls_prev); g_depth_hist[depth > 31 ? 31 : depth]++;
                                          const int lid = tree.n[pos].childID, sl = lf_slot[lid];
                                          g_slot_acc[0]++; if (lf_root[lid]) g_slot_acc[1]++; else { if (sl < 4) g_slot_acc[2]++; if (sl < 8) g_slot_acc[3]++; if (sl < 16) g_slot_acc[4]++; } }
+                        if (visits) visits[pos]++;
                         diff = read_symbol(&rac, leaves + (size_t)tree.n[pos].childID * CH_N, g_table_pixel, mn, mx);
                     }
                     c->data[(size_t)y * c->w + x] = px(diff + guess);
@@ -1176,6 +1182,16 @@ static int decode_channel_group(fo_io *io, fo_image *img, int *beginc_io, size_t
     }
     img->stat_rac_decisions += rac.decisions;
     free(ls_ids); free(sn_rank); free(lf_slot); free(lf_root);
+    if (visits) {
+        FILE *df = fopen(dump_path, "ab");
+        if (df) {
+            const int32_t hdr[4] = {beginc, tree.size, nref, nprops};
+            fwrite(hdr, 4, 4, df);
+            for (int k = 0; k < tree.size; k++) { const int32_t rec[4] = {tree.n[k].property, tree.n[k].childID, tree.n[k].splitval, (int32_t)visits[k]}; fwrite(rec, 4, 4, df); }
+            fclose(df);
+        }
+        free(visits);
+    }
     free(leaves);
     free(tree.n);
     *beginc_io = endc;

@@ -140,16 +140,17 @@ def test_c4_shape_at_4096_matches_oracle(gpulib, port):
 
 
 def test_c4_full_size_image_matches_oracle(gpulib, port):
-    """BASELINE config C4 at its real geometry: ONE 8192x8192, 4-channel, 14-bit, Squeeze-only lossless stream (268 M
-    symbols, 2.1 GB of planes) through the C-ABI with the group index, every coded plane and every output plane against the
-    CPU oracle.  Takes minutes (one 8192x8192 launch lasts a minute -- its longest group is 33.5 M symbols on one range coder --
-    the writer and two oracle decodes another two) and ~12 GB of host memory, so it only runs when FUIF_TEST_C4_FULL=1.  The
-    routine suite has the same shape at 4096x4096 against the oracle (above); at the real size the streamed bench compares ALL 256
-    pictures with the generator's pixels and has the real reference decode stream 0 to the same pixels (bench.py --workload c4,
-    profiles/r4_c4_full_size.txt)."""
+    """BASELINE config C4 at its real geometry, in the routine -m gpu set since round 6: ONE 8192x8192, 4-channel, 14-bit, Squeeze-only
+    lossless stream (268 M symbols, 2.1 GB of planes; its longest group is 33.5 M symbols on one range coder) through the C-ABI with
+    the group index.  EVERY coded plane against ONE CPU-oracle decode of the same bytes, every output plane against the source
+    pixels (the stream is lossless; the oracle's own inverse chain at this shape is pinned by the 4096x4096 test above): one writer
+    pass, one launch of about a minute, ONE oracle decode -- three to four minutes.  FUIF_TEST_C4_FULL=0 skips it on a box that is
+    short of host memory (~8 GB)."""
     import os
-    if not os.environ.get("FUIF_TEST_C4_FULL"):
-        pytest.skip("set FUIF_TEST_C4_FULL=1 (minutes of CPU for the writer and the oracle)")
+    if os.environ.get("FUIF_TEST_C4_FULL") == "0":
+        pytest.skip("FUIF_TEST_C4_FULL=0")
+    if "_emu" in os.path.basename(os.environ.get("FUIF_AMD_LIB", "")):
+        pytest.skip("hours on the wavefront emulator")
     w = h = 8192
     img = photographic(w, h, 4, 14, seed=8192)
     blob = gpulib.encode_image(img, 14, ycocg=False, tree_mode=1, index=True)
@@ -167,13 +168,13 @@ def test_c4_full_size_image_matches_oracle(gpulib, port):
         post = batch.out_planes(0)
     finally:
         batch.close()
-    d_pre, d_post = port.decode_both(blob)
-    for g, e in zip(pre, d_pre.channels):
-        assert np.array_equal(g, e["data"])
-    for g, e in zip(post, d_post.channels):
-        assert np.array_equal(g, e["data"])
     for k in range(4):
         assert np.array_equal(post[k], img[k])
+    del post, img
+    d_pre = port.decode(blob, undo=False)
+    assert len(pre) == len(d_pre.channels)
+    for g, e in zip(pre, d_pre.channels):
+        assert np.array_equal(g, e["data"])
 
 
 def test_sibling_batch_pipelines_uploads(gpulib):

@@ -51,7 +51,7 @@ def classify(ins, ops):
 
 
 def main():
-    flags = sys.argv[1:]
+    flags = [a for a in sys.argv[1:] if a != "--all"]
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", *flags,
@@ -104,32 +104,35 @@ def main():
                 lanes[o[0]].add(o[-1])
     SPILL_VGPRS.update(v for v, ls in lanes.items() if len(ls) >= 4)
     # the pixel loop: the loop that holds the hand-written symbol decoder
-    host = next(k for k, b in blocks.items() if any(re.match(r"v_mov_b32 v\d+, 0x800", a) for a in b["asm"]))
-    loop = blocks[host]["header"] if not blocks[host]["is_header"] else host
+    hosts = [k for k, b in blocks.items() if any(re.match(r"v_mov_b32 v\d+, 0x800", a) for a in b["asm"])]
+    if "--all" not in sys.argv:
+        hosts = hosts[:1]   # (--all: every instantiation of the pixel loop that holds the decoder -- wide / narrow supernodes x chunk with / without the end-of-stream test)
     parents_of = {k: b["parents"] for k, b in blocks.items() if b["is_header"]}
-
-    def inside(k):
-        b = blocks[k]
-        if k == loop or b["header"] == loop:
-            return "body"
-        h = k if b["is_header"] else b["header"]
-        if h and loop in parents_of.get(h, []):
-            return "inner loop " + h
-        return None
-
     cols = ["salu", "valu", "cross", "lds", "vmem", "smem", "branch", "wait", "sgpr_spill", "vgpr_spill"]
-    print("pixel loop = %s (holds fast_symbol_hw in %s), flags %s; SGPR spill slots live in %s" % (loop, host, " ".join(flags) or "(release)", " ".join(sorted(SPILL_VGPRS))))
-    print("%-12s %-22s %5s " % ("block", "where", "instr") + " ".join("%10s" % c for c in cols) + "   inline asm")
-    tot = collections.Counter(); n_blocks = 0
-    for k, b in blocks.items():
-        w = inside(k)
-        if not w:
-            continue
-        n_blocks += 1
-        c = collections.Counter(classify(i, o) for i, o in b["ins"])
-        tot.update(c)
-        print("%-12s %-22s %5d " % (k, w, len(b["ins"])) + " ".join("%10d" % c[x] for x in cols) + ("   " + "; ".join(a[:40] for a in b["asm"]) if b["asm"] else ""))
-    print("%-12s %-22s %5d " % ("total", "%d blocks" % n_blocks, sum(tot.values())) + " ".join("%10d" % tot[x] for x in cols))
+    for host in hosts:
+        loop = blocks[host]["header"] if not blocks[host]["is_header"] else host
+
+        def inside(k):
+            b = blocks[k]
+            if k == loop or b["header"] == loop:
+                return "body"
+            h = k if b["is_header"] else b["header"]
+            if h and loop in parents_of.get(h, []):
+                return "inner loop " + h
+            return None
+
+        print("pixel loop = %s (holds fast_symbol_hw in %s), flags %s; SGPR spill slots live in %s" % (loop, host, " ".join(flags) or "(release)", " ".join(sorted(SPILL_VGPRS))))
+        print("%-12s %-22s %5s " % ("block", "where", "instr") + " ".join("%10s" % c for c in cols) + "   inline asm")
+        tot = collections.Counter(); n_blocks = 0
+        for k, b in blocks.items():
+            w = inside(k)
+            if not w:
+                continue
+            n_blocks += 1
+            c = collections.Counter(classify(i, o) for i, o in b["ins"])
+            tot.update(c)
+            print("%-12s %-22s %5d " % (k, w, len(b["ins"])) + " ".join("%10d" % c[x] for x in cols) + ("   " + "; ".join(a[:40] for a in b["asm"]) if b["asm"] else ""))
+        print("%-12s %-22s %5d " % ("total", "%d blocks" % n_blocks, sum(tot.values())) + " ".join("%10d" % tot[x] for x in cols))
     whole = collections.Counter(classify(i, o) for b in blocks.values() for i, o in b["ins"])
     print("%-12s %-22s %5d " % ("kernel", "%d blocks" % len(blocks), sum(whole.values())) + " ".join("%10d" % whole[x] for x in cols))
 

@@ -36,7 +36,12 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_test(const Case *cases, R
             s.p = reinterpret_cast<const uint8_t *>(k.window); s.size = 256; s.pos = rflu(k.pos); s.limit = 0; s.win_base = 0;
             s.win = k.window[lane]; s.eof_flag = 0; s.blob_mode = 1;
             Rac r; r.range = rflu(k.range); r.low = rflu(k.low);
-            LeafRegs L; L.leafv = lane < 31 ? (int)k.chances[lane] : 0; L.touched = 0; L.bits = 0;
+            // every second case with amax <= 255 runs on COMPACT leaves (16 chances, mantissa from slot 9, lanes 16..63 mirror 0..15); the others on the
+            // 31-chance form (lanes 32..63 mirror 0..31)
+            const bool compact = (c & 1) && k.amax_pos <= 255u && k.amax_neg <= 255u;
+            const int slot = lane & (compact ? 15 : 31);
+            LeafRegs L; L.leafv = slot < 31 ? (int)k.chances[slot] : 0; L.touched = 0; L.bits = 0;
+            L.mb = rfl(compact ? kMantCompact : CH_MANT); L.mirror = rflu(compact ? 0x10001u : 1u);
             const int res = v ? fast_symbol_hw(r, s, L, F) : fast_symbol(r, s, L, F);
             out.res[v] = res; out.range[v] = r.range; out.low[v] = r.low; out.pos[v] = s.pos; out.touched[v] = L.touched; out.bits[v] = L.bits;
             if (v) {
@@ -44,7 +49,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_test(const Case *cases, R
                 const int before = L.leafv;
                 const uint32_t t = L.touched, b = L.bits;
                 int want = before;
-                if ((t >> lane) & 1u) want = table[before * 2 + ((b >> lane) & 1u)];
+                if ((t >> slot) & 1u) want = table[before * 2 + ((b >> slot) & 1u)];
                 leaf_commit(L, lane, table);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 out.commit_bad = (uint32_t)__popcll(__ballot(L.leafv != want));
@@ -77,8 +82,8 @@ int main(int argc, char **argv) {
         k.low = rnd() % k.range;
         if (mode == 2) k.low = k.range - 1 - rnd() % 16;
         k.pos = rnd() % 190;
-        k.amax_pos = 1 + rnd() % (mode == 3 ? 3 : mode == 4 ? 32767 : 600);
-        k.amax_neg = 1 + rnd() % (mode == 3 ? 2 : mode == 4 ? 32767 : 600);
+        k.amax_pos = 1 + rnd() % (mode == 3 ? 3 : mode == 4 ? 32767 : (c & 2) ? 255 : 600);
+        k.amax_neg = 1 + rnd() % (mode == 3 ? 2 : mode == 4 ? 32767 : (c & 2) ? 255 : 600);
         for (int i = 0; i < 32; i++) {
             k.chances[i] = 1 + rnd() % 4095;
             if (mode == 5) k.chances[i] = 1 + rnd() % 40;              // tiny chances: double renormalisations

@@ -10,11 +10,11 @@
 #include <vector>
 
 template <int kNodeBytes, int kLeafBytes>
-__global__ __launch_bounds__(64) void chase(unsigned char *base, size_t region_bytes, size_t queue_bytes, int per_queue, unsigned n_super, unsigned n_leaves, int iters, int alu, unsigned long long *out) {
+__global__ __launch_bounds__(64) void chase(unsigned char *base, size_t region_bytes, size_t queue_bytes, int per_queue, size_t leaf_gap, unsigned n_super, unsigned n_leaves, int iters, int alu, unsigned long long *out) {
     const int lane = threadIdx.x;
     // layout: `per_queue` consecutive regions inside a queue's arena of `queue_bytes` (the context arenas of capi.hip: 64 MiB per CU queue)
     unsigned char *region = base + (size_t)(blockIdx.x / per_queue) * queue_bytes + (size_t)(blockIdx.x % per_queue) * region_bytes;
-    unsigned char *leaves = region + (size_t)n_super * 64 * kNodeBytes;
+    unsigned char *leaves = region + (leaf_gap ? leaf_gap : (size_t)n_super * 64 * kNodeBytes);   // leaf_gap: the leaves' fixed offset inside a wavefront's scratch area (rounds 1-5: 2 MB behind the supernodes)
     unsigned state = blockIdx.x * 2654435761u + 12345u;
     unsigned cur_leaf = 0;
     unsigned leafv = lane;
@@ -59,20 +59,23 @@ int main(int argc, char **argv) {
     struct Cfg { int node, leaf; unsigned ns, nl; };
     // a long 4K tile: ~120 supernodes, ~900 leaves
     const Cfg cfgs[] = {{8, 64, 120, 900}, {4, 64, 120, 900}, {8, 32, 120, 900}, {4, 32, 120, 900}, {4, 32, 60, 900}, {4, 32, 120, 450}, {8, 64, 30, 225}, {8, 64, 8, 64}};
-    const int waves_list[] = {512, 3072, 6144};
+    const int waves_list[] = {512, 1024, 2048, 3072, 6144};
     for (int waves : waves_list)
         for (const Cfg &c : cfgs) {
             const size_t region = ((size_t)c.ns * 64 * c.node + (size_t)c.nl * c.leaf + 255) / 256 * 256;
-            for (int layout = 0; layout < 2; layout++) {
+            for (int layout = 0; layout < 3; layout++) {
             // layout 0: the regions back to back; 1: as the context arenas place them -- 256 queues of 64 MiB, a queue's tiles 4 regions apart
-            const int per_queue = layout ? (waves + 255) / 256 : waves;
-            const size_t stride = layout ? region * 4 : region;
-            const size_t queue_bytes = layout ? (size_t)64 << 20 : 0;
-            if (layout && ((size_t)per_queue * stride > queue_bytes || (size_t)256 * queue_bytes > max_bytes)) continue;
+            // layout 2: the per-wavefront scratch areas of tiles that are not suspendable (streams without group index): 4.7 MB apart, leaves 2 MB behind the supernodes
+            const int per_queue = layout == 1 ? (waves + 255) / 256 : waves;
+            const size_t stride = layout == 1 ? region * 4 : layout == 2 ? (size_t)4700 << 10 : region;
+            const size_t queue_bytes = layout == 1 ? (size_t)64 << 20 : 0;
+            const size_t leaf_gap = layout == 2 ? (size_t)2 << 20 : 0;
+            if (layout == 1 && ((size_t)per_queue * stride > queue_bytes || (size_t)256 * queue_bytes > max_bytes)) continue;
+            if (layout == 2 && (size_t)waves * stride > max_bytes) continue;
             const int iters = 20000;
             for (int pass = 0; pass < 2; pass++) {
                 const int it = pass ? iters : 2000;
-#define LAUNCH(N, L) hipLaunchKernelGGL((chase<N, L>), dim3(waves), dim3(64), 0, 0, buf, stride, queue_bytes, per_queue, c.ns, c.nl, it, alu, out)
+#define LAUNCH(N, L) hipLaunchKernelGGL((chase<N, L>), dim3(waves), dim3(64), 0, 0, buf, stride, queue_bytes, per_queue, leaf_gap, c.ns, c.nl, it, alu, out)
                 if (c.node == 8 && c.leaf == 64) LAUNCH(8, 64); else if (c.node == 4 && c.leaf == 64) LAUNCH(4, 64); else if (c.node == 8) LAUNCH(8, 32); else LAUNCH(4, 32);
             }
             if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 1; }
@@ -80,7 +83,7 @@ int main(int argc, char **argv) {
             hipMemcpy(h.data(), out, 8 * waves, hipMemcpyDeviceToHost);
             double s = 0;
             for (auto v : h) s += (double)v;
-            printf("%6d %6d %6d %8u %8u %9.1f %9.0f %8s %10.0f\n", waves, c.node, c.leaf, c.ns, c.nl, region / 1024.0, waves * (double)region / 1048576.0, layout ? "arenas" : "tight", s / waves / iters);
+            printf("%6d %6d %6d %8u %8u %9.1f %9.0f %8s %10.0f\n", waves, c.node, c.leaf, c.ns, c.nl, region / 1024.0, waves * (double)region / 1048576.0, layout == 1 ? "arenas" : layout == 2 ? "scratch" : "tight", s / waves / iters);
             fflush(stdout);
             }
         }
