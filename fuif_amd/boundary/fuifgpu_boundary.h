@@ -11,7 +11,7 @@
 #include "image/image.h"
 
 // images[i] receives file i; ok[i] (optional) says whether it decoded.  Returns the number of files decoded.
-// A file outside the GPU scope is an error (ok[i] = false) unless FUIFGPU_ALLOW_CPU_FALLBACK=1 lets the reference's own code decode it.
+// A file outside the GPU scope is an error (ok[i] = false); only a binding built with -DFUIFGPU_WITH_CPU_FALLBACK can route it to the reference's own decoder (FUIFGPU_ALLOW_CPU_FALLBACK=1).
 // The files are decoded on the calling thread's current GPU -- or, with FUIFGPU_DEVICES="all" / "0,1,..." in the environment, spread over those
 // GPUs of the node as fuif_decode_files_on does.
 int fuif_decode_files(const char *const *filenames, int n_files, Image *images, fuif_options options, bool *ok = nullptr);

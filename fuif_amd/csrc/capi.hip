@@ -72,8 +72,6 @@ struct fuifgpu_batch {
     bool decode_timed = false, transform_timed = false;
     bool no_out = false;              // fuifgpu_batch_create_streaming: no output slab; fuifgpu_batch_undo_transforms_to writes into caller memory
     std::vector<char> undone;         // ... which images of the current decode have been through it (each once: the channel metadata is rewritten)
-    std::vector<uint32_t> exp_preset;   // EXPERIMENT (FUIFGPU_EXP_SKIP_SAMPLES): progress words preset to 'final' for the tiles left out of the launch
-    int exp_waves_per_simd = 0;
     bool coef_consumed = false;   // undo_transforms has run on the current decode: several inverse steps work in place on the coefficients
     // A sibling (fuifgpu_batch_create_sibling) owns only what an UPLOAD writes -- stream bytes, tile lists, per-image results -- and
     // decodes with the primary's slabs, decoder scratch, context arenas and transform arena (everything a LAUNCH uses)
@@ -431,12 +429,6 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
     }
     int64_t image_samples = 0;
     for (int c = 0; c < nch; c++) image_samples += (int64_t)b->plan.coded[c].w * b->plan.coded[c].h;
-    int64_t exp_skip = 0;
-    if (const char *e = getenv("FUIFGPU_EXP_SKIP_SAMPLES")) exp_skip = atoll(e);
-    b->exp_preset.clear();
-    if (exp_skip > 0) b->exp_preset.assign((size_t)n_images * std::max(nch, 1), 0u);
-    b->exp_waves_per_simd = 0;
-    if (const char *e = getenv("FUIFGPU_EXP_WAVES_PER_SIMD")) b->exp_waves_per_simd = atoi(e);
     auto push_tile = [&](int i, size_t k) {
         const std::vector<GroupEntry> &g = groups[group_of[i]];
         if (k >= g.size()) return;
@@ -454,10 +446,6 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
         uint32_t cls = 15;
         if (mine > 0) { cls = 0; while (cls < 15 && (mine << (cls + 1)) <= image_samples) cls++; }
         t.flags |= cls << kTileSizeClassShift;
-        if (exp_skip > 0 && mine <= exp_skip) {   // EXPERIMENT: the tile's planes are taken from the previous decode of the same batch
-            for (int c = (int)t.first_channel; c <= (int)t.last_channel; c++) b->exp_preset[(size_t)i * nch + c] = (uint32_t)b->plan.coded[c].h + 1u;
-            return;
-        }
         b->tiles.push_back(t);
     };
     // Dense launches with more tiles than wavefronts use the context scheduler (maniac_decode.h, sched == 1): tiles image by
@@ -506,8 +494,6 @@ int fuifgpu_batch_upload(fuifgpu_batch *b, const uint8_t *const *blobs, const si
         itb[n_images] = (uint32_t)b->tiles.size();
     }
     b->n_tiles = (int)b->tiles.size();
-    if (b->exp_waves_per_simd > 0) b->n_waves = std::min(b->n_waves, b->max_waves[b->cfg] / std::max(1, b->waves_per_simd) * b->exp_waves_per_simd);
-    if (exp_skip > 0) b->n_waves = std::min(b->n_waves, std::max(1, b->n_tiles));
     {
         // scheduler state, zeroed before every launch: q_head | done_total | statistics | started_total | heartbeat | cu claim table |
         // cu_alive | cu_live | cu_foreign | img_next | img_done | ctx_used | tile records
@@ -578,10 +564,9 @@ int fuifgpu_batch_decode(fuifgpu_batch *b, void *stream) {
     if (!b || b->n_loaded < 1) return FUIFGPU_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int nch = (int)b->plan.coded.size();
-    if (b->exp_preset.empty()) HIPCHK(hipMemsetAsync(b->d_meta, 0, sizeof(ChannelMeta) * (size_t)b->n_loaded * std::max(nch, 1), st));
+    HIPCHK(hipMemsetAsync(b->d_meta, 0, sizeof(ChannelMeta) * (size_t)b->n_loaded * std::max(nch, 1), st));
     // every word the tiles poll or accumulate into is zeroed before every launch
     HIPCHK(hipMemsetAsync(b->d_progress, 0, sizeof(uint32_t) * (size_t)b->n_loaded * std::max(nch, 1), st));
-    if (!b->exp_preset.empty()) HIPCHK(hipMemcpyAsync(b->d_progress, b->exp_preset.data(), sizeof(uint32_t) * b->exp_preset.size(), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(b->d_group_start, 0, sizeof(uint32_t) * (size_t)b->n_loaded * std::max(nch, 1), st));
     HIPCHK(hipMemsetAsync(b->d_sched, 0, b->sched_words * 4, st));
     HIPCHK(hipMemsetAsync(b->d_status, 0, sizeof(int32_t) * b->n_loaded, st));

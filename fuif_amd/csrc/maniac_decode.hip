@@ -104,15 +104,10 @@ constexpr int CH_ZERO = 0, CH_SIGN = 1, CH_EXP = 2, CH_MANT = 16, CH_N = 31;
 #define FUIF_LDS_WIDE_ALONE 58
 #endif
 constexpr int kLdsWide = FUIF_LDS_WIDE, kLdsDense = FUIF_LDS_DENSE, kLdsWideAlone = FUIF_LDS_WIDE_ALONE;
-// Round 6: the dense configuration keeps the first kLdsDenseNarrow NARROW supernodes behind the root (256 bytes each) in LDS after all.  Since round 3 the
-// children of the top supernodes are numbered by subtree size, and subtree size predicts the traffic almost perfectly: on the long 4K groups the 11 largest
-// second-level supernodes serve 63-70 % of the rounds behind the root (tools/supernode_packing.py on the oracle's visit counts; round 2's "two slots serve
-// 0.9 %" was measured on breadth-first numbering).  The room comes from the property rows, which a narrow group stores as int16 (its properties lie inside
-// 13 bits): 2112 bytes of the 4224, plus 704 bytes more -- 6440 bytes per wavefront, still 24 wavefronts per CU (13 x 512-byte LDS granules each).
-#ifndef FUIF_LDS_DENSE_NARROW
-#define FUIF_LDS_DENSE_NARROW 11
-#endif
-constexpr int kLdsDenseNarrow = FUIF_LDS_DENSE_NARROW;
+// (Round 6 tried 11 narrow supernodes resident in LDS in the dense configuration as well -- since the children of the top supernodes are numbered by subtree
+// size, the 11 largest second-level supernodes of a long 4K group serve 63-70 % of the rounds behind the root (tools/supernode_packing.py), with the room taken
+// from int16 property rows.  A long group alone got 7 % faster, the 1024-picture launch 4.7 % SLOWER: with every wavefront slot busy the launch is bound by what a
+// SIMD issues, and the six instructions per round cost more than the hidden round trips gave back.  Removed: profiles/r6_variants_lds_records_vs_none.txt.)
 #ifndef FUIF_SIZE_ORDERED
 #define FUIF_SIZE_ORDERED 64   // supernodes (breadth first) whose children are numbered by subtree size; 0 = exit order everywhere
 #endif
@@ -772,21 +767,12 @@ struct Shared {
     uint2 snodes[kLdsSuper > 0 ? kLdsSuper * 64 : 1];   // breadth-first top of the supernode tree: lane i = {split_i, prop_i << 2 | exit_i << 8}
     static constexpr int kChunk = kDense ? kChunkDense : 64;
     static constexpr int kPropWords = (kChunk > 4 ? kChunk : 4) * kPropPitch;
-    // narrow supernodes resident in LDS: the wide configurations keep them in `snodes`; the dense one behind the int16 property rows of a narrow
-    // group, i.e. in the second half of `cprops` and in `ntail` right behind it (kNarrowBase: word offset from cprops)
-    static constexpr int kLdsN = kDense ? kLdsDenseNarrow : kLdsSuper;
-    static constexpr int kNarrowBase = (kPropWords + 1) / 2;
-    static constexpr int kTailWords = kDense && kLdsDenseNarrow * 64 > kPropWords - kNarrowBase ? kLdsDenseNarrow * 64 - (kPropWords - kNarrowBase) : 1;
+    static constexpr int kLdsN = 2 * kLdsSuper;   // narrow supernodes (256 bytes) resident in LDS: twice as many as 512-byte ones fit the wide configurations' `snodes`
     int32_t cprops[kPropWords]; // [pixel of the chunk][property]; the supernode build borrows 256 words
-    uint32_t ntail[kTailWords];
     uint16_t meta_ctx[3][32];            // three SimpleSymbolCoder contexts of the tree coder
     int32_t lo[kMaxProps], hi[kMaxProps];
     RefChan refs[kMaxRefs];
 };
-
-// the element type of a chunk's property rows (k_maniac_decode: int16 for a narrow group in the dense configuration)
-template <bool kNarrow, int kLdsSuper>
-struct PropRow { using type = std::conditional_t<kNarrow && Shared<kLdsSuper>::kDense, int16_t, int32_t>; };
 
 // kHandOff = false: every image is one tile, nothing a tile writes is read by another one before the
 // kernel ends -- plain cached stores and loads (write-through stores drop the line from L2, and the
@@ -812,8 +798,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
     constexpr int kLdsN = Shared<kLdsSuper>::kLdsN;          // narrow supernodes resident in LDS (behind the root)
     constexpr bool kDense = Shared<kLdsSuper>::kDense;
     const int lane = threadIdx.x;
-    // where they live: the wide configurations' `snodes`, the dense one's second half of the property rows (a narrow group's rows are int16)
-    uint32_t *const lds_narrow = kDense ? reinterpret_cast<uint32_t *>(sh.cprops) + Shared<kLdsSuper>::kNarrowBase : reinterpret_cast<uint32_t *>(sh.snodes);
+    uint32_t *const lds_narrow = reinterpret_cast<uint32_t *>(sh.snodes);   // (a narrow group keeps 2 * kLdsSuper supernodes of 256 bytes there)
 
     const uint16_t *tree_table = P.tables;          // cut 2, alpha 0xFFFFFFFF/19 (compound.h:262)
     const uint16_t *pixel_table = P.tables + 8192;  // cut 6, alpha 0x0d000000 (encoding.h:54-55)
@@ -1538,7 +1523,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                     // (every inner exit is admitted: the area holds (7n+5)/12 + 1 supernodes, which is what made the group narrow)
                     const uint32_t w = pack_narrow((int)out.x, (uint32_t)st_prop[lane], inner ? (tgt & 0x1FFFu) : (kLeafFlagN | (uint32_t)n.child));
                     reinterpret_cast<uint32_t *>(snodes_g)[(size_t)sn * 64 + lane] = w;
-                    if (sn >= 1 && sn <= kLdsN) lds_narrow[(sn - 1) * 64 + lane] = w;   // (dense configuration: behind the 1020 bytes of cprops this build borrows)
+                    if (sn >= 1 && sn <= kLdsN) lds_narrow[(sn - 1) * 64 + lane] = w;
                 } else {
                     snodes_g[(size_t)sn * 64 + lane] = out;
                     if (sn >= 1 && sn <= kLdsSuper) sh.snodes[(sn - 1) * 64 + lane] = out;   // the root (0) lives in registers: LDS holds 1..kLdsSuper
@@ -1570,13 +1555,19 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         }
         }  // !resumed
 #ifdef FUIF_EMU_DEBUG
-        if (lane == 0 || lane == 20) fprintf(stderr, "group c%d: lane %d tree %d n_super %d narrow %d nprops %d ctx %d resumed %d\n", ci, lane, tree_size, n_super, (int)narrow, nprops, ctx_slot, (int)resumed);
+        if (lane == 0 || lane == 20) fprintf(stderr, "group c%d: lane %d tree %d n_super %d narrow %d compact %d nprops %d ctx %d resumed %d\n", ci, lane, tree_size, n_super, (int)narrow, (int)compact, nprops, ctx_slot, (int)resumed);
 #endif
         const uint2 root_nd = narrow ? uint2{0u, 0u} : snodes_g[lane];  // the root supernode lives in registers
         const uint32_t root_w = narrow ? reinterpret_cast<const uint32_t *>(snodes_g)[lane] : 0u;
         LeafRegs L;
         const uint32_t leaf_shift = compact ? 5u : 6u, leaf_l2 = (uint32_t)(lane & (compact ? 15 : 31)) * 2u;   // a leaf's bytes; this lane's chance inside it
         L.leafv = (int)*reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(leaves) + (((uint32_t)cur_leaf << leaf_shift) + leaf_l2));   // lanes 32..63 mirror lanes 0..31 (switch_leaf)
+        // the shift as a per-lane value the compiler cannot see through: (id << shift) + offset is then ONE vector instruction (v_lshl_add_u32 with the shift
+        // in a VGPR) instead of a scalar shift + a vector add per address -- the scalar pipe is the loaded one (two addresses per symbol)
+        uint32_t leaf_shift_v = leaf_shift;
+#ifndef FUIF_EMU
+        asm volatile("v_mov_b32 %0, %1" : "=v"(leaf_shift_v) : "s"(leaf_shift));
+#endif
         L.touched = 0; L.bits = 0;
         L.mb = rfl(compact ? kMantCompact : CH_MANT); L.mirror = rflu(compact ? 0x10001u : 1u);
         auto switch_leaf = [&](int id) {
@@ -1588,8 +1579,8 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 // the fetch is issued FIRST: it does not depend on the chances in leafv, the write-back does (the commit's table lookup may
                 // still be landing in them) -- where the walk is short (wide configuration: every round from LDS) that wait would
                 // otherwise sit in front of the leaf's memory round trip
-                const int fresh = (int)*reinterpret_cast<const uint16_t *>(lb + (((uint32_t)id << leaf_shift) + l2));
-                *reinterpret_cast<uint16_t *>(lb + (((uint32_t)cur_leaf << leaf_shift) + l2)) = (uint16_t)L.leafv;
+                const int fresh = (int)*reinterpret_cast<const uint16_t *>(lb + (((uint32_t)id << leaf_shift_v) + l2));
+                *reinterpret_cast<uint16_t *>(lb + (((uint32_t)cur_leaf << leaf_shift_v) + l2)) = (uint16_t)L.leafv;
                 L.leafv = fresh;
                 cur_leaf = id;
             }
@@ -1630,9 +1621,7 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 auto rows = [&](auto pred0_tag, auto narrow_tag) {
                     constexpr bool PRED0 = decltype(pred0_tag)::value;
                     constexpr bool NARROW = decltype(narrow_tag)::value;   // 4-byte supernode lane words (kLeafFlagN)
-                    // dense configuration, narrow group: the property rows are int16 (every property of such a group lies inside 13 bits, the partial sums the
-                    // vector phase parks inside 15), which leaves the other half of cprops to the LDS-resident supernodes (Shared::kNarrowBase)
-                    using prop_t = typename PropRow<decltype(narrow_tag)::value, kLdsSuper>::type;
+                    using prop_t = int32_t;
                     for (; y < h; y++) {
                         if (s_limit_hit(s)) break;
                         __syncthreads();  // the previous row's stores are complete before it is re-read as `top`
@@ -1812,8 +1801,8 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                             const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
                                             const bool hit = ((((mlo ^ exp_lo) & msk_lo) | ((mhi ^ exp_hi) & msk_hi)) == 0u);
                                             const int e = __builtin_ctzll(__ballot(hit));
-                                            const uint32_t rot = (w >> 20) | (w << 12);               // exit: bits 13..0 (v_alignbit_b32)
-                                            return (uint32_t)rdlane((int)rot, e) & 0x3FFFu;
+                                            const uint32_t ex = ((w >> 20) | (w << 12)) & 0x3FFFu;    // exit: v_alignbit_b32 + v_and (masked on the vector side: the scalar pipe is the loaded one)
+                                            return (uint32_t)rdlane((int)ex, e);
                                         };
                                         tgt = walk_round_n(root_w);
                                         EMU_COUNT(0);

@@ -66,7 +66,8 @@ SELECTED = [
     ("tests/test_gpu_parity.py::test_wide_configuration_for_two_batches_in_flight", 25),
     ("tests/test_gpu_synthetic.py::test_jpeg_like_chain_fused_and_unfused_match_oracle", 20),
     ("tests/test_gpu_group_parallel.py::test_add_group_index_copies_refused_streams_through", 2),
-]
+] + [("tests/test_gpu_synthetic.py::test_context_formats_of_round_6[%s-%s]" % (ix, case), 25) for ix in ("False", "True")
+     for case in ("narrow_compact", "narrow_full_leaves", "tall_wide_format", "deep_bits_wide_format", "many_properties_wide_format")]
 
 
 def run_dealt(weighted, env, workers, timeout=1700):
@@ -97,6 +98,9 @@ CONCURRENT = [
     "tests/test_gpu_group_parallel.py::test_reference_written_files_indexed_after_the_fact",
     "tests/test_gpu_group_parallel.py::test_mixed_batch_with_more_tiles_than_wavefronts",
     "tests/test_gpu_group_parallel.py::test_jpeg_like_indexed",
+    # round 6: suspended and resumed tiles whose supernodes are narrow / whose leaves are compact (the format flags travel in the tile record)
+    "tests/test_gpu_synthetic.py::test_context_formats_of_round_6[True-narrow_compact]",
+    "tests/test_gpu_synthetic.py::test_context_formats_of_round_6[True-narrow_full_leaves]",
 ]
 
 

@@ -66,6 +66,44 @@ def test_deep_trees_walk_through_chained_supernodes(gpulib, port, index):
         assert np.array_equal(post[1][k], img[k])
 
 
+@pytest.mark.parametrize("case", ["narrow_compact", "narrow_full_leaves", "tall_wide_format", "deep_bits_wide_format", "many_properties_wide_format"])
+@pytest.mark.parametrize("index", [False, True])
+def test_context_formats_of_round_6(gpulib, port, case, index):
+    """the context layouts k_maniac_decode chooses per channel group (round 6): NARROW supernodes (4-byte lane words) when every property of the group
+    lies inside 13 bits, the group has at most 32 properties and its tree at most 13 999 nodes -- 8-byte ones otherwise; COMPACT leaves (16 chances,
+    32 bytes) when every symbol of the group has at most 8 magnitude bits -- 31 chances otherwise.  Each case forces one combination on most of its
+    groups (the small low-resolution groups of every picture still mix them); every coded plane and every output plane against the CPU oracle, with and
+    without the group index (dense configuration + context scheduler / wide configurations with LDS-resident supernodes)."""
+    import os
+    emulated = ("_emu" in os.path.basename(os.environ.get("FUIF_AMD_LIB", "")))
+    kw = dict(tree_mode=1, index=index, split_bits=2)      # (a split only has to save 2 bits: bushy trees on small pictures)
+    if case == "narrow_compact":            # 8 bit, sigma 3: residuals within +-255 -> 13-bit properties, 8 magnitude bits
+        img, bits = photographic(200 if emulated else 400, 150 if emulated else 300, 3, 8, seed=1), 8
+    elif case == "narrow_full_leaves":      # 8 bit, sigma 90 (clipped): residuals of 9 magnitude bits in the large groups, properties still inside 13 bits
+        img, bits = photographic(200 if emulated else 400, 150 if emulated else 300, 3, 8, seed=2, sigma=90.0), 8
+    elif case == "tall_wide_format":        # the first residual plane has more than 4096 rows: the row property leaves 13 bits -> 8-byte supernodes on 8-bit data
+        img, bits = photographic(8 if emulated else 24, 8400, 1, 8, seed=3), 8
+    elif case == "deep_bits_wide_format":   # 14 bit
+        img, bits = photographic(160 if emulated else 320, 120 if emulated else 240, 4, 14, seed=4), 14
+    else:                                   # -E 18: 2 * 9 + 13 = 31 properties (narrow); -E 24 would be 37 > 32 (wide): both in one batch is not possible (one plan) -> the wide one
+        img, bits = photographic(160 if emulated else 320, 120 if emulated else 240, 4, 8, seed=5), 8
+        kw["max_properties"] = 24
+    ycocg = img.shape[0] == 3
+    blob = gpulib.encode_image(img, bits, ycocg=ycocg, **kw)
+    pre, post, st, used = gpu_decode(gpulib, [blob, blob])
+    d_pre, d_post = port.decode_both(blob)
+    assert not st.any()
+    for planes in pre:
+        assert len(planes) == len(d_pre.channels)
+        for g, e in zip(planes, d_pre.channels):
+            assert np.array_equal(g, e["data"])
+    for planes in post:
+        for g, e in zip(planes, d_post.channels):
+            assert np.array_equal(g, e["data"])
+        for k in range(img.shape[0]):
+            assert np.array_equal(planes[k], img[k])
+
+
 def test_batch_of_distinct_images(gpulib):
     imgs = [photographic(800, 600, 3, 8, seed=5000 + i) for i in range(6)]
     blobs = [gpulib.encode_image(im, 8, tree_mode=1) for im in imgs]

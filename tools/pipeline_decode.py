@@ -28,7 +28,7 @@ from bench import make_inputs  # noqa: E402
 import fuif_amd  # noqa: E402
 
 argv = sys.argv[1:]
-pos = [a for i, a in enumerate(argv) if not a.startswith("--") and (i == 0 or argv[i - 1] not in ("--launches", "--stagger", "--size", "--distinct", "--rounds"))]
+pos = [a for i, a in enumerate(argv) if not a.startswith("--") and (i == 0 or argv[i - 1] not in ("--launches", "--stagger", "--size", "--distinct", "--rounds", "--batches"))]
 n = int(pos[0]) if pos else 1024
 
 
@@ -41,19 +41,20 @@ stagger = opt("--stagger", 3.6, float)
 w, h = (int(x) for x in opt("--size", "3840x2160", str).split("x"))
 distinct = opt("--distinct", 8, int)
 rounds = opt("--rounds", 2, int)
+NB = opt("--batches", 2, int)     # batch objects / HIP streams the launches alternate between (round 6: 3 for streams without group index)
 inputs = make_inputs(distinct, w, h, 3, 8, 1000, os.environ.get("FUIF_BENCH_CACHE", "/tmp/fuif_bench_cache"))
 blobs = [inputs[i % distinct][1] for i in range(n)]
 plan = fuif_amd.Plan(blobs[0])
 L = fuif_amd.lib()
-streams = [None, None]
+streams = [None] * NB
 if "--no-streams" not in argv:
     hip = fuif_amd.hip_runtime()            # (the runtime the library itself runs on: torch's bundled copy when torch is installed)
-    for k in range(2):
+    for k in range(NB):
         s = C.c_void_p()
         assert hip.hipStreamCreateWithFlags(C.byref(s), 1) == 0     # hipStreamNonBlocking
         streams[k] = s
 cap = sum(len(b) for b in blobs) + 4096 * n
-batches = [fuif_amd.Batch(plan, n, cap, streaming=True) for _ in range(2)]
+batches = [fuif_amd.Batch(plan, n, cap, streaming=True) for _ in range(NB)]
 for b, s in zip(batches, streams):
     b.set_in_flight(1 if "--in-flight-1" in argv else 2)     # (1: the 58-supernode wide configuration of a launch alone)
     if "--no-index" in argv:
@@ -66,7 +67,7 @@ px = n * w * h
 with_tr = "--with-transforms" in argv
 L.fuifgpu_dev_alloc.restype = C.c_void_p
 n_slice = max(1, min(n, (8 << 30) // (4 * max(plan.info.out_elems, 1))))
-outs = [L.fuifgpu_dev_alloc(C.c_size_t(n_slice * plan.info.out_elems * 4)) for _ in range(2)] if with_tr else [None, None]
+outs = [L.fuifgpu_dev_alloc(C.c_size_t(n_slice * plan.info.out_elems * 4)) for _ in range(NB)] if with_tr else [None] * NB
 assert not with_tr or all(outs), "device allocation failed"
 
 
@@ -90,12 +91,12 @@ def last_slice_hash():
 def run(pipelined):
     t0 = time.perf_counter()
     for i in range(K):
-        b, s = batches[i % 2], streams[i % 2]
+        b, s = batches[i % NB], streams[i % NB]
         if pipelined and i == 1 and stagger > 0:
             time.sleep(stagger)                # the second launch is queued while the first is in its busy phase
         b.decode(s)                            # asynchronous: a launch waits for its predecessor on the same stream only
         if with_tr:
-            transforms(b, s, outs[i % 2])
+            transforms(b, s, outs[i % NB])
         if not pipelined:
             b.sync(s)
     for b, s in zip(batches, streams):
@@ -118,13 +119,13 @@ if "--per-launch" in argv:
         b, s = batches[k], streams[k]
         if k == 1 and stagger > 0:
             time.sleep(stagger)
-        for i in range(k, K, 2):
+        for i in range(k, K, NB):
             b.decode(s)
             if with_tr:
                 transforms(b, s, outs[k])
             b.sync(s)
             done.append((time.perf_counter() - t_start, i))
-    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(NB)]
     for t in th:
         t.start()
     for t in th:
@@ -147,7 +148,7 @@ if tile_log:
 for mode in ((True,) if "--only-pipelined" in argv else (False,) if "--only-sequential" in argv else (False, True)) * rounds:
     dt = run(mode)
     print("%s: %d launches of %d x %dx%d in %.2f s -> %.2f s per launch, %.1f Mpixels/s (%s)" % (
-        "pipelined (two streams, stagger %.1f s)" % stagger if mode else "sequential", K, n, w, h, dt, dt / K, K * px / dt / 1e6,
+        "pipelined (%d streams, stagger %.1f s)" % (NB, stagger) if mode else "sequential", K, n, w, h, dt, dt / K, K * px / dt / 1e6,
         "entropy + inverse transforms; last output slices %s" % "/".join(last_slice_hash()) if with_tr else "entropy only"), flush=True)
 print("last launches by their own events: %.0f / %.0f ms" % (batches[0].timing()[0], batches[1].timing()[0]))
 
