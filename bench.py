@@ -415,6 +415,7 @@ def pmc_traffic(batch, mode):
     src = {"profile": best["_file"], "round": best.get("round"), "kernel_ms_when_profiled": best.get("kernel_ms_under_pmc"),
            "read_factor_leaf_pattern": best.get("read_factor_leaf_pattern", (best.get("calibration", {}).get("read") or {}).get("factor")),
            "read_factor_supernode_pattern": best.get("read_factor_supernode_pattern"), "read_factor_used": best.get("read_factor_used"),
+           "write_factor_used": best.get("write_factor_used"),
            "range_bytes": [best.get("traffic_bytes_per_launch_all_leaf_factor"), best.get("traffic_bytes_per_launch_all_supernode_factor")]}
     return int(best["traffic_bytes_per_launch"]), src
 
@@ -862,8 +863,8 @@ def live_pmc_traffic(args, committed_src):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     # one factor per access pattern (committed calibration): reads are a mix of supernodes and leaves weighted by requested bytes
-    rf = (committed_src or {}).get("read_factor_used") or 1.9
-    wf = 1.0
+    rf = (committed_src or {}).get("read_factor_used") or 1.0
+    wf = (committed_src or {}).get("write_factor_used") or 1.0
     traffic = int(out["FETCH_SIZE"] * 1024 * rf + out["WRITE_SIZE"] * 1024 * wf)
     return traffic, {"measured": "live: two rocprofv3 --pmc passes in this run (FETCH_SIZE, WRITE_SIZE), one launch each", "FETCH_SIZE_KiB": round(out["FETCH_SIZE"]),
                      "WRITE_SIZE_KiB": round(out["WRITE_SIZE"]), "read_factor_used": rf, "write_factor_used": wf,

@@ -1415,22 +1415,16 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
         // (Without a free area the context stays in the wavefront's scratch area and the tile is PINNED to this wavefront: it
         // is suspended and resumed like the others, but by this wavefront only -- see pinned_tix.)
         int max_super_here = P.max_super;
-        if (sched && kHandOff && (rflu(tile.flags) & kTileSuspendable) && beginc == endc && endc == last_c && nrefs > 0) {
-            // (7n+5)/12 supernodes are enough for n inner nodes (capi.hip), so nothing falls to the node-by-node walk
-            const uint32_t inner = (uint32_t)(tree_size - 1) / 2u;
-            const uint32_t sn_cap = (7u * inner + 5u) / 12u + 1u;
-            narrow = narrow_ok && tree_size <= kNarrowMaxNodes;
-            const uint32_t sn_units = narrow ? sn_cap : sn_cap * 2u;   // a narrow supernode is one 256-byte unit
-            const uint32_t units = sn_units + ((uint32_t)nleaves * leaf_bytes + 255u) / 256u;   // 256-byte units
+        // ONE arena, two bump pointers in one 64-bit word: the tiles that hold >= 1/16 of their picture -- the long per-symbol chains that bound
+        // the launch, whose contexts are what the memory system has to keep close -- are packed from the bottom, everything else from the top.
+        // (Rounds 2-5 gave every CU queue its own 64 MiB arena: the hot contexts of a launch lay 512 pages apart instead of ~100; tight
+        // placement is worth ~6 % of a long tile's per-symbol chain, profiles/r6_ubench_context_layouts.txt.)  Both counters only grow, and an
+        // area is granted from ONE atomic snapshot of both, so areas never overlap; a failed request leaves its units unused (the arena
+        // was full: the tile is pinned to this wavefront's scratch area).
+        auto grant_area = [&](uint32_t units) -> uint32_t {
             uint32_t off = 0xFFFFFFFFu;
             const bool low_end = ((rflu(tile.flags) >> kTileSizeClassShift) & 15u) <= kLongClass + 1u;
             if (lane == 0) {
-                // ONE arena, two bump pointers in one 64-bit word: the tiles that hold >= 1/16 of their picture -- the long per-symbol chains that bound
-                // the launch, whose contexts are what the memory system has to keep close -- are packed from the bottom, everything else from the top.
-                // (Rounds 2-5 gave every CU queue its own 64 MiB arena: the hot contexts of a launch lay 512 pages apart instead of ~100; tight
-                // placement is worth ~6 % of a long tile's per-symbol chain, profiles/r6_ubench_context_layouts.txt.)  Both counters only grow, and an
-                // area is granted from ONE atomic snapshot of both, so areas never overlap; a failed request leaves its units unused (the arena
-                // was full: the tile is pinned to this wavefront's scratch area).
                 const uint32_t total = P.ctx_units_per_queue * (uint32_t)n_queues;
                 const unsigned long long seen = __hip_atomic_load(P.ctx_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned long long)(uint32_t)seen + (seen >> 32) + units <= total) {
@@ -1439,22 +1433,37 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                     if (lo + hi <= total) off = low_end ? (uint32_t)o : total - (uint32_t)hi;
                 }
             }
-            off = rflu(off);
+            return rflu(off);
+        };
+        // (7n+5)/12 supernodes are enough for n inner nodes (capi.hip), so a build with room for that many never falls to the node-by-node walk
+        const uint32_t sn_cap = (7u * ((uint32_t)(tree_size - 1) / 2u) + 5u) / 12u + 1u;
+        const bool suspendable_here = sched && kHandOff && (rflu(tile.flags) & kTileSuspendable) && beginc == endc && endc == last_c && nrefs > 0;
+        // Round 6: a suspendable tile whose worst case fits the wavefront's scratch area builds its supernodes THERE and moves them, once their real number
+        // is known, into a context area of exactly that size (rounds 2-5 reserved the worst case: 526 supernode slots for the ~150 a long 4K group has, with
+        // the leaves behind the unused ones -- 2.5x the footprint, and C4's 743 KB per tile ran the arenas dry).  Only trees too large for the scratch
+        // area (more than ~7000 inner nodes) still reserve their worst case up front.
+        bool exact_area = false;
+        narrow = narrow_ok && tree_size <= kNarrowMaxNodes && (int)sn_cap <= P.max_super;
+        if (suspendable_here) {
             can_yield = true;
-            if (off != 0xFFFFFFFFu) {
-                ctx_slot = (int)off;
-                uint8_t *cb = P.ctx_scratch + (size_t)off * 256u;
-                snodes_g = reinterpret_cast<uint2 *>(cb);
-                leaves = reinterpret_cast<uint16_t *>(cb + (size_t)sn_units * 256u);
-                ctx_leaves_units = sn_units;
-                max_super_here = (int)sn_cap;
-            } else {
-                // no area left: the context stays in this wavefront's scratch area and the tile is pinned to the wavefront
-                STATS(st_noctx++;)
-                pinned_tix = tix;
-                narrow = narrow && (int)sn_cap <= max_super_here;   // (the wavefront's scratch area holds P.max_super supernodes)
+            if ((int)sn_cap <= P.max_super) exact_area = true;
+            else {
+                const uint32_t sn_units = sn_cap * 2u;   // (such a tree is never narrow)
+                const uint32_t off = grant_area(sn_units + ((uint32_t)nleaves * leaf_bytes + 255u) / 256u);
+                if (off != 0xFFFFFFFFu) {
+                    ctx_slot = (int)off;
+                    uint8_t *cb = P.ctx_scratch + (size_t)off * 256u;
+                    snodes_g = reinterpret_cast<uint2 *>(cb);
+                    leaves = reinterpret_cast<uint16_t *>(cb + (size_t)sn_units * 256u);
+                    ctx_leaves_units = sn_units;
+                    max_super_here = (int)sn_cap;
+                } else {
+                    // no area left: the context stays in this wavefront's scratch area and the tile is pinned to the wavefront
+                    STATS(st_noctx++;)
+                    pinned_tix = tix;
+                }
             }
-        } else narrow = narrow_ok && tree_size <= kNarrowMaxNodes && (7 * ((tree_size - 1) / 2) + 5) / 12 + 1 <= max_super_here;
+        }
         // Subtree sizes (nodes, saturating): children always have larger indices than their parent in the parse-order
         // array, so one backward sweep does it.  The learner splits contexts that see many samples, so a child
         // supernode with a big subtree is (statistically) a frequently walked one: numbering them big-first puts the
@@ -1529,6 +1538,25 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                     if (sn >= 1 && sn <= kLdsSuper) sh.snodes[(sn - 1) * 64 + lane] = out;   // the root (0) lives in registers: LDS holds 1..kLdsSuper
                 }
                 __syncthreads();
+            }
+        }
+        if (exact_area) {
+            const uint32_t sn_units = narrow ? (uint32_t)n_super : (uint32_t)n_super * 2u;   // a narrow supernode is one 256-byte unit
+            const uint32_t off = grant_area(sn_units + ((uint32_t)nleaves * leaf_bytes + 255u) / 256u);
+            if (off != 0xFFFFFFFFu) {
+                ctx_slot = (int)off;
+                uint8_t *cb = P.ctx_scratch + (size_t)off * 256u;
+                uint32_t *dst = reinterpret_cast<uint32_t *>(cb);
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(snodes_w);
+                for (uint32_t k = (uint32_t)lane; k < sn_units * 64u; k += 64u) dst[k] = src[k];   // (the supernodes just built, 256 bytes per unit)
+                snodes_g = reinterpret_cast<uint2 *>(cb);
+                leaves = reinterpret_cast<uint16_t *>(cb + (size_t)sn_units * 256u);
+                ctx_leaves_units = sn_units;
+                __syncthreads();
+            } else {
+                // no area left: the context stays in this wavefront's scratch area and the tile is pinned to the wavefront
+                STATS(st_noctx++;)
+                pinned_tix = tix;
             }
         }
         // A context that lives in this wavefront's scratch area (streams without group index, pinned tiles): the leaf chances start right behind the
