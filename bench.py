@@ -260,7 +260,8 @@ def run_extra_leg(name, spec, streams, dev):
            "bits_per_pixel": round(8.0 * sum(sum(len(b) for b in p["blobs"]) for p in parts) / px, 3), "parity_ok": bool(ok),
            "parity_check": "lossless pictures == source pixels (every image); lossy ones: all replicas identical and MSE vs source < 40; status 0; picture 0 of every kind: "
                            "every output plane == the REAL reference's decode of the same stream (reference_decode_of_stream0)",
-           "reference_decode_of_stream0": ref_compared if ref_compared else "oracle/_ref not available on this box",
+           "reference_decode_of_stream0": ref_compared if ref_compared else ("oracle/_ref not available on this box" if ref_lib is None else
+                                                                                   "not run: pictures above 40 M samples (lossless: every picture is compared with its source pixels instead)"),
            "roofline": {"bound": "hbm", "kernel": "k_maniac_decode", "achieved": round(alg / max(d_avg, 1e-9) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(alg / max(d_avg, 1e-9) / 1e9 / HBM_PEAK_GBS, 6), "kernel_ms": round(d_avg * 1e3, 3), "algorithmic_bytes_per_launch": int(alg),
                         "transforms": {"ms": round(t_avg * 1e3, 3), "achieved": round(alg_tr / max(t_avg, 1e-9) / 1e9, 1), "unit": "GB/s",

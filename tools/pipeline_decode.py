@@ -150,7 +150,7 @@ for mode in ((True,) if "--only-pipelined" in argv else (False,) if "--only-sequ
     print("%s: %d launches of %d x %dx%d in %.2f s -> %.2f s per launch, %.1f Mpixels/s (%s)" % (
         "pipelined (%d streams, stagger %.1f s)" % (NB, stagger) if mode else "sequential", K, n, w, h, dt, dt / K, K * px / dt / 1e6,
         "entropy + inverse transforms; last output slices %s" % "/".join(last_slice_hash()) if with_tr else "entropy only"), flush=True)
-print("last launches by their own events: %.0f / %.0f ms" % (batches[0].timing()[0], batches[1].timing()[0]))
+print("last launches by their own events: " + " / ".join("%.0f" % b.timing()[0] for b in batches) + " ms")
 
 if tile_log:
     # the LAST launch of each batch object on one time axis (the log's ticks are the device's 100 MHz real-time counter): per launch and per

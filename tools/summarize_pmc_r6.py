@@ -36,7 +36,8 @@ write, nw = counter_sum("pmc_write", "WRITE_SIZE", "k_maniac_decode")
 res = {"kernel": "k_maniac_decode", "batch": 1024, "mode": "groups", "round": 6,
        "FETCH_SIZE_KiB_per_launch": fetch / max(nf, 1), "WRITE_SIZE_KiB_per_launch": write / max(nw, 1), "calibration": cal}
 f_sn = cal["snode4"]["factor"] or 1.0
-f_lf = cal["read32"]["factor"] or 1.0
+# a 32-byte leaf costs a whole 64-byte fetch (the counter shows 64 bytes per record: factor 0.5 against the REQUESTED bytes): for HBM traffic the counter is right as it is
+f_lf = max(cal["read32"]["factor"] or 1.0, 1.0)
 f_w = cal["write32"]["factor"] or 1.0
 # Requested read bytes per symbol of the headline streams (narrow supernodes, compact leaves; tools/supernode_packing.py, profiles/r6_phases_by_channel_narrow.txt):
 # ~1.35 supernodes of 256 bytes behind the root and ~0.98 leaves of 32 bytes: 92 % of the requested context bytes are supernode bytes.  Both factors are
