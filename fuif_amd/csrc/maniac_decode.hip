@@ -796,7 +796,6 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
     __shared__ Shared<kLdsSuper> sh;
     constexpr int kChunk = Shared<kLdsSuper>::kChunk;
     constexpr int kLdsN = Shared<kLdsSuper>::kLdsN;          // narrow supernodes resident in LDS (behind the root)
-    constexpr bool kDense = Shared<kLdsSuper>::kDense;
     const int lane = threadIdx.x;
     uint32_t *const lds_narrow = reinterpret_cast<uint32_t *>(sh.snodes);   // (a narrow group keeps 2 * kLdsSuper supernodes of 256 bytes there)
 
@@ -1582,9 +1581,6 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
             __syncthreads();
         }
         }  // !resumed
-#ifdef FUIF_EMU_DEBUG
-        if (lane == 0 || lane == 20) fprintf(stderr, "group c%d: lane %d tree %d n_super %d narrow %d compact %d nprops %d ctx %d resumed %d\n", ci, lane, tree_size, n_super, (int)narrow, (int)compact, nprops, ctx_slot, (int)resumed);
-#endif
         const uint2 root_nd = narrow ? uint2{0u, 0u} : snodes_g[lane];  // the root supernode lives in registers
         const uint32_t root_w = narrow ? reinterpret_cast<const uint32_t *>(snodes_g)[lane] : 0u;
         LeafRegs L;
@@ -1649,7 +1645,6 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                 auto rows = [&](auto pred0_tag, auto narrow_tag) {
                     constexpr bool PRED0 = decltype(pred0_tag)::value;
                     constexpr bool NARROW = decltype(narrow_tag)::value;   // 4-byte supernode lane words (kLeafFlagN)
-                    using prop_t = int32_t;
                     for (; y < h; y++) {
                         if (s_limit_hit(s)) break;
                         __syncthreads();  // the previous row's stores are complete before it is re-read as `top`
@@ -1715,14 +1710,14 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                             const int vtr = (x + 1 < w && y) ? row1[x + 1] : vtop;         // context_predict.h:129
                             const int vtt = y > 1 ? row2[x] : vtop;                        // :133
                             if (lane < chunk_px) {
-                                prop_t *cp = reinterpret_cast<prop_t *>(sh.cprops) + lane * prop_pitch;
+                                int32_t *cp = sh.cprops + lane * prop_pitch;
                                 // (more than kFastRefs references, -E > 18: the rest one by one -- rare, and its chunks are half as long)
                                 for (int k = kFastRefs; k < nrefs; k++) {
                                     const RefChan rc = sh.refs[k];
                                     int ry = (y << gvs) >> rc.vshift; if (ry >= rc.h) ry = rc.h - 1;
                                     int rx = ghs < 0 ? rc.w - 1 : (x << ghs) >> rc.hshift; if (rx >= rc.w) rx = rc.w - 1;
                                     const int v = ld_plane<kHandOff>(coef + rc.off + (int64_t)ry * rc.w + rx);
-                                    cp[2 * k] = (prop_t)iabs(v); cp[2 * k + 1] = (prop_t)slog(v);
+                                    cp[2 * k] = iabs(v); cp[2 * k + 1] = slog(v);
                                 }
                                 // The reference samples of this pixel: every load is a memory round trip (another tile's plane, read past the L1), so the
                                 // loads of up to 6 references -- what the default options give -- are ISSUED TOGETHER and consumed afterwards.  (Rounds 1-5
@@ -1742,25 +1737,25 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                 static_assert(kFastRefs == 9, "the reference loads are issued in batches of 6 + 3");
                                 if (nrefs > 0) {
                                     const int r0 = ref_sample(0), r1 = ref_sample(1), r2 = ref_sample(2), r3 = ref_sample(3), r4 = ref_sample(4), r5 = ref_sample(5);
-                                    cp[0] = (prop_t)iabs(r0); cp[1] = (prop_t)slog(r0);
-                                    if (nrefs > 1) { cp[2] = (prop_t)iabs(r1); cp[3] = (prop_t)slog(r1); }
-                                    if (nrefs > 2) { cp[4] = (prop_t)iabs(r2); cp[5] = (prop_t)slog(r2); }
-                                    if (nrefs > 3) { cp[6] = (prop_t)iabs(r3); cp[7] = (prop_t)slog(r3); }
-                                    if (nrefs > 4) { cp[8] = (prop_t)iabs(r4); cp[9] = (prop_t)slog(r4); }
-                                    if (nrefs > 5) { cp[10] = (prop_t)iabs(r5); cp[11] = (prop_t)slog(r5); }
+                                    cp[0] = iabs(r0); cp[1] = slog(r0);
+                                    if (nrefs > 1) { cp[2] = iabs(r1); cp[3] = slog(r1); }
+                                    if (nrefs > 2) { cp[4] = iabs(r2); cp[5] = slog(r2); }
+                                    if (nrefs > 3) { cp[6] = iabs(r3); cp[7] = slog(r3); }
+                                    if (nrefs > 4) { cp[8] = iabs(r4); cp[9] = slog(r4); }
+                                    if (nrefs > 5) { cp[10] = iabs(r5); cp[11] = slog(r5); }
                                     if (nrefs > 6) {
                                         const int r6 = ref_sample(6), r7 = ref_sample(7), r8 = ref_sample(8);
-                                        cp[12] = (prop_t)iabs(r6); cp[13] = (prop_t)slog(r6);
-                                        if (nrefs > 7) { cp[14] = (prop_t)iabs(r7); cp[15] = (prop_t)slog(r7); }
-                                        if (nrefs > 8) { cp[16] = (prop_t)iabs(r8); cp[17] = (prop_t)slog(r8); }
+                                        cp[12] = iabs(r6); cp[13] = slog(r6);
+                                        if (nrefs > 7) { cp[14] = iabs(r7); cp[15] = slog(r7); }
+                                        if (nrefs > 8) { cp[16] = iabs(r8); cp[17] = slog(r8); }
                                     }
                                 }
-                                prop_t *q = cp + nrefprops;
-                                q[0] = (prop_t)iabs(vtop); q[2] = (prop_t)slog(vtop); q[4] = (prop_t)y; q[5] = (prop_t)(x0 + lane);
-                                q[10] = (prop_t)slog(vtop - vtr); q[11] = (prop_t)slog(vtop - vtt);
+                                int32_t *q = cp + nrefprops;
+                                q[0] = iabs(vtop); q[2] = slog(vtop); q[4] = y; q[5] = (x0 + lane);
+                                q[10] = slog(vtop - vtr); q[11] = slog(vtop - vtt);
                                 q[1] = 0; q[3] = 0; q[12] = 0;
-                                if (y) { q[6] = (prop_t)(vtop - vtl); q[7] = (prop_t)(vtl + vtr - vtop); q[8] = (prop_t)-vtl; q[9] = (prop_t)(vtl - vtop); }
-                                else { q[6] = (prop_t)zero; q[7] = 0; q[8] = 0; q[9] = (prop_t)-zero; }
+                                if (y) { q[6] = (vtop - vtl); q[7] = (vtl + vtr - vtop); q[8] = -vtl; q[9] = (vtl - vtop); }
+                                else { q[6] = zero; q[7] = 0; q[8] = 0; q[9] = -zero; }
                             }
                             __syncthreads();
                             PROF_LAP(0);
@@ -1773,12 +1768,12 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                             // leftleft = value at x-2, except at x == 1 where the rule is leftleft = left (context_predict.h:131): the first
                             // pixel of a row is a loop part of its own, so that the rule costs nothing per pixel
                             const int j_split = x0 == 0 ? 1 : 0;
-                            const prop_t *prow = reinterpret_cast<const prop_t *>(sh.cprops) + (lane & prop_mask);
+                            const int32_t *prow = &sh.cprops[lane & prop_mask];
                             for (int part = 0; part < 2; part++) {
                             const int j_end = part ? nx : j_split;
                             for (int j = part ? j_split : 0; j < j_end; j++) {
                                 PROF_START();
-                                int pv = (int)*prow; prow += prop_pitch;   // cprops[j * prop_pitch + (lane & prop_mask)]
+                                int pv = *prow; prow += prop_pitch;   // cprops[j * prop_pitch + (lane & prop_mask)]
                                 const int l = left;
                                 {
                                     const int d = pv + (l & m_left) + (-leftleft & m_ll);
@@ -1836,9 +1831,6 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                         EMU_COUNT(0);
                                         while (!(tgt & kLeafFlagN)) {
                                             EMU_COUNT(tgt <= (uint32_t)kLdsN ? 1 : 2);
-#ifdef FUIF_EMU_DEBUG
-                                            if ((int)tgt >= n_super || tgt == 0) { fprintf(stderr, "narrow walk: tgt %u n_super %d tree %d lane %d\n", tgt, n_super, tree_size, lane); abort(); }
-#endif
                                             uint32_t w;
                                             if (kLdsN > 0) {
                                                 const uint32_t li = tgt <= (uint32_t)kLdsN ? tgt : (uint32_t)kLdsN;
@@ -1848,9 +1840,6 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                             tgt = walk_round_n(w);
                                         }
                                         tgt &= kLeafFlagN - 1u;
-#ifdef FUIF_EMU_DEBUG
-                                        if ((int)tgt >= (tree_size + 1) / 2) { fprintf(stderr, "narrow walk: leaf %u of %d\n", tgt, (tree_size + 1) / 2); abort(); }
-#endif
                                     } else {
                                     tgt = walk_round(root_nd);
                                     EMU_COUNT(0);
