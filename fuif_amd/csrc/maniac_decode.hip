@@ -33,7 +33,13 @@
 // the per-symbol chain (and by two dependent HBM round trips per symbol: a supernode, the leaf); every
 // item above trades scalar instructions for vector ones.  Measured on the 1024 x 4K launch (round 4,
 // profiles/r4_instruction_probes.txt): one more scalar instruction per symbol costs 0.37 % of the launch,
-// a vector one 0.19 %, a taken branch 0.44 % -- ~165 instructions per symbol since round 4 (was 202).
+// a vector one 0.19 %, a taken branch 0.44 % -- ~200 instructions per symbol on the ISA of the pixel loop, 122 of them the symbol decoder.
+// Round 6: the context of a group comes in two supernode forms (8-byte lane words; NARROW 4-byte ones when every property lies inside
+// 13 bits: kLeafFlagN below) and two leaf forms (31 chances in 64 bytes; COMPACT 16 chances in 32 bytes when the symbols have at most 8 magnitude bits:
+// LeafRegs::mb), chosen per group and carried in the tile record; context areas have the exact size of their context and come from one two-ended arena;
+// the reference loads of a pixel chunk are issued together.  With every wavefront slot busy the launch is bound by what a SIMD ISSUES (LDS-resident
+// supernodes in the dense configuration made a long group 7 % faster and the launch 4.7 % slower: removed), so nothing here may add an instruction
+// to the per-symbol path lightly.
 // Three LDS configurations are built: "wide" for a launch alone = 38.9 KB per wave (58 supernodes = 29 KB, 8.4 KB of chunk properties,
 // small state; one wave per SIMD), "wide" for hosts with two batches in flight = 19.7 KB (20 supernodes; exactly two waves per SIMD:
 // fuifgpu_batch_set_in_flight, round 5) and "dense" = 5.7 KB (no supernode slots, 32-pixel chunks;
