@@ -610,17 +610,48 @@ DEV int fast_symbol(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
 #define FS_VC "v125"
 #define FS_VA "v127"
 #endif
-#define FS_THR_PREP "v_mad_u64_u32 " FS_VBC ", vcc, %[R], %[leafv], " FS_VK "\n\tv_alignbit_b32 " FS_VA ", " FS_VC ", " FS_VB ", 12\n\tv_sub_u32 " FS_VA ", %[R], " FS_VA "\n\t"
+// (the _R forms take the register that holds `range` at that point: the unrolled exponent decisions below leave the threshold they read where it is when it
+// becomes the new range, instead of copying it)
+#define FS_THR_PREP_R(Rr) "v_mad_u64_u32 " FS_VBC ", vcc, " Rr ", %[leafv], " FS_VK "\n\tv_alignbit_b32 " FS_VA ", " FS_VC ", " FS_VB ", 12\n\tv_sub_u32 " FS_VA ", " Rr ", " FS_VA "\n\t"
+#define FS_THR_PREP FS_THR_PREP_R("%[R]")
 // one or two bytes from the window registers into `low` (rac.h:70-81), then back to label `back`
-#define FS_RENORM(lbl, back) \
+// (a second byte is needed only after a decision whose chance left less than 1/256 of the range: the stub then runs once more instead of carrying a second copy --
+// every decision site has its own stub, and the decoder's code size is what the deeper unrolling lost to: profiles/r6_unrolled_decoder.txt)
+#define FS_RENORM_R(lbl, back, Rr) \
     lbl ":\n\t" \
     "s_lshr_b32 %[t0], %[widx], 2\n\tv_readlane_b32 %[t0], %[win], %[t0]\n\ts_lshl_b32 %[t1], %[widx], 3\n\ts_lshr_b32 %[t0], %[t0], %[t1]\n\t" \
-    "s_and_b32 %[t0], %[t0], 0xff\n\ts_lshl_b32 %[L], %[L], 8\n\ts_or_b32 %[L], %[L], %[t0]\n\ts_add_u32 %[widx], %[widx], 1\n\ts_lshl_b32 %[R], %[R], 8\n\t" \
-    "s_cmp_gt_u32 %[R], 0x10000\n\ts_cbranch_scc1 " back "\n\t" \
-    "s_lshr_b32 %[t0], %[widx], 2\n\tv_readlane_b32 %[t0], %[win], %[t0]\n\ts_lshl_b32 %[t1], %[widx], 3\n\ts_lshr_b32 %[t0], %[t0], %[t1]\n\t" \
-    "s_and_b32 %[t0], %[t0], 0xff\n\ts_lshl_b32 %[L], %[L], 8\n\ts_or_b32 %[L], %[L], %[t0]\n\ts_add_u32 %[widx], %[widx], 1\n\ts_lshl_b32 %[R], %[R], 8\n\t" \
-    "s_branch " back "\n\t"
-#define FS_RN_CHECK(lbl, back) "s_cmp_le_u32 %[R], 0x10000\n\ts_cbranch_scc1 " lbl "\n" back ":\n\t"
+    "s_and_b32 %[t0], %[t0], 0xff\n\ts_lshl_b32 %[L], %[L], 8\n\ts_or_b32 %[L], %[L], %[t0]\n\ts_add_u32 %[widx], %[widx], 1\n\ts_lshl_b32 " Rr ", " Rr ", 8\n\t" \
+    "s_cmp_gt_u32 " Rr ", 0x10000\n\ts_cbranch_scc1 " back "\n\t" \
+    "s_branch " lbl "b\n\t"
+#define FS_RENORM(lbl, back) FS_RENORM_R(lbl, back, "%[R]")
+#define FS_RN_CHECK_R(lbl, back, Rr) "s_cmp_le_u32 " Rr ", 0x10000\n\ts_cbranch_scc1 " lbl "\n" back ":\n\t"
+#define FS_RN_CHECK(lbl, back) FS_RN_CHECK_R(lbl, back, "%[R]")
+// Round 6, last session: the first four exponent decisions (chances 2..5) UNROLLED, each with its own exit that knows e: no chance-index add, loop-end test or
+// taken back-branch per decision, the threshold read stays where it is when it becomes the new range (Rr / Tr swap roles from one decision to the next), and the
+// exit of e = k - 2 runs exactly e mantissa decisions without a counter test and builds the (index, bit) masks from constants.  Needs ilast >= 4 (emax >= 3;
+// chance 5 is tested separately); smaller ranges and exponents beyond chance 5 take the loops below, as in rounds 4-5.  Six unrolled decisions were slower
+// (profiles/r6_unrolled_decoder.txt: the channels whose range ends below chance 7 fall back to the loops).
+#define FS_UEXP(k, Rr, Tr, exitl, rnl, backl) \
+    FS_THR_PREP_R(Rr) "s_nop 0\n\tv_readlane_b32 " Tr ", " FS_VA ", " k "\n\t" \
+    "s_cmp_ge_u32 %[L], " Tr "\n\ts_cbranch_scc1 " exitl "\n\t" \
+    FS_RN_CHECK_R(rnl, backl, Tr)
+#define FS_EXIT_HEAD(lbl, Rr, Tr, rnl, backl) \
+    lbl ":\n\t" \
+    "s_sub_u32 %[L], %[L], " Tr "\n\ts_sub_u32 %[R], " Rr ", " Tr "\n\t" \
+    FS_RN_CHECK(rnl, backl)
+#define FS_MINIT(e) "s_add_u32 %[midx], %[mb], " e "\n\ts_mov_b32 %[hv], 0\n\t"
+#define FS_MBIT(rnl, backl) \
+    FS_THR_PREP "s_sub_u32 %[midx], %[midx], 1\n\tv_readlane_b32 %[thr], " FS_VA ", %[midx]\n\t" \
+    "s_sub_u32 %[t0], %[R], %[thr]\n\ts_sub_u32 %[t1], %[L], %[thr]\n\t" \
+    "s_cselect_b32 %[L], %[L], %[t1]\n\ts_cselect_b32 %[R], %[thr], %[t0]\n\ts_addc_u32 %[hv], %[hv], %[hv]\n\t" \
+    FS_RN_CHECK(rnl, backl)
+// e >= 1, closing 1 at chance k = e + 2, tl = (1 << (k + 1)) - 1: the zero, sign and exponent chances touched
+#define FS_MASKS(e, k, tl) \
+    "s_bfm_b32 %[t1], " e ", %[mb]\n\ts_or_b32 %[touched], %[t1], " tl "\n\t" \
+    "s_lshl_b32 %[t0], %[hv], %[mb]\n\ts_andn2_b32 %[t0], %[t1], %[t0]\n\t" \
+    "s_andn2_b32 %[t1], 2, %[sm]\n\ts_or_b32 %[bits], %[t0], %[t1]\n\ts_bitset1_b32 %[bits], " k "\n\t" \
+    "s_lshr_b32 %[t0], %[t0], %[mb]\n\ts_bitset1_b32 %[t0], " e "\n\t" \
+    "s_xor_b32 %[t0], %[t0], %[sm]\n\ts_sub_u32 %[res], %[t0], %[sm]\n\t"
 // (Round 4 measured what one more scalar / vector instruction / taken branch per symbol costs the launch with probe builds of this block: +0.37 % / +0.19 % /
 // +0.44 %, profiles/r4_instruction_probes.txt; the probe macros left the source in round 5 -- `git log -S FUIF_PROBE_S` has them.)
 DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
@@ -639,14 +670,24 @@ DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
         // ---- zero?  (chance 0)
         FS_THR_PREP "s_nop 0\n\tv_readlane_b32 %[thr], " FS_VA ", 0\n\t"
         "s_cmp_ge_u32 %[L], %[thr]\n\ts_cbranch_scc1 70f\n\t"
-        "s_mov_b32 %[R], %[thr]\n\t"
-        FS_RN_CHECK("91f", "81")
+        FS_RN_CHECK_R("91f", "81", "%[thr]")   // (not zero: the threshold IS the new range and stays in %[thr]; the sign's threshold is read into %[R])
         // ---- sign  (chance 1): bit 1 = positive.  sm = 0 for positive, -1 for negative
-        FS_THR_PREP "s_nop 0\n\tv_readlane_b32 %[thr], " FS_VA ", 1\n\t"
-        "s_sub_u32 %[t0], %[R], %[thr]\n\ts_sub_u32 %[t1], %[L], %[thr]\n\t"
-        "s_cselect_b32 %[L], %[L], %[t1]\n\ts_cselect_b32 %[R], %[thr], %[t0]\n\ts_cselect_b32 %[sm], -1, 0\n\ts_cselect_b32 %[ilast], %[ilastn], %[ilastp]\n\t"
+        FS_THR_PREP_R("%[thr]") "s_nop 0\n\tv_readlane_b32 %[R], " FS_VA ", 1\n\t"
+        "s_sub_u32 %[t0], %[thr], %[R]\n\ts_sub_u32 %[t1], %[L], %[R]\n\t"
+        "s_cselect_b32 %[L], %[L], %[t1]\n\ts_cselect_b32 %[R], %[R], %[t0]\n\ts_cselect_b32 %[sm], -1, 0\n\ts_cselect_b32 %[ilast], %[ilastn], %[ilastp]\n\t"
         FS_RN_CHECK("92f", "82")
         // ---- unary exponent  (chances 2 .. emax + 1 = ilast); idx = the chance decided last
+        // ---- chances 2..5 unrolled (ilast >= 4; chance 5 only when ilast >= 5); a 1 leaves through 102..105 with e = 0..3
+        "s_cmp_lt_u32 %[ilast], 4\n\ts_cbranch_scc1 19f\n\t"
+        FS_UEXP("2", "%[R]", "%[thr]", "102f", "112f", "122")
+        FS_UEXP("3", "%[thr]", "%[R]", "103f", "113f", "123")
+        FS_UEXP("4", "%[R]", "%[thr]", "104f", "114f", "124")
+        "s_cmp_lt_u32 %[ilast], 5\n\ts_cbranch_scc1 18f\n\t"          // emax = 3: chance 4 was the last one, the exponent is exhausted
+        FS_UEXP("5", "%[thr]", "%[R]", "105f", "115f", "125")
+        "s_mov_b32 %[idx], 5\n\ts_cmp_lt_u32 %[idx], %[ilast]\n\ts_cbranch_scc1 20f\n\ts_branch 40f\n"
+        "18:\n\t"
+        "s_mov_b32 %[R], %[thr]\n\ts_mov_b32 %[idx], 4\n\ts_branch 40f\n"
+        "19:\n\t"
         "s_mov_b32 %[idx], 1\n\ts_cmp_lt_u32 %[idx], %[ilast]\n\ts_cbranch_scc0 40f\n"
         "20:\n\t"
         FS_THR_PREP "s_add_u32 %[idx], %[idx], 1\n\tv_readlane_b32 %[thr], " FS_VA ", %[idx]\n\t"
@@ -708,7 +749,18 @@ DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
         "s_sub_u32 %[L], %[L], %[thr]\n\ts_sub_u32 %[R], %[R], %[thr]\n\ts_mov_b32 %[res], 0\n\ts_mov_b32 %[touched], 1\n\ts_mov_b32 %[bits], 1\n\t"
         FS_RN_CHECK("95f", "85")
         "s_branch 99f\n"
-        FS_RENORM("91", "81b") FS_RENORM("92", "82b") FS_RENORM("93", "83b") FS_RENORM("94", "84b") FS_RENORM("95", "85b") FS_RENORM("96", "86b")
+        FS_RENORM_R("91", "81b", "%[thr]") FS_RENORM("92", "82b") FS_RENORM("93", "83b") FS_RENORM("94", "84b") FS_RENORM("95", "85b") FS_RENORM("96", "86b")
+        // ---- the exits of the unrolled exponent: e = 0 (value +-1), 2, 3; e = 1 comes last and falls through to the end
+        FS_EXIT_HEAD("102", "%[R]", "%[thr]", "132f", "142")
+        "s_mov_b32 %[touched], 7\n\ts_andn2_b32 %[t1], 2, %[sm]\n\ts_or_b32 %[bits], %[t1], 4\n\ts_or_b32 %[res], %[sm], 1\n\ts_branch 99f\n"
+        FS_EXIT_HEAD("104", "%[R]", "%[thr]", "134f", "144") FS_MINIT("2") FS_MBIT("152f", "162") FS_MBIT("153f", "163") FS_MASKS("2", "4", "31") "s_branch 99f\n"
+        FS_EXIT_HEAD("105", "%[thr]", "%[R]", "135f", "145") FS_MINIT("3") FS_MBIT("154f", "164") FS_MBIT("155f", "165") FS_MBIT("156f", "166") FS_MASKS("3", "5", "63") "s_branch 99f\n"
+        FS_RENORM("115", "125b") FS_RENORM("135", "145b") FS_RENORM("154", "164b") FS_RENORM("155", "165b") FS_RENORM("156", "166b")
+        FS_RENORM_R("112", "122b", "%[thr]") FS_RENORM("113", "123b") FS_RENORM_R("114", "124b", "%[thr]")
+        FS_RENORM("132", "142b") FS_RENORM("134", "144b")
+        FS_RENORM("152", "162b") FS_RENORM("153", "163b")
+        FS_RENORM("133", "143f") FS_RENORM("151", "161f")
+        FS_EXIT_HEAD("103", "%[thr]", "%[R]", "133b", "143") FS_MINIT("1") FS_MBIT("151b", "161") FS_MASKS("1", "3", "15")
         "99:\n\t"
         : [R] "+s"(R), [L] "+s"(Lo), [widx] "+s"(widx), [res] "=&s"(res), [touched] "=&s"(touched), [bits] "=&s"(bits), [t0] "=&s"(t0),
           [t1] "=&s"(t1), [thr] "=&s"(thr), [idx] "=&s"(idx), [ilast] "=&s"(ilast), [sm] "=&s"(sm), [hv] "=&s"(hv), [e] "=&s"(e),

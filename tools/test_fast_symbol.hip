@@ -84,6 +84,9 @@ int main(int argc, char **argv) {
         k.pos = rnd() % 190;
         k.amax_pos = 1 + rnd() % (mode == 3 ? 3 : mode == 4 ? 32767 : (c & 2) ? 255 : 600);
         k.amax_neg = 1 + rnd() % (mode == 3 ? 2 : mode == 4 ? 32767 : (c & 2) ? 255 : 600);
+        // the ranges at which the unrolled exponent decisions of fast_symbol_hw end: emax = 3 (chance 4 is the last one), 4 and 5
+        if (c % 16 == 11) { k.amax_pos = 8 + rnd() % 8; k.amax_neg = 8 + rnd() % 8; }
+        if (c % 16 == 13) { k.amax_pos = 8 + rnd() % 56; k.amax_neg = 16 + rnd() % 16; }
         for (int i = 0; i < 32; i++) {
             k.chances[i] = 1 + rnd() % 4095;
             if (mode == 5) k.chances[i] = 1 + rnd() % 40;              // tiny chances: double renormalisations
@@ -103,10 +106,12 @@ int main(int argc, char **argv) {
     std::vector<Result> res(n);
     hipMemcpy(res.data(), d_res, sizeof(Result) * n, hipMemcpyDeviceToHost);
     int bad = 0, commit_bad = 0, bperm_bad = 0, zero = 0, exhausted = 0;
+    int by_e[16] = {0};   // nonzero symbols by exponent (the decoder has its own exit for e = 0..3 and a loop beyond)
     for (int c = 0; c < n; c++) {
         const Result &r = res[c];
         const bool same = r.res[0] == r.res[1] && r.range[0] == r.range[1] && r.low[0] == r.low[1] && r.pos[0] == r.pos[1] && r.touched[0] == r.touched[1] && r.bits[0] == r.bits[1];
         zero += r.res[0] == 0;
+        if (r.res[0]) { int a = abs(r.res[0]), e = 0; while (a >> (e + 1)) e++; by_e[e < 15 ? e : 15]++; }
         if (!same && bad++ < 12)
             printf("case %d (range %x low %x pos %u amax %u/%u): spec res %d R %x L %x pos %u touched %x bits %x | hw res %d R %x L %x pos %u touched %x bits %x\n", c, cases[c].range,
                    cases[c].low, cases[c].pos, cases[c].amax_pos, cases[c].amax_neg, r.res[0], r.range[0], r.low[0], r.pos[0], r.touched[0], r.bits[0], r.res[1], r.range[1], r.low[1],
@@ -114,5 +119,8 @@ int main(int argc, char **argv) {
         commit_bad += r.commit_bad != 0; bperm_bad += r.bperm_bad != 0;
     }
     printf("%d cases: %d decoder mismatches, %d commit mismatches, %d bpermute mismatches (%d zero symbols)\n", n, bad, commit_bad, bperm_bad, zero);
+    printf("nonzero symbols by exponent:");
+    for (int e = 0; e < 16; e++) printf(" %d", by_e[e]);
+    printf("\n");
     return bad || commit_bad || bperm_bad ? 1 : 0;
 }
