@@ -645,16 +645,17 @@ DEV int fast_symbol(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
     "s_sub_u32 %[t0], %[R], %[thr]\n\ts_sub_u32 %[t1], %[L], %[thr]\n\t" \
     "s_cselect_b32 %[L], %[L], %[t1]\n\ts_cselect_b32 %[R], %[thr], %[t0]\n\ts_addc_u32 %[hv], %[hv], %[hv]\n\t" \
     FS_RN_CHECK(rnl, backl)
-// e >= 1, closing 1 at chance k = e + 2, tl = (1 << (k + 1)) - 1: the zero, sign and exponent chances touched
-#define FS_MASKS(e, k, tl) \
+// e >= 1, closing 1 at chance k = e + 2, tl = (1 << (k + 1)) - 1: the zero, sign and exponent chances touched, ml = (1 << e) - 1
+#define FS_MASKS(e, k, tl, ml) \
+    "s_andn2_b32 %[t0], " ml ", %[hv]\n\ts_lshl_b32 %[t1], %[t0], %[mb]\n\t"                                /* the mantissa as decided (hv holds it inverted); at mb .. */ \
+    "s_andn2_b32 %[bits], 2, %[sm]\n\ts_or_b32 %[bits], %[bits], %[t1]\n\ts_bitset1_b32 %[bits], " k "\n\t"   /* + the sign decision + the exponent's closing 1 */ \
     "s_bfm_b32 %[t1], " e ", %[mb]\n\ts_or_b32 %[touched], %[t1], " tl "\n\t" \
-    "s_lshl_b32 %[t0], %[hv], %[mb]\n\ts_andn2_b32 %[t0], %[t1], %[t0]\n\t" \
-    "s_andn2_b32 %[t1], 2, %[sm]\n\ts_or_b32 %[bits], %[t0], %[t1]\n\ts_bitset1_b32 %[bits], " k "\n\t" \
-    "s_lshr_b32 %[t0], %[t0], %[mb]\n\ts_bitset1_b32 %[t0], " e "\n\t" \
-    "s_xor_b32 %[t0], %[t0], %[sm]\n\ts_sub_u32 %[res], %[t0], %[sm]\n\t"
+    "s_bitset1_b32 %[t0], " e "\n\ts_xor_b32 %[t0], %[t0], %[sm]\n\ts_sub_u32 %[res], %[t0], %[sm]\n\t"       /* magnitude = 1 << e | mantissa, signed */
 // (Round 4 measured what one more scalar / vector instruction / taken branch per symbol costs the launch with probe builds of this block: +0.37 % / +0.19 % /
 // +0.44 %, profiles/r4_instruction_probes.txt; the probe macros left the source in round 5 -- `git log -S FUIF_PROBE_S` has them.)
-DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
+// (widx = the stream position inside the window registers `win`: the pixel loop of a chunk whose bytes are all in the stream carries it from symbol to symbol
+// instead of converting to and from Stream::pos around every symbol)
+DEV int fast_symbol_hw_w(Rac &r, uint32_t &widx_io, const uint32_t win, LeafRegs &L, const FastSym &F) {
     // Round 4 (profiles/r4_instruction_probes.txt: a scalar instruction or a taken branch costs the launch twice a vector one):
     //   * a decision is `s_sub t, low, thr`: SCC = borrow = (low < thr) = NOT the bit, and three s_cselect / s_addc take it from there
     //     (no compare, no separate subtraction of the selected amount);
@@ -663,7 +664,7 @@ DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
     //     branches per bit (was 15 and 3), the bits collected INVERTED by s_addc and turned round once at the end;
     //   * the exhausted exponent (e == emax, under 1 % of the symbols) keeps the careful loop with the amax test per bit;
     //   * (index, bit) masks for leaf_commit from s_bfm_b32 fields.
-    uint32_t R = r.range, Lo = r.low, widx = s.pos - s.win_base;
+    uint32_t R = r.range, Lo = r.low, widx = widx_io;
     uint32_t res, touched, bits, t0, t1, thr, idx, ilast, sm, hv, e, midx, amax, have, skipped;
     asm volatile(
         "v_mov_b32 " FS_VK0 ", 0x800\n\tv_mov_b32 " FS_VK1 ", 0\n\t"
@@ -753,24 +754,30 @@ DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
         // ---- the exits of the unrolled exponent: e = 0 (value +-1), 2, 3; e = 1 comes last and falls through to the end
         FS_EXIT_HEAD("102", "%[R]", "%[thr]", "132f", "142")
         "s_mov_b32 %[touched], 7\n\ts_andn2_b32 %[t1], 2, %[sm]\n\ts_or_b32 %[bits], %[t1], 4\n\ts_or_b32 %[res], %[sm], 1\n\ts_branch 99f\n"
-        FS_EXIT_HEAD("104", "%[R]", "%[thr]", "134f", "144") FS_MINIT("2") FS_MBIT("152f", "162") FS_MBIT("153f", "163") FS_MASKS("2", "4", "31") "s_branch 99f\n"
-        FS_EXIT_HEAD("105", "%[thr]", "%[R]", "135f", "145") FS_MINIT("3") FS_MBIT("154f", "164") FS_MBIT("155f", "165") FS_MBIT("156f", "166") FS_MASKS("3", "5", "63") "s_branch 99f\n"
+        FS_EXIT_HEAD("104", "%[R]", "%[thr]", "134f", "144") FS_MINIT("2") FS_MBIT("152f", "162") FS_MBIT("153f", "163") FS_MASKS("2", "4", "31", "3") "s_branch 99f\n"
+        FS_EXIT_HEAD("105", "%[thr]", "%[R]", "135f", "145") FS_MINIT("3") FS_MBIT("154f", "164") FS_MBIT("155f", "165") FS_MBIT("156f", "166") FS_MASKS("3", "5", "63", "7") "s_branch 99f\n"
         FS_RENORM("115", "125b") FS_RENORM("135", "145b") FS_RENORM("154", "164b") FS_RENORM("155", "165b") FS_RENORM("156", "166b")
         FS_RENORM_R("112", "122b", "%[thr]") FS_RENORM("113", "123b") FS_RENORM_R("114", "124b", "%[thr]")
         FS_RENORM("132", "142b") FS_RENORM("134", "144b")
         FS_RENORM("152", "162b") FS_RENORM("153", "163b")
         FS_RENORM("133", "143f") FS_RENORM("151", "161f")
-        FS_EXIT_HEAD("103", "%[thr]", "%[R]", "133b", "143") FS_MINIT("1") FS_MBIT("151b", "161") FS_MASKS("1", "3", "15")
+        FS_EXIT_HEAD("103", "%[thr]", "%[R]", "133b", "143") FS_MINIT("1") FS_MBIT("151b", "161") FS_MASKS("1", "3", "15", "1")
         "99:\n\t"
         : [R] "+s"(R), [L] "+s"(Lo), [widx] "+s"(widx), [res] "=&s"(res), [touched] "=&s"(touched), [bits] "=&s"(bits), [t0] "=&s"(t0),
           [t1] "=&s"(t1), [thr] "=&s"(thr), [idx] "=&s"(idx), [ilast] "=&s"(ilast), [sm] "=&s"(sm), [hv] "=&s"(hv), [e] "=&s"(e),
           [midx] "=&s"(midx), [amax] "=&s"(amax), [have] "=&s"(have), [skipped] "=&s"(skipped)
-        : [leafv] "v"(L.leafv), [win] "v"(s.win), [amaxp] "s"(F.amax_pos), [amaxn] "s"(F.amax_neg), [ilastp] "s"(F.ilast_pos),
+        : [leafv] "v"(L.leafv), [win] "v"(win), [amaxp] "s"(F.amax_pos), [amaxn] "s"(F.amax_neg), [ilastp] "s"(F.ilast_pos),
           [ilastn] "s"(F.ilast_neg), [mb] "s"(L.mb), [mb2] "s"(L.mb - 2)
         : "scc", "vcc", FS_VA, FS_VB, FS_VC, FS_VK0, FS_VK1);
-    r.range = R; r.low = Lo; s.pos = s.win_base + widx;
+    r.range = R; r.low = Lo; widx_io = widx;
     L.touched = touched; L.bits = bits;
     return (int)res;
+}
+DEV int fast_symbol_hw(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
+    uint32_t widx = s.pos - s.win_base;
+    const int res = fast_symbol_hw_w(r, widx, s.win, L, F);
+    s.pos = s.win_base + widx;
+    return res;
 }
 #endif
 DEV void leaf_commit(LeafRegs &L, int lane, const uint16_t *table) {
@@ -1827,6 +1834,9 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                             // pixel of a row is a loop part of its own, so that the rule costs nothing per pixel
                             const int j_split = x0 == 0 ? 1 : 0;
                             const int32_t *prow = &sh.cprops[lane & prop_mask];
+#ifndef FUIF_EMU
+                            uint32_t widx = s.pos - s.win_base;   // (used by the kChunkFast instance only)
+#endif
                             for (int part = 0; part < 2; part++) {
                             const int j_end = part ? nx : j_split;
                             for (int j = part ? j_split : 0; j < j_end; j++) {
@@ -1940,14 +1950,28 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                                     if (kChunkFast || (PRED0 && sym_fast && LIKELY(s.pos + 64u <= s.size))) {
                                         // the symbol's bytes (at most 62) are in the stream; keep them in the window registers
                                         // (the reload starts at a 4-byte boundary; the 256 bytes it reads lie inside the allocation)
+#ifdef FUIF_EMU
                                         if (UNLIKELY(s.pos - s.win_base > 188u)) {
                                             s.win_base = s.pos & ~3u;
                                             s.win = reinterpret_cast<const uint32_t *>(s.p + s.win_base)[lane];
                                         }
-#ifdef FUIF_EMU
                                         diff = fast_symbol(rac, s, L, fsym);
 #else
-                                        diff = fast_symbol_hw(rac, s, L, fsym);
+                                        if constexpr (kChunkFast) {   // the position lives in widx for the whole chunk
+                                            if (UNLIKELY(widx > 188u)) {
+                                                s.pos = s.win_base + widx;
+                                                s.win_base = s.pos & ~3u;
+                                                widx = s.pos - s.win_base;
+                                                s.win = reinterpret_cast<const uint32_t *>(s.p + s.win_base)[lane];
+                                            }
+                                            diff = fast_symbol_hw_w(rac, widx, s.win, L, fsym);
+                                        } else {
+                                            if (UNLIKELY(s.pos - s.win_base > 188u)) {
+                                                s.win_base = s.pos & ~3u;
+                                                s.win = reinterpret_cast<const uint32_t *>(s.p + s.win_base)[lane];
+                                            }
+                                            diff = fast_symbol_hw(rac, s, L, fsym);
+                                        }
 #endif
                                     } else diff = leaf_symbol(rac, s, lane, L, mn, mx);
                                     PROF_LAP(4);
@@ -1962,6 +1986,9 @@ __global__ __launch_bounds__(64) FUIF_OCCUPANCY void k_maniac_decode(DecodeParam
                             }
                             if (part == 0 && j_split) leftleft = left;   // after x == 0
                             }
+#ifndef FUIF_EMU
+                            if constexpr (kChunkFast) s.pos = s.win_base + widx;
+#endif
                             };
                             if (PRED0 && sym_fast && s.pos + 64u * (uint32_t)(nx + 1) <= s.size) pixels(std::true_type{}); else pixels(std::false_type{});
                             PROF_START();
