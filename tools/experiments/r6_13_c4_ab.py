@@ -22,6 +22,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         print("%s n=%d 8192x8192x4: entropy launch %.1f ms, status %s" % (os.path.basename(os.environ.get("FUIF_AMD_LIB", "libfuifgpu.so")), n, batch.timing()[0], "ok" if not st.any() else "FLAGGED"), flush=True)
     sys.exit(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-for lib in ("build/libfuifgpu_r5.so", "fuif_amd/libfuifgpu.so", "build/libfuifgpu_r5.so", "fuif_amd/libfuifgpu.so"):
+# (C4_LIBS=a.so,b.so,... overrides the pair: the round's last session compared the library before and after the decoder rewrite)
+for lib in os.environ.get("C4_LIBS", "build/libfuifgpu_r5.so,fuif_amd/libfuifgpu.so,build/libfuifgpu_r5.so,fuif_amd/libfuifgpu.so").split(","):
     env = dict(os.environ, FUIF_AMD_LIB=os.path.join(ROOT, lib), FUIFGPU_CTX_MB="32")
     subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(n), "1"], env=env)
