@@ -632,8 +632,9 @@ DEV int fast_symbol(Rac &r, Stream &s, LeafRegs &L, const FastSym &F) {
 // Round 6, last session: the first four exponent decisions (chances 2..5) UNROLLED, each with its own exit that knows e: no chance-index add, loop-end test or
 // taken back-branch per decision, the threshold read stays where it is when it becomes the new range (Rr / Tr swap roles from one decision to the next), and the
 // exit of e = k - 2 runs exactly e mantissa decisions without a counter test and builds the (index, bit) masks from constants.  Needs ilast >= 4 (emax >= 3;
-// chance 5 is tested separately); smaller ranges and exponents beyond chance 5 take the loops below, as in rounds 4-5.  Six unrolled decisions were slower
-// (profiles/r6_unrolled_decoder.txt: the channels whose range ends below chance 7 fall back to the loops).
+// chances 5..9 are each tested for existence first); smaller ranges and exponents beyond chance 9 take the loops below, as in rounds 4-5.  The exits of
+// chances 6..9 (exponent 4..7) share one mantissa ladder and the loops' mask code at label 60.  (Six unrolled decisions WITHOUT the existence tests were slower
+// than the loops: the channels whose range ends below chance 7 fell back to them -- profiles/r6_unrolled_decoder.txt.)
 #define FS_UEXP(k, Rr, Tr, exitl, rnl, backl) \
     FS_THR_PREP_R(Rr) "s_nop 0\n\tv_readlane_b32 " Tr ", " FS_VA ", " k "\n\t" \
     "s_cmp_ge_u32 %[L], " Tr "\n\ts_cbranch_scc1 " exitl "\n\t" \
@@ -681,14 +682,27 @@ DEV int fast_symbol_hw_w(Rac &r, uint32_t &widx_io, const uint32_t win, LeafRegs
         "s_cselect_b32 %[L], %[L], %[t1]\n\ts_cselect_b32 %[R], %[R], %[t0]\n\ts_cselect_b32 %[sm], -1, 0\n\ts_cselect_b32 %[ilast], %[ilastn], %[ilastp]\n\t"
         FS_RN_CHECK("92f", "82")
         // ---- unary exponent  (chances 2 .. emax + 1 = ilast); idx = the chance decided last
-        // ---- chances 2..5 unrolled (ilast >= 4; chance 5 only when ilast >= 5); a 1 leaves through 102..105 with e = 0..3
+        // ---- chances 2..9 unrolled (ilast >= 4; chances 5..9 only where they exist); a 1 leaves through 102..109 with e = 0..7
         "s_cmp_lt_u32 %[ilast], 4\n\ts_cbranch_scc1 19f\n\t"
         FS_UEXP("2", "%[R]", "%[thr]", "102f", "112f", "122")
         FS_UEXP("3", "%[thr]", "%[R]", "103f", "113f", "123")
         FS_UEXP("4", "%[R]", "%[thr]", "104f", "114f", "124")
         "s_cmp_lt_u32 %[ilast], 5\n\ts_cbranch_scc1 18f\n\t"          // emax = 3: chance 4 was the last one, the exponent is exhausted
         FS_UEXP("5", "%[thr]", "%[R]", "105f", "115f", "125")
-        "s_mov_b32 %[idx], 5\n\ts_cmp_lt_u32 %[idx], %[ilast]\n\ts_cbranch_scc1 20f\n\ts_branch 40f\n"
+        // chances 6..9, each behind its own existence test (a channel's range may end anywhere here); their exits share one mantissa ladder
+        "s_cmp_lt_u32 %[ilast], 6\n\ts_cbranch_scc1 17f\n\t"
+        FS_UEXP("6", "%[R]", "%[thr]", "106f", "116f", "126")
+        "s_cmp_lt_u32 %[ilast], 7\n\ts_cbranch_scc1 16f\n\t"
+        FS_UEXP("7", "%[thr]", "%[R]", "107f", "117f", "127")
+        "s_cmp_lt_u32 %[ilast], 8\n\ts_cbranch_scc1 15f\n\t"
+        FS_UEXP("8", "%[R]", "%[thr]", "108f", "118f", "128")
+        "s_cmp_lt_u32 %[ilast], 9\n\ts_cbranch_scc1 14f\n\t"
+        FS_UEXP("9", "%[thr]", "%[R]", "109f", "119f", "129")
+        "s_mov_b32 %[idx], 9\n\ts_cmp_lt_u32 %[idx], %[ilast]\n\ts_cbranch_scc1 20f\n\ts_branch 40f\n"
+        "17:\n\ts_mov_b32 %[idx], 5\n\ts_branch 40f\n"
+        "16:\n\ts_mov_b32 %[R], %[thr]\n\ts_mov_b32 %[idx], 6\n\ts_branch 40f\n"
+        "15:\n\ts_mov_b32 %[idx], 7\n\ts_branch 40f\n"
+        "14:\n\ts_mov_b32 %[R], %[thr]\n\ts_mov_b32 %[idx], 8\n\ts_branch 40f\n"
         "18:\n\t"
         "s_mov_b32 %[R], %[thr]\n\ts_mov_b32 %[idx], 4\n\ts_branch 40f\n"
         "19:\n\t"
@@ -759,6 +773,15 @@ DEV int fast_symbol_hw_w(Rac &r, uint32_t &widx_io, const uint32_t win, LeafRegs
         "s_mov_b32 %[touched], 7\n\ts_andn2_b32 %[t1], 2, %[sm]\n\ts_or_b32 %[bits], %[t1], 4\n\ts_or_b32 %[res], %[sm], 1\n\ts_branch 99f\n"
         FS_EXIT_HEAD("104", "%[R]", "%[thr]", "134f", "144") FS_MINIT("2") FS_MBIT("152f", "162") FS_MBIT("153f", "163") FS_MASKS("2", "4", "31", "3") "s_branch 99f\n"
         FS_EXIT_HEAD("105", "%[thr]", "%[R]", "135f", "145") FS_MINIT("3") FS_MBIT("154f", "164") FS_MBIT("155f", "165") FS_MBIT("156f", "166") FS_MASKS("3", "5", "63", "7") "s_branch 99f\n"
+        FS_EXIT_HEAD("106", "%[R]", "%[thr]", "136f", "146") "s_mov_b32 %[idx], 6\n\t" FS_MINIT("4") "s_branch 204f\n"
+        FS_EXIT_HEAD("107", "%[thr]", "%[R]", "137f", "147") "s_mov_b32 %[idx], 7\n\t" FS_MINIT("5") "s_branch 205f\n"
+        FS_EXIT_HEAD("108", "%[R]", "%[thr]", "138f", "148") "s_mov_b32 %[idx], 8\n\t" FS_MINIT("6") "s_branch 206f\n"
+        FS_EXIT_HEAD("109", "%[thr]", "%[R]", "139f", "149") "s_mov_b32 %[idx], 9\n\t" FS_MINIT("7")
+        "207:\n\t" FS_MBIT("177f", "187") "206:\n\t" FS_MBIT("176f", "186") "205:\n\t" FS_MBIT("175f", "185") "204:\n\t" FS_MBIT("174f", "184")
+        FS_MBIT("173f", "183") FS_MBIT("172f", "182") FS_MBIT("171f", "181") "s_branch 60b\n"
+        FS_RENORM_R("116", "126b", "%[thr]") FS_RENORM("117", "127b") FS_RENORM_R("118", "128b", "%[thr]") FS_RENORM("119", "129b")
+        FS_RENORM("136", "146b") FS_RENORM("137", "147b") FS_RENORM("138", "148b") FS_RENORM("139", "149b")
+        FS_RENORM("171", "181b") FS_RENORM("172", "182b") FS_RENORM("173", "183b") FS_RENORM("174", "184b") FS_RENORM("175", "185b") FS_RENORM("176", "186b") FS_RENORM("177", "187b")
         FS_RENORM("115", "125b") FS_RENORM("135", "145b") FS_RENORM("154", "164b") FS_RENORM("155", "165b") FS_RENORM("156", "166b")
         FS_RENORM_R("112", "122b", "%[thr]") FS_RENORM("113", "123b") FS_RENORM_R("114", "124b", "%[thr]")
         FS_RENORM("132", "142b") FS_RENORM("134", "144b")
