@@ -41,8 +41,8 @@
 // supernodes in the dense configuration made a long group 7 % faster and the launch 4.7 % slower: removed), so nothing here may add an instruction
 // to the per-symbol path lightly.
 // The round's last session took instructions OUT (profiles/r6_sq_counters_final.txt: 171 instructions per decoded sample, 81 of them scalar, the scalar issue
-// slots the busier ones): fast_symbol_hw with its first four exponent decisions unrolled and an exit per exponent, ~25 scalar / branch instructions fewer for a
-// typical symbol, the launch 6.36 -> 6.02 s (profiles/r6_unrolled_decoder.txt).
+// slots the busier ones): fast_symbol_hw with the exponent decisions on chances 2..9 unrolled and an exit per exponent -- 159 instructions per sample, 71 scalar,
+// the launch 6.36 -> 6.02 s (profiles/r6_unrolled_decoder.txt).
 // Three LDS configurations are built: "wide" for a launch alone = 38.9 KB per wave (58 supernodes = 29 KB, 8.4 KB of chunk properties,
 // small state; one wave per SIMD), "wide" for hosts with two batches in flight = 19.7 KB (20 supernodes; exactly two waves per SIMD:
 // fuifgpu_batch_set_in_flight, round 5) and "dense" = 5.7 KB (no supernode slots, 32-pixel chunks;
